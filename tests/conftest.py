@@ -1,0 +1,57 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, os.path.join(ROOT, "tsp-gnn_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_pack(name, seed=0):
+    """A tests/golden/pack_*.npz fixture (outputs of the reference's create_batch) as a dict with
+    the instances re-assembled and ev_uv [M,2]."""
+    z = np.load(os.path.join(GOLDEN, "pack_%s_seed%d.npz" % (name, seed)))
+    n = int(z["n_instances"])
+    M = int(z["ev_shape"][0])
+    assert np.array_equal(z["ev_rows"], np.repeat(np.arange(M), 2))
+    out = {k: z[k] for k in ("W", "C", "route_exists", "n_vertices", "n_edges", "ev_shape")}
+    out["ev_uv"] = z["ev_cols"].reshape(M, 2)
+    out["dev"] = float(z["dev"])
+    tc = float(z["target_cost"])
+    out["target_cost"] = None if np.isnan(tc) else tc
+    out["instances"] = [(z["Ma_%d" % i].astype(int), z["Mw_%d" % i], [int(x) for x in z["route_%d" % i]])
+                        for i in range(n)]
+    if "EV_dense" in z.files:
+        out["EV_dense"] = z["EV_dense"]
+    return out
+
+
+def batch_from_tuple(t):
+    """create_batch 6-tuple (with SparseEV) -> oracle batch dict."""
+    EV, W, C, route_exists, n_vertices, n_edges = t
+    return {"ev_uv": EV.uv, "W": W, "C": C, "route_exists": route_exists, "n_vertices": n_vertices,
+            "n_edges": n_edges}
+
+
+@pytest.fixture(scope="session")
+def cuda_device():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test running without a HIP device")
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    """max |a-b| normalised by the scale of the reference tensor b."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(float(np.abs(b).max()), 1e-30)
+    return float(np.abs(a - b).max()) / scale

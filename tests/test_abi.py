@@ -1,0 +1,50 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/tspgnn.h
+declares; argument validation answers before any launch."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+from tspgnn import _lib
+
+HEADER = os.path.join(ROOT, "include", "tspgnn.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(tspgnn_\w+)\s*\(([^)]*)\)\s*;", src):
+        args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
+        out[m.group(1)] = args
+    return out
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    decl = declared_functions()
+    assert len(decl) >= 12
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name, args in decl.items():
+        assert hasattr(lib, name), "libtspgnn.so lacks %s" % name
+        if name in ("tspgnn_version", "tspgnn_last_error"):
+            continue
+        assert name in _lib.SIGNATURES, "no ctypes signature for %s" % name
+        assert len(_lib.SIGNATURES[name]) == len(args), name
+    for name in _lib.SIGNATURES:
+        assert name in decl, "%s bound but not declared in tspgnn.h" % name
+
+
+def test_version_and_error_string():
+    assert _lib.lib.tspgnn_version() == 1
+    status = _lib.lib.tspgnn_gather2_sum_f32(None, None, None, 4, 4, 3, None)   # d=3: rejected before launch
+    assert status == -1
+    assert b"multiple of 4" in _lib.lib.tspgnn_last_error()
+    try:
+        _lib.call("tspgnn_mlp_fwd_f32", None, None, None, None, 8, 48, 4, 7, None)
+        assert False
+    except _lib.TspgnnError as e:
+        assert e.status == -1 and "d=48" in str(e)
+    assert _lib.lib.tspgnn_lnlstm_fwd_f32(None, 8, None, None, None, None, None, None, 4, 64, None) == -1
+    # empty problems are a no-op, not an error
+    assert _lib.lib.tspgnn_gather2_sum_f32(None, None, None, 0, 0, 64, None) == 0
+    assert _lib.lib.tspgnn_segment_mean_f32(None, None, None, 0, None) == 0

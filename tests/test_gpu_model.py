@@ -1,0 +1,153 @@
+"""End-to-end parity of the HIP path (build_network / Session / GraphNN) with the CPU oracle on
+identical instances and identical weights.  Tolerance: 1e-5 relative on predictions / last
+states (BASELINE.json north_star), measured against the float64 oracle; the fp32 op-for-op
+restatement is shown next to it as the error any fp32 implementation carries."""
+import numpy as np
+import pytest
+import torch
+
+import tspgnn
+from conftest import batch_from_tuple, load_pack, rel_err
+from oracle import params as P
+from oracle import torch_oracle as TO
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+
+
+def run_hip(d, params, batch_tuple, T, fetch=("loss", "acc", "predictions", "TP", "FP", "TN", "FN", "last_states")):
+    model = tspgnn.build_network(d)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    EV, W, C, route_exists, n_vertices, n_edges = batch_tuple
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    vals = sess.run([model[k] for k in fetch], feed_dict=feed)
+    return dict(zip(fetch, vals))
+
+
+def pack_tuple(name, seed=0, dense=False):
+    g = load_pack(name, seed)
+    ev = tspgnn.SparseEV(g["ev_uv"], int(g["ev_shape"][1]))
+    return (ev.todense() if dense else ev, g["W"], g["C"], g["route_exists"], g["n_vertices"], g["n_edges"])
+
+
+@pytest.mark.parametrize("name,d,T", [("n5_B2", 32, 3), ("ragged_B6", 64, 4), ("sparse_B4", 64, 8),
+                                      ("n20_B32", 64, 8), ("target_B4", 32, 2), ("n20_B32", 128, 2)])
+def test_forward_parity_with_oracle(cuda_device, name, d, T):
+    t = pack_tuple(name)
+    params = P.init_params(d, seed=11, perturb=True)
+    hip = run_hip(d, params, t, T)
+    batch = {"ev_uv": t[0].uv, "W": t[1], "C": t[2], "route_exists": t[3], "n_vertices": t[4], "n_edges": t[5]}
+    ref = TO.forward(TO.to_torch(params, torch.float64), batch, T)
+    f32 = TO.forward(TO.to_torch(params, torch.float32), batch, T, dense=True)
+    e_pred = rel_err(hip["predictions"], ref["predictions"].numpy())
+    e_Eh = rel_err(hip["last_states"]["E"].h, ref["last_states"]["E"][0].numpy())
+    e_Vc = rel_err(hip["last_states"]["V"].c, ref["last_states"]["V"][1].numpy())
+    b_Eh = rel_err(f32["last_states"]["E"][0].numpy(), ref["last_states"]["E"][0].numpy())
+    print("\n[%s d=%d T=%d] HIP vs f64: pred %.2e  E.h %.2e  V.c %.2e | fp32 restatement vs f64: E.h %.2e"
+          % (name, d, T, e_pred, e_Eh, e_Vc, b_Eh))
+    assert e_pred < REL_TOL and e_Eh < REL_TOL and e_Vc < REL_TOL
+    assert abs(float(hip["loss"]) - ref["loss"].item()) < REL_TOL
+    for k in ("acc", "TP", "FP", "TN", "FN"):
+        assert float(hip[k]) == float(ref[k]), k
+
+
+def test_reference_hyperparameters_c1(cuda_device):
+    """BASELINE configs[0]: n=20, B=32, d=64, T=8 with the reference's initialisers."""
+    t = pack_tuple("n20_B32", 2)
+    params = P.init_params(64, seed=0)
+    hip = run_hip(64, params, t, 8)
+    batch = {"ev_uv": t[0].uv, "W": t[1], "C": t[2], "route_exists": t[3], "n_vertices": t[4], "n_edges": t[5]}
+    ref = TO.forward(TO.to_torch(params, torch.float64), batch, 8)
+    assert rel_err(hip["predictions"], ref["predictions"].numpy()) < REL_TOL
+    assert rel_err(hip["last_states"]["E"].h, ref["last_states"]["E"][0].numpy()) < REL_TOL
+
+
+def test_dense_feed_equals_sparse_feed(cuda_device):
+    params = P.init_params(32, seed=3, perturb=True)
+    a = run_hip(32, params, pack_tuple("ragged_B6", 1, dense=False), 3)
+    b = run_hip(32, params, pack_tuple("ragged_B6", 1, dense=True), 3)
+    assert np.array_equal(a["predictions"], b["predictions"])          # same kernels, same order: bit exact
+    assert np.array_equal(a["last_states"]["E"].c, b["last_states"]["E"].c)
+
+
+def test_zero_time_steps(cuda_device):
+    params = P.init_params(32, seed=5)
+    out = run_hip(32, params, pack_tuple("n5_B2"), 0)
+    V = out["last_states"]["V"]
+    assert np.all(V.c == 0)
+    assert rel_err(V.h, np.tile(params["V_init"] / np.sqrt(32.0), (V.h.shape[0], 1))) < 1e-6
+
+
+def test_block_diagonal_independence_on_device(cuda_device):
+    """Each problem's prediction in a ragged batch equals the prediction of that problem alone."""
+    g = load_pack("ragged_B6", 2)
+    params = P.init_params(64, seed=8, perturb=True)
+    whole = run_hip(64, params, pack_tuple("ragged_B6", 2), 4)
+    eo = np.concatenate([[0], np.cumsum(g["n_edges"])]); vo = np.concatenate([[0], np.cumsum(g["n_vertices"])])
+    for i in (0, 2, 5):
+        ev = tspgnn.SparseEV(g["ev_uv"][eo[i]:eo[i + 1]] - vo[i], int(g["n_vertices"][i]))
+        t = (ev, g["W"][eo[i]:eo[i + 1]], g["C"][eo[i]:eo[i + 1]], g["route_exists"][i:i + 1],
+             g["n_vertices"][i:i + 1], g["n_edges"][i:i + 1])
+        one = run_hip(64, params, t, 4)
+        assert abs(float(one["predictions"][0]) - float(whole["predictions"][i])) < 2e-6
+
+
+def test_generic_graphnn_wiring_two_inputs(cuda_device):
+    """A GraphNN the TSP model does not use: two loop entries for one variable (identity entry +
+    a valued, non-incidence matrix) -> concatenated cell input of width 2d (graphnn.py:142-173)."""
+    from tspgnn import variables as V
+    d = 32
+    store = V.VariableStore()
+    rng = np.random.RandomState(0)
+    A = (rng.randn(9, 7) * (rng.rand(9, 7) < 0.5)).astype(np.float32)       # valued "M": U x W
+    gnn = tspgnn.GraphNN({"U": d, "W": d}, {"M": ("U", "W")}, {"c": ("W", "U"), "b": ("U", "W")},
+                         {"U": [{"var": "U"}, {"mat": "M", "msg": "c", "var": "W"}],
+                          "W": [{"mat": "M", "transpose?": True, "msg": "b", "var": "U"}]}, name="G", store=store)
+    store.finalize(cuda_device); store.initialize(seed=4)
+    sd = {k: v.astype(np.float64) for k, v in store.state_dict().items()}
+    U0 = rng.randn(9, d).astype(np.float32); W0 = rng.randn(7, d).astype(np.float32)
+    out = gnn({"M": A}, {"U": torch.from_numpy(U0).to(cuda_device), "W": torch.from_numpy(W0).to(cuda_device)}, 3)
+    torch.cuda.synchronize()
+    # oracle of the same wiring from the NumPy helpers
+    from oracle import np_oracle as NO
+    def mlp(x, name):
+        return NO.mlp(x, [(sd["G/%s_MLP_layer_%d/kernel" % (name, i)], sd["G/%s_MLP_layer_%d/bias" % (name, i)])
+                          for i in range(1, 5)], [True, True, True, False])
+    def cell(x, h, c, v):
+        base = "G/%s_cell/layer_norm_basic_lstm_cell" % v
+        ln = {g: (sd["%s/%s/gamma" % (base, g)], sd["%s/%s/beta" % (base, g)])
+              for g in ("input", "transform", "forget", "output", "state")}
+        return NO.lnlstm(x, h, c, sd[base + "/kernel"], ln)
+    Uh, Uc, Wh, Wc = U0.astype(np.float64), np.zeros((9, d)), W0.astype(np.float64), np.zeros((7, d))
+    A64 = A.astype(np.float64)
+    for _ in range(3):
+        xu = np.concatenate([Uh, A64 @ mlp(Wh, "c")], axis=1)
+        xw = A64.T @ mlp(Uh, "b")
+        (Uh, Uc), (Wh, Wc) = cell(xu, Uh, Uc, "U"), cell(xw, Wh, Wc, "W")
+    assert rel_err(out["U"].h.cpu().numpy(), Uh) < REL_TOL and rel_err(out["W"].c.cpu().numpy(), Wc) < REL_TOL
+
+
+def test_c2_full_size_properties(cuda_device):
+    """BASELINE configs[1] (n=40, B=128, d=64, T=32) at full size: finite outputs, the paired
+    instances (same graph, C*(1-/+dev)) differ, and shuffling the problems permutes predictions."""
+    sizes = [40] * 128
+    t = tspgnn.synthetic_batch(sizes, seed=1234)
+    params = P.init_params(64, seed=0)
+    out = run_hip(64, params, t, 32, fetch=("predictions", "loss"))
+    assert np.all(np.isfinite(out["predictions"])) and np.isfinite(out["loss"])
+    # problem-level permutation: reverse the order of the problems
+    EV, W, C, r, nv, ne = t
+    eo = np.concatenate([[0], np.cumsum(ne)]); vo = np.concatenate([[0], np.cumsum(nv)])
+    order = np.arange(len(ne))[::-1]
+    uv2, W2, C2 = [], [], []
+    acc_v = 0
+    for i in order:
+        uv2.append(EV.uv[eo[i]:eo[i + 1]] - vo[i] + acc_v); W2.append(W[eo[i]:eo[i + 1]]); C2.append(C[eo[i]:eo[i + 1]])
+        acc_v += nv[i]
+    t2 = (tspgnn.SparseEV(np.concatenate(uv2), EV.shape[1]), np.concatenate(W2), np.concatenate(C2), r[order], nv[order], ne[order])
+    out2 = run_hip(64, params, t2, 32, fetch=("predictions",))
+    assert rel_err(out2["predictions"], out["predictions"][order]) < 2e-6

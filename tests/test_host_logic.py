@@ -1,0 +1,93 @@
+"""Host-side mirror of the reference interface: constructor checks, variable layout, plumbing
+that must work (or fail loudly) without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+import tspgnn
+from oracle import params as P
+from tspgnn import variables as V
+
+
+def test_build_network_keys_and_variables():
+    m = tspgnn.build_network(64)
+    for k in ("gnn", "route_exists", "n_vertices", "n_edges", "EV", "W", "C", "time_steps", "last_states",
+              "predictions", "TP", "FP", "TN", "FN", "acc", "loss", "train_step"):      # model.py:97-167
+        assert k in m
+    assert m.store.names() == P.param_names(64)
+    assert m.store.size == 115529
+    m128 = tspgnn.build_network(128)
+    assert m128.store.size == 457617
+
+
+def test_store_layout_is_pack_contiguous_and_aligned():
+    m = tspgnn.build_network(32)
+    st = m.store.finalize("cpu")
+    st.initialize(seed=1)
+    for name in st.names():
+        assert st.offset(name) % 4 == 0
+    mlp = m["gnn"]._msg_MLPs["E_msg_V"]
+    wb = mlp.wb()
+    assert wb.numel() == 4 * (32 * 32 + 32)
+    assert torch.equal(wb[:32 * 32].view(32, 32), st.view("TSP/E_msg_V_MLP_layer_1/kernel"))
+    cell = m["gnn"]._RNN_cells["E"]
+    assert cell.ln().numel() == 10 * 32 and torch.equal(cell.ln()[:32], torch.ones(32))
+    # initialisers: zero biases for E_init / E_vote, xavier (non-zero) biases for the message MLPs
+    assert torch.count_nonzero(st.view("E_vote_MLP_layer_1/bias")) == 0
+    assert torch.count_nonzero(st.view("TSP/V_msg_E_MLP_layer_1/bias")) > 0
+    lim = np.sqrt(6.0 / (64 + 128))
+    assert st.view("TSP/V_cell/layer_norm_basic_lstm_cell/kernel").abs().max() <= lim
+    sd = st.state_dict()
+    st.load({k: v * 2 for k, v in sd.items()})
+    assert np.allclose(st.state_dict()["V_init"], 2 * sd["V_init"])
+
+
+def test_check_model_errors_match_reference():
+    store = V.VariableStore()
+    with pytest.raises(Warning):        # graphnn.py:76
+        tspgnn.GraphNN({"V": 64, "U": 64}, {}, {}, {"V": []}, store=store)
+    with pytest.raises(Exception, match="Updating variable"):   # graphnn.py:82
+        tspgnn.GraphNN({"V": 64}, {}, {}, {"V": [], "X": []}, store=V.VariableStore())
+    with pytest.raises(Exception, match="Matrix M definition depends on undeclared"):   # graphnn.py:88
+        tspgnn.GraphNN({"V": 64}, {"M": ("Q", "V")}, {}, {"V": []}, store=V.VariableStore())
+    with pytest.raises(Exception, match="maps to undeclared"):   # graphnn.py:100
+        tspgnn.GraphNN({"V": 64}, {}, {"c": ("V", "Z")}, {"V": []}, store=V.VariableStore())
+
+
+def test_check_run_errors():
+    m = tspgnn.build_network(32)
+    m.store.finalize("cpu")
+    gnn = m["gnn"]
+    ev = tspgnn.SparseEV(np.array([[0, 1], [1, 2], [0, 2]]), 3)
+    V0, E0 = torch.zeros(3, 32), torch.zeros(3, 32)
+    with pytest.raises(ValueError, match="dimensionality 32"):
+        gnn({"EV": ev}, {"V": torch.zeros(3, 16), "E": E0}, 1)
+    with pytest.raises(ValueError, match="same number of nodes"):
+        gnn({"EV": ev}, {"V": torch.zeros(4, 32), "E": E0}, 1)
+    with pytest.raises(ValueError, match="same shape"):
+        gnn({"EV": ev}, {"V": V0, "E": E0}, 1, LSTM_initial_states={"V": torch.zeros(2, 32)})
+
+
+def test_unsupported_shapes_raise_not_fallback():
+    with pytest.raises(NotImplementedError):
+        tspgnn.Mlp([48, 48], output_size=48, activations=["relu", "relu"], name="odd", input_size=48,
+                   store=V.VariableStore())
+    with pytest.raises(NotImplementedError):
+        tspgnn.Mlp([64], output_size=64, activations=["tanh"], name="t", input_size=64, store=V.VariableStore())
+
+
+def test_session_requires_gpu_or_fails_loudly():
+    tspgnn.build_network(32)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            tspgnn.Session()
+
+
+def test_product_does_not_import_oracle():
+    import os, re
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "tsp-gnn_amd", "tspgnn")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn

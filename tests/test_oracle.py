@@ -1,0 +1,163 @@
+"""The CPU oracle checked against itself (two independent restatements), against analytic
+known answers, against the golden regression vectors, and through metamorphic properties
+(SURVEY.md §4 items 1-4).  The reference holds no vectors for this path -> "parity unpinned"."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_pack, rel_err
+from oracle import np_oracle as NO
+from oracle import params as P
+from oracle import torch_oracle as TO
+
+
+def pack_batch(name, seed=0):
+    g = load_pack(name, seed)
+    return {k: g[k] for k in ("ev_uv", "W", "C", "route_exists", "n_vertices", "n_edges")}
+
+
+def test_param_inventory():
+    assert P.n_params(64) == 115529 and P.n_params(128) == 457617
+    shapes = P.param_shapes(64)
+    assert shapes["E_init_MLP_MLP_layer_1/kernel"] == (2, 8)         # int(d/8) quirk, model.py:34
+    assert shapes["TSP/E_cell/layer_norm_basic_lstm_cell/kernel"] == (128, 256)
+    assert shapes["E_vote_MLP_layer_4/kernel"] == (64, 1)
+
+
+@pytest.mark.parametrize("name,d,T", [("n5_B2", 32, 3), ("ragged_B6", 64, 2), ("sparse_B4", 32, 5)])
+def test_numpy_and_torch_restatements_agree(name, d, T):
+    batch = pack_batch(name)
+    params = P.init_params(d, seed=3, perturb=True)
+    a = NO.forward(params, batch, T, dtype=np.float64)
+    b = TO.forward(TO.to_torch(params), batch, T)
+    assert rel_err(a["predictions"], b["predictions"].numpy()) < 1e-12
+    assert rel_err(a["E"][0], b["last_states"]["E"][0].numpy()) < 1e-11
+    assert rel_err(a["V"][1], b["last_states"]["V"][1].numpy()) < 1e-11
+    assert abs(a["loss"] - b["loss"].item()) < 1e-12
+    for k in ("TP", "FP", "TN", "FN", "acc"):
+        assert float(a[k]) == float(b[k])
+
+
+def test_dense_variant_equals_index_variant():
+    batch = pack_batch("ragged_B6", 2)
+    params = TO.to_torch(P.init_params(32, seed=5, perturb=True))
+    a = TO.forward(params, batch, 3, dense=True)
+    b = TO.forward(params, batch, 3, dense=False)
+    assert rel_err(a["logits"].numpy(), b["logits"].numpy()) < 1e-12
+    assert rel_err(a["last_states"]["E"][0].numpy(), b["last_states"]["E"][0].numpy()) < 1e-12
+
+
+@pytest.mark.parametrize("fname", ["oracle_n5_B2_d32_T3.npz", "oracle_ragged_B6_d64_T4.npz"])
+def test_golden_regression(fname):
+    z = np.load(os.path.join(GOLDEN, fname))
+    name = fname.split("_d")[0].replace("oracle_", "")
+    d, T = int(z["d"]), int(z["T"])
+    batch = pack_batch(name)
+    params = P.init_params(d, seed=int(z["param_seed"]), perturb=True)
+    out, grads = TO.loss_and_grads(params, batch, T)
+    assert rel_err(out["predictions"].detach().numpy(), z["predictions"]) < 1e-12
+    assert abs(out["loss"].item() - float(z["loss"])) < 1e-13
+    assert rel_err(out["last_states"]["V"][0].detach().numpy(), z["Vh"]) < 1e-11
+    gn = np.array([np.sqrt((g ** 2).sum()) for g in grads.values()])
+    assert rel_err(gn, z["grad_norms"]) < 1e-9
+
+
+# ----------------------------------------------------------------- analytic known answers
+def test_kat_aggregation():
+    batch = pack_batch("ragged_B6")
+    uv, N = batch["ev_uv"].astype(np.int64), int(batch["n_vertices"].sum())
+    X = np.random.RandomState(0).randn(N, 8)
+    Y = NO.gather2_sum(uv, X)
+    assert np.array_equal(Y[5], X[uv[5, 0]] + X[uv[5, 1]])
+    ones = np.ones((uv.shape[0], 4))
+    deg = NO.rowsum_by_vertex(uv, ones, N)[:, 0]
+    offs = np.concatenate([[0], np.cumsum(batch["n_vertices"])])
+    for i, n in enumerate(batch["n_vertices"]):
+        assert np.all(deg[offs[i]:offs[i + 1]] == n - 1)          # EV^T 1 = degree = n-1
+    rowptr, eid = NO.csr_by_vertex(uv, N)
+    Z = np.random.RandomState(1).randn(uv.shape[0], 8)
+    assert np.allclose(NO.csr_rowsum(rowptr, eid, Z), NO.rowsum_by_vertex(uv, Z, N), atol=1e-13)
+    # adjoint identity <EV x, y> = <x, EV^T y>
+    assert abs((NO.gather2_sum(uv, X) * Z).sum() - (X * NO.rowsum_by_vertex(uv, Z, N)).sum()) < 1e-9
+
+
+def test_kat_layer_norm_of_ramp():
+    x = np.arange(8, dtype=np.float64)[None, :] * 3.0 + 5.0
+    y = NO.layer_norm(x, np.ones(8), np.zeros(8))
+    expect = (np.arange(8) - 3.5) / np.sqrt(5.25)
+    assert np.allclose(y[0], expect, atol=1e-10)
+    y2 = NO.layer_norm(x, 2 * np.ones(8), np.ones(8))
+    assert np.allclose(y2[0], 2 * expect + 1, atol=1e-10)
+
+
+def test_kat_lstm_with_zero_kernel():
+    """K=0, gamma=1, beta=0: every gate LN sees a constant row -> (x-mean)*inv = 0 exactly, so
+    i=j=f=o=0, c' = LN(c*sigmoid(1) + sigmoid(0)*relu(0)) = LN(c*sigmoid(1)), h' = relu(c')/2."""
+    d, rows = 8, 5
+    rng = np.random.RandomState(0)
+    c = rng.randn(rows, d); h = rng.randn(rows, d); x = rng.randn(rows, d)
+    ln = {g: (np.ones(d), np.zeros(d)) for g in ("input", "transform", "forget", "output", "state")}
+    nh, nc = NO.lnlstm(x, h, c, np.zeros((2 * d, 4 * d)), ln)
+    expect_c = NO.layer_norm(c * NO.sigmoid(1.0), np.ones(d), np.zeros(d))
+    assert np.allclose(nc, expect_c, atol=1e-12) and np.allclose(nh, np.maximum(expect_c, 0) * 0.5, atol=1e-12)
+
+
+def test_zero_time_steps_returns_initial_states():
+    batch = pack_batch("n5_B2")
+    params = TO.to_torch(P.init_params(32, seed=1))
+    out = TO.forward(params, batch, 0)
+    Vh, Vc = out["last_states"]["V"]
+    assert torch.equal(Vc, torch.zeros_like(Vc))
+    assert torch.allclose(Vh, (params["V_init"] / np.sqrt(32.0)).repeat(Vh.shape[0], 1))
+
+
+# ----------------------------------------------------------------- metamorphic properties
+def test_block_diagonal_independence():
+    """A batch of B graphs == B separate runs (EV is block diagonal, instance_loader.py:56-66)."""
+    g = load_pack("ragged_B6", 1)
+    params = TO.to_torch(P.init_params(32, seed=2, perturb=True))
+    whole = TO.forward(params, {k: g[k] for k in ("ev_uv", "W", "C", "route_exists", "n_vertices", "n_edges")}, 3)
+    eo = np.concatenate([[0], np.cumsum(g["n_edges"])]); vo = np.concatenate([[0], np.cumsum(g["n_vertices"])])
+    for i in range(len(g["n_edges"])):
+        sub = {"ev_uv": g["ev_uv"][eo[i]:eo[i + 1]] - vo[i], "W": g["W"][eo[i]:eo[i + 1]],
+               "C": g["C"][eo[i]:eo[i + 1]], "route_exists": g["route_exists"][i:i + 1],
+               "n_vertices": g["n_vertices"][i:i + 1], "n_edges": g["n_edges"][i:i + 1]}
+        one = TO.forward(params, sub, 3)
+        assert abs(one["logits"][0].item() - whole["logits"][i].item()) < 1e-12
+
+
+def test_edge_permutation_equivariance():
+    g = load_pack("n5_B2", 2)
+    params = TO.to_torch(P.init_params(32, seed=4, perturb=True))
+    batch = {k: g[k] for k in ("ev_uv", "W", "C", "route_exists", "n_vertices", "n_edges")}
+    base = TO.forward(params, batch, 3)
+    m0 = int(g["n_edges"][0])
+    perm = np.concatenate([np.random.RandomState(0).permutation(m0), np.arange(m0, g["ev_uv"].shape[0])])
+    pb = dict(batch, ev_uv=g["ev_uv"][perm], W=g["W"][perm], C=g["C"][perm])
+    out = TO.forward(params, pb, 3)
+    assert rel_err(out["logits"].numpy(), base["logits"].numpy()) < 1e-12
+    assert rel_err(out["last_states"]["E"][0].numpy(), base["last_states"]["E"][0].numpy()[perm]) < 1e-12
+
+
+def test_fp32_restatement_error_budget():
+    """fp32 op-for-op restatement vs the fp64 oracle: the size of the error any fp32
+    implementation of this recurrence carries (the budget the HIP path is held to)."""
+    batch = pack_batch("ragged_B6")
+    p = P.init_params(64, seed=0)
+    ref = TO.forward(TO.to_torch(p, torch.float64), batch, 8)
+    f32 = TO.forward(TO.to_torch(p, torch.float32), batch, 8, dense=True)
+    assert rel_err(f32["predictions"].numpy(), ref["predictions"].numpy()) < 1e-5
+    assert rel_err(f32["last_states"]["E"][0].numpy(), ref["last_states"]["E"][0].numpy()) < 1e-4
+
+
+def test_clip_and_adam_formulas():
+    g = {"a": np.array([3.0, 4.0])}
+    clipped, gn = TO.clip_by_global_norm(g, 0.65)
+    assert gn == 5.0 and np.allclose(clipped["a"], g["a"] * 0.65 / 5.0)
+    small, _ = TO.clip_by_global_norm({"a": np.array([0.3, 0.4])}, 0.65)
+    assert np.allclose(small["a"], [0.3, 0.4])                        # below the threshold: unchanged
+    p, m, v = TO.adam_step({"a": np.zeros(2)}, {"a": np.array([1.0, -2.0])}, {"a": np.zeros(2)}, {"a": np.zeros(2)}, 1)
+    # first Adam step moves by ~lr*sign(g)
+    assert np.allclose(p["a"], [-2e-5, 2e-5], rtol=1e-6)

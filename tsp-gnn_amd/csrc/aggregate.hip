@@ -1,0 +1,167 @@
+// The vertex<->edge aggregation (the reference's two dense tf.matmul on EV, graphnn.py:156-160)
+// as pattern-only gather / CSR row-sum kernels for gfx950.  HBM-bound: every [M,d] row is
+// touched exactly once with 16-byte lanes (a 64-float row = one 256 B coalesced segment,
+// 16 lanes), the small [N,d] operand stays L2-resident.
+#include "common.h"
+
+namespace tspgnn {
+
+// ---------------------------------------------------------------- E <- V : gather, 2 nnz / row
+// One float4 per thread; a row of d floats is covered by d/4 adjacent lanes, so a wave64
+// writes 64*16 B = 1 KiB of contiguous Y per store instruction.
+__global__ __launch_bounds__(256) void gather2_sum_kernel(const int2* __restrict__ uv,
+                                                          const float4* __restrict__ X,
+                                                          float4* __restrict__ Y, int M, int d4) {
+    const long long total = (long long)M * d4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int e = (int)(i / d4);
+        const int c = (int)(i - (long long)e * d4);
+        const int2 ends = uv[e];
+        const float4 a = X[(long long)ends.x * d4 + c];
+        const float4 b = X[(long long)ends.y * d4 + c];
+        float4 r;
+        r.x = a.x + b.x;
+        r.y = a.y + b.y;
+        r.z = a.z + b.z;
+        r.w = a.w + b.w;
+        Y[i] = r;
+    }
+}
+
+// ---------------------------------------------------------------- V <- E : CSR row-sum
+// One wavefront per vertex.  LPR = d/4 lanes cover one edge row (float4 each), so the wave
+// reads RPW = 64/LPR edge rows per step; lane-group s accumulates the edges k = s (mod RPW)
+// in ascending order, the groups are then combined with wavefront shuffles in a fixed
+// order (deterministic result).  Edge ids of the row are fetched with one coalesced load
+// per 64 edges and broadcast by shuffle instead of one dependent scalar load per edge.
+template <int LPR, bool VALUED>
+__global__ __launch_bounds__(256) void csr_rowsum_kernel(const int* __restrict__ rowptr,
+                                                         const int* __restrict__ eid,
+                                                         const float* __restrict__ val,
+                                                         const float4* __restrict__ X,
+                                                         float4* __restrict__ Y, int N) {
+    constexpr int RPW = kWave / LPR;
+    const int v = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (v >= N) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR;
+    const int c = lane % LPR;
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = beg; base < end; base += kWave) {
+        const int cnt = min(kWave, end - base);
+        const int my_e = (lane < cnt) ? eid[base + lane] : 0;
+        float my_w = 1.0f;
+        if (VALUED) my_w = (lane < cnt) ? val[base + lane] : 0.f;
+#pragma unroll 4
+        for (int k0 = 0; k0 < cnt; k0 += RPW) {
+            const int k = k0 + sub;
+            const int src = min(k, cnt - 1);
+            const int e = __shfl(my_e, src);
+            const float w = VALUED ? __shfl(my_w, src) : 1.0f;
+            if (k < cnt) {
+                const float4 x = X[(long long)e * LPR + c];
+                if (VALUED) {
+                    acc.x = fmaf(w, x.x, acc.x);
+                    acc.y = fmaf(w, x.y, acc.y);
+                    acc.z = fmaf(w, x.z, acc.z);
+                    acc.w = fmaf(w, x.w, acc.w);
+                } else {
+                    acc.x += x.x;
+                    acc.y += x.y;
+                    acc.z += x.z;
+                    acc.w += x.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off);
+        acc.y += __shfl_xor(acc.y, off);
+        acc.z += __shfl_xor(acc.z, off);
+        acc.w += __shfl_xor(acc.w, off);
+    }
+    if (sub == 0) Y[(long long)v * LPR + c] = acc;
+}
+
+// Any d that is a multiple of 4 but not 32/64/128/256: one thread per (row, float4 column).
+template <bool VALUED>
+__global__ __launch_bounds__(256) void csr_rowsum_generic_kernel(const int* __restrict__ rowptr,
+                                                                 const int* __restrict__ eid,
+                                                                 const float* __restrict__ val,
+                                                                 const float4* __restrict__ X,
+                                                                 float4* __restrict__ Y, int N, int d4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * d4) return;
+    const int v = (int)(i / d4), c = (int)(i % d4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = rowptr[v]; k < rowptr[v + 1]; ++k) {
+        const float4 x = X[(long long)eid[k] * d4 + c];
+        const float w = VALUED ? val[k] : 1.0f;
+        acc.x = VALUED ? fmaf(w, x.x, acc.x) : acc.x + x.x;
+        acc.y = VALUED ? fmaf(w, x.y, acc.y) : acc.y + x.y;
+        acc.z = VALUED ? fmaf(w, x.z, acc.z) : acc.z + x.z;
+        acc.w = VALUED ? fmaf(w, x.w, acc.w) : acc.w + x.w;
+    }
+    Y[i] = acc;
+}
+
+template <bool VALUED>
+static int launch_csr(const int32_t* rowptr, const int32_t* idx, const float* val, const float* X,
+                      float* Y, int R, int d, hipStream_t st) {
+    const float4* X4 = reinterpret_cast<const float4*>(X);
+    float4* Y4 = reinterpret_cast<float4*>(Y);
+    const int d4 = d / 4;
+    const unsigned grid = (unsigned)(((long long)R * kWave + 255) / 256);
+    switch (d4) {
+        case 8: csr_rowsum_kernel<8, VALUED><<<grid, 256, 0, st>>>(rowptr, idx, val, X4, Y4, R); break;
+        case 16: csr_rowsum_kernel<16, VALUED><<<grid, 256, 0, st>>>(rowptr, idx, val, X4, Y4, R); break;
+        case 32: csr_rowsum_kernel<32, VALUED><<<grid, 256, 0, st>>>(rowptr, idx, val, X4, Y4, R); break;
+        case 64: csr_rowsum_kernel<64, VALUED><<<grid, 256, 0, st>>>(rowptr, idx, val, X4, Y4, R); break;
+        default: {
+            const unsigned g2 = (unsigned)(((long long)R * d4 + 255) / 256);
+            csr_rowsum_generic_kernel<VALUED><<<g2, 256, 0, st>>>(rowptr, idx, val, X4, Y4, R, d4);
+        }
+    }
+    return launched(VALUED ? "tspgnn_csr_spmm_f32" : "tspgnn_csr_rowsum_f32");
+}
+
+}  // namespace tspgnn
+
+using namespace tspgnn;
+
+extern "C" int tspgnn_gather2_sum_f32(const int32_t* uv, const float* X, float* Y, int M, int N, int d,
+                                      void* stream) {
+    TSPGNN_REQUIRE(M >= 0 && N >= 0, "gather2_sum: negative size (M=%d N=%d)", M, N);
+    TSPGNN_REQUIRE(d > 0 && d % 4 == 0, "gather2_sum: d=%d must be a positive multiple of 4", d);
+    if (M == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(uv && X && Y, "gather2_sum: null pointer");
+    const int d4 = d / 4;
+    const long long total = (long long)M * d4;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
+    gather2_sum_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(
+        reinterpret_cast<const int2*>(uv), reinterpret_cast<const float4*>(X), reinterpret_cast<float4*>(Y), M,
+        d4);
+    return launched("tspgnn_gather2_sum_f32");
+}
+
+extern "C" int tspgnn_csr_rowsum_f32(const int32_t* rowptr, const int32_t* eid, const float* X, float* Y, int N,
+                                     int M, int d, void* stream) {
+    TSPGNN_REQUIRE(M >= 0 && N >= 0, "csr_rowsum: negative size (N=%d M=%d)", N, M);
+    TSPGNN_REQUIRE(d > 0 && d % 4 == 0, "csr_rowsum: d=%d must be a positive multiple of 4", d);
+    if (N == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(rowptr && Y && (M == 0 || (eid && X)), "csr_rowsum: null pointer");
+    return launch_csr<false>(rowptr, eid, nullptr, X, Y, N, d, as_stream(stream));
+}
+
+extern "C" int tspgnn_csr_spmm_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+                                   float* Y, int R, int C, int d, void* stream) {
+    TSPGNN_REQUIRE(R >= 0 && C >= 0, "csr_spmm: negative size (R=%d C=%d)", R, C);
+    TSPGNN_REQUIRE(d > 0 && d % 4 == 0, "csr_spmm: d=%d must be a positive multiple of 4", d);
+    if (R == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(rowptr && Y && (C == 0 || (col && val && X)), "csr_spmm: null pointer");
+    return launch_csr<true>(rowptr, col, val, X, Y, R, d, as_stream(stream));
+}

@@ -1,0 +1,36 @@
+// Shared host/device helpers for libtspgnn (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tspgnn.h"
+
+namespace tspgnn {
+
+// Records a thread-local message and returns `code` (see tspgnn_last_error()).
+int fail(int code, const char* fmt, ...);
+// hipGetLastError() after a launch; 0 or the positive hipError_t (message recorded).
+int launched(const char* what);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TSPGNN_REQUIRE(cond, ...) \
+    do {                          \
+        if (!(cond)) return ::tspgnn::fail(TSPGNN_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Sum over the four 16-lane groups of a wavefront (lanes l, l^16, l^32, l^48); every lane
+// ends with the total.  The order (l + l^16) + (l^32 + l^48) is fixed -> deterministic.
+__device__ __forceinline__ float sum_over_lane_groups16(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+}  // namespace tspgnn

@@ -1,0 +1,78 @@
+"""ctypes binding of libtspgnn.so (the C ABI declared in include/tspgnn.h).
+
+There is no CPU fallback: if the shared object is missing this module raises at import, and
+a launch on a machine without an MI355X surfaces as a ``TspgnnError`` carrying the HIP error.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtspgnn.so")
+ABI_VERSION = 1
+
+c_int, c_uint, c_float, c_void_p, c_char_p = (ctypes.c_int, ctypes.c_uint, ctypes.c_float, ctypes.c_void_p,
+                                              ctypes.c_char_p)
+
+# name -> argtypes; every function returns int.  Mirrors include/tspgnn.h one to one
+# (tests/test_abi.py parses the header and checks this table against it).
+SIGNATURES = {
+    "tspgnn_gather2_sum_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tspgnn_csr_rowsum_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tspgnn_csr_spmm_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tspgnn_mlp_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_uint, c_void_p],
+    "tspgnn_lnlstm_fwd_f32": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                              c_int, c_void_p],
+    "tspgnn_einit_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_tile_rows_f32": [c_void_p, c_float, c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_rowdot_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_segment_mean_f32": [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "tspgnn_bce_metrics_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+}
+
+
+class TspgnnError(RuntimeError):
+    """A libtspgnn entry point returned a non-zero status."""
+
+    def __init__(self, fn, status, message):
+        super().__init__("%s failed with status %d: %s" % (fn, status, message))
+        self.fn, self.status, self.message = fn, status, message
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libtspgnn.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C tsp-gnn_amd/csrc`; there is no CPU fallback for the tspgnn hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.tspgnn_version.restype = c_int
+    lib.tspgnn_version.argtypes = []
+    lib.tspgnn_last_error.restype = c_char_p
+    lib.tspgnn_last_error.argtypes = []
+    if lib.tspgnn_version() != ABI_VERSION:
+        raise ImportError("libtspgnn.so ABI %d != binding ABI %d" % (lib.tspgnn_version(), ABI_VERSION))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = c_int
+        fn.argtypes = argtypes
+    return lib
+
+
+lib = _load()
+
+
+def call(name, *args):
+    """Invoke an entry point; raise TspgnnError on a non-zero status."""
+    status = getattr(lib, name)(*args)
+    if status != 0:
+        raise TspgnnError(name, status, lib.tspgnn_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

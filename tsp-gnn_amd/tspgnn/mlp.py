@@ -1,0 +1,135 @@
+"""``Mlp``: the dense block of the hot path with the reference's constructor and call
+signature (/root/reference/mlp.py:3-64), executed by hand-written HIP kernels.
+
+Supported layer patterns (everything the reference instantiates; anything else raises
+NotImplementedError rather than falling back to a generic slow path):
+  * square chains d -> d -> ... -> d, d in {32,64,128}   (message MLPs, graphnn.py:114-125)
+        -> tspgnn_mlp_fwd_f32 (MFMA, weights resident in LDS)
+  * a square chain followed by Dense(1)                   (E_vote, model.py:107-115)
+        -> tspgnn_mlp_fwd_f32 + tspgnn_rowdot_f32
+  * 2 -> d/8 -> d/4 -> d/2 -> d with relu x3 + linear     (E_init_MLP, model.py:33-43)
+        -> tspgnn_einit_fwd_f32
+"""
+import torch
+
+from . import _lib
+from . import variables as V
+
+
+def _is_relu(act):
+    if act is None:
+        return False
+    if act == "relu":
+        return True
+    name = getattr(act, "__name__", "")
+    if name == "relu":
+        return True
+    raise NotImplementedError("Mlp activation %r: only relu and None have HIP kernels" % (act,))
+
+
+class Mlp(object):
+    def __init__(self, layer_sizes, output_size=None, activations=None, output_activation=None, use_bias=True,
+                 kernel_initializer=None, bias_initializer=V.zeros_init, kernel_regularizer=None,
+                 bias_regularizer=None, activity_regularizer=None, kernel_constraint=None, bias_constraint=None,
+                 trainable=True, name=None, name_internal_layers=True, input_size=None, store=None):
+        """Stacks len(layer_sizes) dense layers, plus one of ``output_size`` units if given
+        (mlp.py:22-55).  ``input_size`` is needed up front because variables are allocated at
+        construction, not lazily at first call like tf.layers.Dense."""
+        if not use_bias:
+            raise NotImplementedError("Mlp(use_bias=False) has no HIP kernel")
+        if any(x is not None for x in (kernel_regularizer, bias_regularizer, activity_regularizer,
+                                       kernel_constraint, bias_constraint)):
+            raise NotImplementedError("regularizers / constraints are not part of the hot path")
+        if name is None or not name_internal_layers:
+            raise ValueError("Mlp needs a name: layers are called <name>_MLP_layer_<i> (mlp.py:37)")
+        layer_sizes = list(layer_sizes)
+        if not isinstance(activations, list):
+            activations = [activations for _ in layer_sizes]
+        if output_size is not None:
+            layer_sizes = layer_sizes + [output_size]
+            activations = activations + [output_activation]
+        # tf.layers.Dense does int(units): model.py:34 passes d/8, d/4, d/2 as floats
+        self.sizes = [int(s) for s in layer_sizes]
+        self.relu = [_is_relu(a) for a in activations]
+        self.name = name
+        self.store = store if store is not None else V.get_default_store()
+        self.input_size = int(input_size) if input_size is not None else self.sizes[0]
+        kinit = kernel_initializer if kernel_initializer is not None else V.xavier_uniform
+        binit = bias_initializer if bias_initializer is not None else V.zeros_init
+        self.layer_names = []
+        fan_in = self.input_size
+        for i, size in enumerate(self.sizes):
+            lname = "%s_MLP_layer_%d" % (name, i + 1)
+            self.store.declare(lname + "/kernel", (fan_in, size), kinit)
+            self.store.declare(lname + "/bias", (size,), binit)
+            self.layer_names.append(lname)
+            fan_in = size
+        self._plan = self._make_plan()
+
+    # ------------------------------------------------------------------ kernel selection
+    def _make_plan(self):
+        dims = [self.input_size] + self.sizes
+        d = dims[1] if len(dims) > 1 else None
+        if all(x == dims[0] for x in dims) and dims[0] in (32, 64, 128):
+            return ("square", dims[0], len(self.sizes), False)
+        if len(dims) >= 3 and dims[-1] == 1 and all(x == dims[0] for x in dims[:-1]) and dims[0] in (32, 64, 128):
+            if self.relu[-1]:
+                raise NotImplementedError("Dense(1) head with an activation")
+            return ("square", dims[0], len(self.sizes) - 1, True)
+        dd = dims[-1]
+        if dims == [2, int(dd / 8), int(dd / 4), int(dd / 2), dd] and dd in (32, 64, 128) \
+                and self.relu == [True, True, True, False]:
+            return ("einit", dd, 4, False)
+        raise NotImplementedError("Mlp with layer widths %s has no HIP kernel (supported: square d->d chains, "
+                                  "a square chain + Dense(1), and 2->d/8->d/4->d/2->d)" % (dims,))
+
+    def wb(self, first=0, last=None):
+        """Flat [W,b,W,b,...] slice of theta for layers first..last (inclusive)."""
+        last = len(self.layer_names) - 1 if last is None else last
+        return self.store.span(self.layer_names[first] + "/kernel", self.layer_names[last] + "/bias")
+
+    # ------------------------------------------------------------------ forward
+    def __call__(self, inputs, save=None):
+        """inputs: fp32 device tensor [rows, input_size].  ``save`` (optional list) receives the
+        tensors a later backward needs."""
+        if not self.store.finalized:
+            raise RuntimeError("variables not allocated: create a Session (or store.finalize) first")
+        x = inputs
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.to(torch.float32).contiguous()
+        rows = x.shape[0]
+        if x.shape[1] != self.input_size:
+            raise ValueError("Mlp %s expects %d input features, got %d" % (self.name, self.input_size, x.shape[1]))
+        st = _lib.current_stream()
+        kind, d, n_sq, head = self._plan
+        if kind == "einit":
+            out = torch.empty((rows, d), dtype=torch.float32, device=x.device)
+            _lib.call("tspgnn_einit_fwd_f32", _lib.ptr(x), _lib.ptr(self.wb()), _lib.ptr(out), rows, d, st)
+            return out
+        max_chunk = 2 if d == 128 else 4
+        l0 = 0
+        while l0 < n_sq:
+            n = min(max_chunk, n_sq - l0)
+            mask = 0
+            for j in range(n):
+                if self.relu[l0 + j]:
+                    mask |= 1 << j
+            out = torch.empty((rows, d), dtype=torch.float32, device=x.device)
+            acts = None
+            if save is not None and n > 1:
+                acts = torch.empty((n - 1, rows, d), dtype=torch.float32, device=x.device)
+            _lib.call("tspgnn_mlp_fwd_f32", _lib.ptr(x), _lib.ptr(self.wb(l0, l0 + n - 1)), _lib.ptr(out),
+                      _lib.ptr(acts), rows, d, n, mask, st)
+            if save is not None:
+                save.append((l0, n, x, acts, out))
+            x = out
+            l0 += n
+        if head:
+            y = torch.empty((rows, 1), dtype=torch.float32, device=x.device)
+            last = self.layer_names[-1]
+            _lib.call("tspgnn_rowdot_f32", _lib.ptr(x), _lib.ptr(self.store.view(last + "/kernel")),
+                      _lib.ptr(self.store.view(last + "/bias")), _lib.ptr(y), rows, d, st)
+            if save is not None:
+                save.append(("head", x))
+            return y
+        return x

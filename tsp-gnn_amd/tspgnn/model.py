@@ -1,0 +1,250 @@
+"""``build_network(d)`` and ``Session``: the operator surface of the reference's model.py
+(/root/reference/model.py:9-171) on the MI355X-native path.
+
+``build_network`` returns a dict with the reference's keys (model.py:97-104,123,147-157,167):
+placeholders ``EV, W, C, time_steps, route_exists, n_vertices, n_edges`` and fetches
+``last_states, predictions, TP, FP, TN, FN, acc, loss, train_step`` plus ``gnn``.  Callers do
+exactly what train.py:25-42 does:
+
+    model = build_network(64)
+    sess = Session(); sess.run(global_variables_initializer())
+    loss, acc, pred, TP, FP, TN, FN = sess.run([model['loss'], ...], feed_dict={model['EV']: EV, ...})
+
+``model['EV']`` accepts the reference's dense float64/float32 matrix (converted once to index
+form; it must be a 0/1 matrix with two ones per row, which is what create_batch emits) or a
+``SparseEV`` that never materialises the dense matrix.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import variables as V
+from .graphnn import GraphNN, LSTMStateTuple
+from .instance_loader import SparseEV
+from .mlp import Mlp
+
+LEARNING_RATE = 2e-5          # model.py:13
+L2NORM_SCALING = 1e-10        # model.py:14
+GLOBAL_NORM_CLIP = 0.65       # model.py:15
+
+
+class Placeholder(object):
+    def __init__(self, name, dtype, ndim):
+        self.name, self.dtype, self.ndim = name, dtype, ndim
+
+    def __repr__(self):
+        return "<tspgnn placeholder %s>" % self.name
+
+
+class Fetch(object):
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return "<tspgnn fetch %s>" % self.name
+
+
+class _InitOp(Fetch):
+    pass
+
+
+def global_variables_initializer(seed=0):
+    """Fetchable like tf.global_variables_initializer(): ``sess.run(global_variables_initializer())``."""
+    op = _InitOp("init")
+    op.seed = seed
+    return op
+
+
+class Network(dict):
+    """The dict build_network returns, plus the objects Session needs."""
+
+
+def build_network(d, store=None):
+    d = int(d)
+    store = store if store is not None else V.reset_default_store()
+    GNN = Network()
+    GNN.d = d
+    GNN.store = store
+    # placeholders (model.py:18-29)
+    GNN["route_exists"] = Placeholder("route_exists", np.float32, 1)
+    GNN["n_vertices"] = Placeholder("n_vertices", np.int32, 1)
+    GNN["n_edges"] = Placeholder("edges", np.int32, 1)
+    GNN["EV"] = Placeholder("EV", np.float32, 2)
+    GNN["W"] = Placeholder("edge_weight", np.float32, 2)
+    GNN["C"] = Placeholder("target_cost", np.float32, 2)
+    GNN["time_steps"] = Placeholder("time_steps", np.int32, 0)
+    # model.py:33-43
+    GNN.edge_init_MLP = Mlp(
+        layer_sizes=[d / 8, d / 4, d / 2],
+        activations=["relu" for _ in range(3)],
+        output_size=d,
+        name="E_init_MLP",
+        name_internal_layers=True,
+        kernel_initializer=V.xavier_uniform,
+        bias_initializer=V.zeros_init,
+        input_size=2,
+        store=store,
+    )
+    # model.py:47
+    store.declare("V_init", (1, d), V.normal_init)
+    # model.py:57-94
+    GNN["gnn"] = GraphNN(
+        {"V": d, "E": d},
+        {"EV": ("E", "V")},
+        {"V_msg_E": ("V", "E"), "E_msg_V": ("E", "V")},
+        {
+            "V": [{"mat": "EV", "msg": "E_msg_V", "transpose?": True, "var": "E"}],
+            "E": [{"mat": "EV", "msg": "V_msg_E", "var": "V"}],
+        },
+        name="TSP",
+        store=store,
+    )
+    # model.py:107-115
+    GNN.E_vote_MLP = Mlp(
+        layer_sizes=[d for _ in range(3)],
+        activations=["relu" for _ in range(3)],
+        output_size=1,
+        name="E_vote",
+        name_internal_layers=True,
+        kernel_initializer=V.xavier_uniform,
+        bias_initializer=V.zeros_init,
+        input_size=d,
+        store=store,
+    )
+    for key in ("last_states", "predictions", "TP", "FP", "TN", "FN", "acc", "loss", "train_step"):
+        GNN[key] = Fetch(key)
+    build_network.last = GNN
+    return GNN
+
+
+build_network.last = None
+
+
+class Session(object):
+    """Executes fetches of a network built by build_network on one MI355X.
+
+    ``Session(model=None, device='cuda:0')``: without ``model`` it binds to the most recently
+    built network (the TF default-graph behaviour train.py:202-206 relies on)."""
+
+    def __init__(self, model=None, device=None):
+        self.model = model if model is not None else build_network.last
+        if self.model is None:
+            raise RuntimeError("Session: call build_network(d) first")
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("tspgnn.Session needs an MI355X (no HIP device visible); there is no CPU path")
+            device = "cuda:%d" % torch.cuda.current_device()
+        self.device = torch.device(device)
+        self.store = self.model.store
+        if not self.store.finalized:
+            self.store.finalize(self.device)
+        self._adj_cache = (None, None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def close(self):
+        pass
+
+    # ------------------------------------------------------------------ feeding
+    def _f32(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    def _adjacency(self, EV):
+        from .graphnn import DeviceAdjacency
+        key, cached = self._adj_cache
+        if key is EV:
+            return cached
+        if isinstance(EV, DeviceAdjacency):
+            adj = EV
+        elif isinstance(EV, SparseEV):
+            adj = DeviceAdjacency.from_sparse_ev(EV, self.device)
+        else:
+            try:
+                adj = DeviceAdjacency.from_sparse_ev(SparseEV.fromdense(EV), self.device)
+            except ValueError as e:
+                raise ValueError("feed for model['EV']: %s" % e)
+        self._adj_cache = (EV, adj)
+        return adj
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, feed):
+        """Runs model.py:33-157 on the device; returns a dict of device tensors."""
+        m, d = self.model, self.model.d
+        st = _lib.current_stream()
+        adj = self._adjacency(feed[m["EV"]])
+        M, N = adj.shape
+        W = np.asarray(feed[m["W"]], dtype=np.float32).reshape(-1)
+        C = np.asarray(feed[m["C"]], dtype=np.float32).reshape(-1)
+        if W.shape[0] != M or C.shape[0] != M:
+            raise ValueError("W and C must have one row per edge (%d), got %d and %d" % (M, W.shape[0], C.shape[0]))
+        n_edges = np.asarray(feed[m["n_edges"]]).astype(np.int64).reshape(-1)
+        n_vertices = np.asarray(feed[m["n_vertices"]]).astype(np.int64).reshape(-1)
+        B = n_vertices.shape[0]
+        labels = self._f32(np.asarray(feed[m["route_exists"]]).reshape(-1))
+        if n_edges.shape[0] != B or labels.shape[0] != B:
+            raise ValueError("route_exists, n_vertices and n_edges must have one entry per problem")
+        if int(n_edges.sum()) != M:
+            raise ValueError("sum(n_edges)=%d does not match the %d rows of EV" % (int(n_edges.sum()), M))
+        T = int(feed[m["time_steps"]])
+        WC = self._f32(np.stack([W, C], axis=1))
+        E0 = m.edge_init_MLP(WC)                                              # model.py:43
+        V0 = torch.empty((N, d), dtype=torch.float32, device=self.device)   # model.py:48-51
+        _lib.call("tspgnn_tile_rows_f32", _lib.ptr(self.store.view("V_init")), 1.0 / math.sqrt(float(d)),
+                  _lib.ptr(V0), N, d, st)
+        last = m["gnn"]({"EV": adj}, {"V": V0, "E": E0}, T)                   # model.py:118-122
+        vote = m.E_vote_MLP(last["E"].h).view(-1)                             # model.py:128
+        seg = torch.from_numpy(np.concatenate([[0], np.cumsum(n_edges)]).astype(np.int32)).to(self.device)
+        logits = torch.empty(B, dtype=torch.float32, device=self.device)
+        _lib.call("tspgnn_segment_mean_f32", _lib.ptr(vote), _lib.ptr(seg), _lib.ptr(logits), B, st)
+        pred = torch.empty(B, dtype=torch.float32, device=self.device)
+        stats = torch.empty(6, dtype=torch.float32, device=self.device)
+        _lib.call("tspgnn_bce_metrics_f32", _lib.ptr(logits), _lib.ptr(labels), _lib.ptr(pred), _lib.ptr(stats), B,
+                  st)
+        return {"last_states": last, "E_vote": vote, "logits": logits, "predictions": pred, "stats": stats}
+
+    # ------------------------------------------------------------------ run
+    def run(self, fetches, feed_dict=None):
+        single = not isinstance(fetches, (list, tuple))
+        flist = [fetches] if single else list(fetches)
+        for f in flist:
+            if isinstance(f, _InitOp):
+                self.store.initialize(seed=f.seed)
+        names = [f.name for f in flist if isinstance(f, Fetch) and not isinstance(f, _InitOp)]
+        out = None
+        if names:
+            if feed_dict is None:
+                raise ValueError("these fetches depend on placeholders: feed_dict is required")
+            missing = [k for k in ("EV", "W", "C", "time_steps", "route_exists", "n_vertices", "n_edges")
+                       if self.model[k] not in feed_dict]
+            if missing:
+                raise ValueError("You must feed a value for placeholder(s) %s" % ", ".join(missing))
+            if "train_step" in names:
+                out = self.train_step(feed_dict)
+            else:
+                out = self.forward(feed_dict)
+        results = []
+        stats = None
+        for f in flist:
+            if isinstance(f, _InitOp) or f.name == "train_step":
+                results.append(None)
+                continue
+            if stats is None:
+                stats = out["stats"].cpu().numpy()
+            if f.name == "predictions":
+                results.append(out["predictions"].cpu().numpy())
+            elif f.name == "last_states":
+                results.append({v: LSTMStateTuple(c=s.c.cpu().numpy(), h=s.h.cpu().numpy())
+                                for v, s in out["last_states"].items()})
+            else:
+                idx = {"loss": 0, "acc": 1, "TP": 2, "FP": 3, "TN": 4, "FN": 5}[f.name]
+                results.append(np.float32(stats[idx]))
+        return results[0] if single else results
+
+    def train_step(self, feed):
+        raise NotImplementedError("train_step: backward kernels are not built yet")

@@ -1,0 +1,137 @@
+"""Trainable-variable store: the counterpart of the TF-1.x default graph's variable collection
+that the reference relies on (tf.get_variable / tf.layers.Dense / tf.trainable_variables(),
+model.py:47,163-167).
+
+All variables live in ONE flat fp32 device buffer (``theta``) in declaration order, so that
+(a) the kernels read whole weight packs (an MLP's W/b chain, an LSTM cell's kernel + LayerNorm
+pairs) as contiguous slices without repacking, and (b) gradient all-reduce, global-norm clip
+and Adam each run on one flat buffer.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+def xavier_uniform(shape, gen):
+    """tf.contrib.layers.xavier_initializer(): U(-l, l), l = sqrt(6/(fan_in+fan_out)); a 1-D
+    shape uses fan_in = fan_out = shape[0] (what the reference gets for the message-MLP biases,
+    graphnn.py:121)."""
+    if len(shape) == 1:
+        fan_in = fan_out = shape[0]
+    else:
+        fan_in, fan_out = shape[0], shape[1]
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return (torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * lim
+
+
+def zeros_init(shape, gen):
+    return torch.zeros(shape, dtype=torch.float64)
+
+
+def ones_init(shape, gen):
+    return torch.ones(shape, dtype=torch.float64)
+
+
+def normal_init(shape, gen):
+    return torch.randn(shape, generator=gen, dtype=torch.float64)
+
+
+class VariableStore(object):
+    def __init__(self):
+        self._decl = OrderedDict()  # name -> (shape, initializer)
+        self._offsets = None
+        self.theta = None
+        self.device = None
+
+    # -- declaration phase -------------------------------------------------------------
+    def declare(self, name, shape, initializer):
+        if self._offsets is not None:
+            raise RuntimeError("variable store already finalised")
+        if name in self._decl:
+            raise ValueError("Variable %s already exists" % name)
+        self._decl[name] = (tuple(int(s) for s in shape), initializer)
+        return name
+
+    def names(self):
+        return list(self._decl.keys())
+
+    def shape(self, name):
+        return self._decl[name][0]
+
+    @property
+    def size(self):
+        return sum(int(np.prod(s)) for s, _ in self._decl.values())
+
+    # -- allocation --------------------------------------------------------------------
+    def finalize(self, device):
+        off, offsets = 0, OrderedDict()
+        for name, (shape, _) in self._decl.items():
+            n = int(np.prod(shape))
+            off = (off + 3) // 4 * 4  # 16-byte alignment: the kernels read packs with float4 loads
+            offsets[name] = (off, n)
+            off += n
+        self._offsets = offsets
+        self.device = torch.device(device)
+        self.theta = torch.zeros(off, dtype=torch.float32, device=self.device)
+        return self
+
+    @property
+    def finalized(self):
+        return self._offsets is not None
+
+    def initialize(self, seed=0):
+        """tf.global_variables_initializer(): run every variable's initialiser (seeded CPU
+        generator, then one upload)."""
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(int(seed))
+        host = torch.zeros(self.theta.numel(), dtype=torch.float32)
+        for name, (shape, init) in self._decl.items():
+            off, n = self._offsets[name]
+            host[off:off + n] = init(shape, gen).reshape(-1).to(torch.float32)
+        self.theta.copy_(host)
+
+    def view(self, name):
+        off, n = self._offsets[name]
+        return self.theta[off:off + n].view(self._decl[name][0])
+
+    def span(self, first, last):
+        """Contiguous flat slice covering variables ``first`` .. ``last`` (inclusive)."""
+        o0, _ = self._offsets[first]
+        o1, n1 = self._offsets[last]
+        return self.theta[o0:o1 + n1]
+
+    def offset(self, name):
+        return self._offsets[name][0]
+
+    def load(self, values):
+        """Assign variables from a {name: array} mapping (checkpoint restore / parity tests)."""
+        host = self.theta.detach().cpu()
+        for name, val in values.items():
+            off, n = self._offsets[name]
+            arr = np.asarray(val, dtype=np.float32).reshape(-1)
+            if arr.size != n:
+                raise ValueError("shape mismatch for %s: expected %s" % (name, self._decl[name][0]))
+            host[off:off + n] = torch.from_numpy(arr.copy())
+        self.theta.copy_(host)
+
+    def state_dict(self):
+        host = self.theta.detach().cpu().numpy()
+        return OrderedDict((name, host[off:off + n].reshape(self._decl[name][0]).copy())
+                           for name, (off, n) in self._offsets.items())
+
+
+# The "default graph": build_network()/Mlp()/GraphNN() declare into it unless given a store.
+_default_store = VariableStore()
+
+
+def get_default_store():
+    return _default_store
+
+
+def reset_default_store():
+    """tf.reset_default_graph() analogue: start a fresh variable collection."""
+    global _default_store
+    _default_store = VariableStore()
+    return _default_store
