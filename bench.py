@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""Benchmark of the TSP-GNN message-passing hot path on MI355X (contract: task prompt + SURVEY.md §8d).
+
+One *step* of this bench = one forward pass of the hot path over one synthetic batch of the
+workload (default C2: 128 complete Euclidean graphs of n=40, d=64, T=32 message-passing steps,
+fp32), inputs already resident in HBM.  ``value`` = message-passing steps per second of the whole
+job (= n_gpus * K * T / max-over-ranks wall time); one message-passing step aggregates 4M
+incidences (E<-V gather of M rows + V<-E row-sum over 2M incidences) and updates both LSTMs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+The forward pass needs no collective (EV is block diagonal: instances never exchange messages), so
+N>1 is weak scaling over independent shards of the global batch: "sharded by instance".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tsp-gnn_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* peak = fp32 vector peak
+
+WORKLOADS = {
+    # name: (graph sizes, d, T)
+    "c1": ([20] * 32, 64, 8),      # BASELINE.json configs[0]
+    "c2": ([40] * 128, 64, 32),    # BASELINE.json configs[1]: the configuration the metric is quoted on
+}
+
+
+def spmm_bytes(N, M, d, eb=4, ib=4):
+    """Algorithmic (compulsory) bytes of the two aggregation kernels, SURVEY.md §8d M4."""
+    gather = N * d * eb + 2 * M * ib + M * d * eb
+    rowsum = M * d * eb + (2 * M + N + 1) * ib + N * d * eb
+    return gather, rowsum
+
+
+def dense_flops_per_step(N, M, d):
+    """MFMA work per message-passing step: two 4-layer d x d MLPs and two [2d,4d] LSTM GEMMs."""
+    return (M + N) * (4 * 2 * d * d + 2 * 2 * d * 4 * d)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (bounded sample)")
+    args = ap.parse_args()
+
+    import torch
+    import tspgnn
+    from tspgnn import _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    sizes, d, T = WORKLOADS[args.workload]
+    t_pack0 = time.perf_counter()
+    batch = tspgnn.synthetic_batch(sizes, seed=1234 + rank)
+    t_pack = time.perf_counter() - t_pack0
+    EV, W, C, route_exists, n_vertices, n_edges = batch
+    M, N = EV.shape
+    model = tspgnn.build_network(d)
+    sess = tspgnn.Session(model, device=device)
+    sess.run(tspgnn.global_variables_initializer(seed=0))
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    dev_batch = sess.prepare(feed)                                     # inputs resident in HBM
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = sess.forward_device(dev_batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = sess.forward_device(dev_batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    loss = float(out["stats"][0].item())
+    if not np.isfinite(loss):
+        raise SystemExit("non-finite loss in the timed region")
+
+    result = None
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        mp_steps_per_s = world * args.steps * T / elapsed
+        gather_b, rowsum_b = spmm_bytes(N, M, d)
+
+        # ---- per-kernel durations, live, HIP events on the launch stream (one instrumented pass)
+        _lib.TIMELINE = []
+        sess.forward_device(dev_batch)
+        torch.cuda.synchronize()
+        per = {}
+        for name, e0, e1 in _lib.TIMELINE:
+            per.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)   # us
+        _lib.TIMELINE = None
+        kernels_us = {k: {"n": len(v), "avg_us": float(np.mean(v)), "total_us": float(np.sum(v))}
+                      for k, v in per.items()}
+
+        # ---- SpMM-only (SURVEY.md §8d M1 i): the two aggregation kernels back to back, >= 200 warm iterations
+        adj = dev_batch.adj
+        X = torch.randn((N, d), device=device)
+        Z = torch.randn((M, d), device=device)
+        Y = torch.empty((M, d), device=device)
+        Vout = torch.empty((N, d), device=device)
+        rowptr, eid, _ = adj.csr_t
+        st = _lib.current_stream()
+
+        def gather():
+            _lib.call("tspgnn_gather2_sum_f32", _lib.ptr(adj.uv), _lib.ptr(X), _lib.ptr(Y), M, N, d, st)
+
+        def rowsum():
+            _lib.call("tspgnn_csr_rowsum_f32", _lib.ptr(rowptr), _lib.ptr(eid), _lib.ptr(Z), _lib.ptr(Vout), N, M, d, st)
+
+        def time_loop(fns, iters=300):
+            for _ in range(20):
+                for f in fns:
+                    f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                for f in fns:
+                    f()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / iters   # us per iteration
+
+        t_gather, t_rowsum, t_pair = time_loop([gather]), time_loop([rowsum]), time_loop([gather, rowsum])
+        pair_gbs = (gather_b + rowsum_b) / (t_pair * 1e-6) / 1e9
+        roofline = {
+            "kernel": "tspgnn_gather2_sum_f32 + tspgnn_csr_rowsum_f32 (the vertex<->edge SpMM pair)",
+            "bound": "hbm", "achieved": round(pair_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(pair_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": {"gather2_sum": gather_b, "csr_rowsum": rowsum_b},
+            "avg_us": {"gather2_sum": round(t_gather, 2), "csr_rowsum": round(t_rowsum, 2), "pair": round(t_pair, 2)},
+            "per_kernel_GBs": {"gather2_sum": round(gather_b / t_gather / 1e3, 1),
+                               "csr_rowsum": round(rowsum_b / t_rowsum / 1e3, 1)},
+            "spmm_steps_per_s": round(1e6 / t_pair, 1),
+            "incidences_per_s": round(4 * M * 1e6 / t_pair, 1),
+        }
+        dense_us = sum(v["total_us"] for k, v in kernels_us.items() if k in ("tspgnn_mlp_fwd_f32", "tspgnn_lnlstm_fwd_f32"))
+        # E_vote's 3 hidden layers also run through mlp_fwd: count their flops too
+        dense_flops = T * dense_flops_per_step(N, M, d) + M * 3 * 2 * d * d
+        roofline_dense = {
+            "kernel": "tspgnn_mlp_fwd_f32 + tspgnn_lnlstm_fwd_f32 (fp32 MFMA 16x16x4)",
+            "bound": "mfma", "achieved": round(dense_flops / (dense_us * 1e-6) / 1e12, 2) if dense_us else None,
+            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(dense_flops / (dense_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4) if dense_us else None,
+        }
+
+        cpu_baseline = None
+        if not args.no_cpu_baseline:
+            cpu_baseline = run_cpu_baseline(d, batch, T, args.cpu_seconds, M)
+
+        result = {
+            "metric": "message-passing steps/sec (edges aggregated/sec) at n=40, batch=128, T=32",
+            "value": round(mp_steps_per_s, 2), "unit": "mp-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d complete Euclidean graphs n=%d, d=%d, T=%d, fp32, forward pass "
+                                   "(E_init -> T x {msg MLPs, SpMM pair, LN-LSTMs} -> vote -> loss)"
+                                   % (args.workload, len(sizes), sizes[0], d, T),
+                       "per_gpu_batch": len(sizes), "global_batch": len(sizes) * world, "N": N, "M": M,
+                       "parallelism": "shard-by-instance x%d, no data-path collective" % world},
+            "edges_per_s": round(mp_steps_per_s * M, 1),
+            "incidences_per_s": round(mp_steps_per_s * 4 * M, 1),
+            "roofline": roofline,
+            "roofline_dense": roofline_dense,
+            "cpu_baseline": cpu_baseline,
+            "kernels_us": {k: {"n": v["n"], "avg_us": round(v["avg_us"], 2)} for k, v in kernels_us.items()},
+            "host_pack_s": round(t_pack, 4),
+            "loss": loss,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def run_cpu_baseline(d, batch, T, budget_s, M):
+    """The oracle's op-for-op dense fp32 restatement of the TF CPU graph (dense EV matmul both
+    directions), timed on this host's cores on a BOUNDED sample: as many message-passing steps of
+    the full batch as fit the budget.  Checker code used as a reported baseline."""
+    import torch
+    from oracle import torch_oracle as TO
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        cores = os.cpu_count()
+    EV, W, C, route_exists, n_vertices, n_edges = batch
+    ob = {"ev_uv": EV.uv, "W": W, "C": C, "route_exists": route_exists, "n_vertices": n_vertices, "n_edges": n_edges}
+    t1, threads = TO.time_dense_forward(d, ob, 1, cores, warm=0, iters=1)       # also warms the allocator
+    n = int(max(1, min(T, budget_s / max(t1, 1e-3))))
+    tn, threads = TO.time_dense_forward(d, ob, n, cores, warm=0, iters=1)
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    steps_per_s = n / tn
+    return {"value": round(steps_per_s, 4), "unit": "mp-steps/s", "cores": int(threads), "kind": "port",
+            "sample": "%d of %d message-passing steps of the full batch, dense EV[%d,%d] fp32 torch-CPU restatement "
+                      "of the TF graph (oracle/torch_oracle.py), %.1f s" % (n, T, M, int(np.sum(n_vertices)), tn),
+            "edges_per_s": round(steps_per_s * M, 1), "cpu": cpu_model}
+
+
+if __name__ == "__main__":
+    main()

@@ -13,8 +13,22 @@ pytestmark = pytest.mark.gpu
 F32_TOL = 2e-6   # single fp32 op chains (<= a few hundred fused multiply-adds per output)
 
 
+_KEEP = []
+
+
 def dev(a, device, dtype=np.float32):
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(device)
+    """Upload; the tensor is kept alive until the end of the test (an inline temporary would be
+    freed -- and its block reused by the next upload -- before the asynchronous kernel runs)."""
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(device)
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _release_uploads():
+    yield
+    torch.cuda.synchronize()
+    del _KEEP[:]
 
 
 def test_library_is_loaded_in_tree():

@@ -6,6 +6,12 @@ a launch on a machine without an MI355X surfaces as a ``TspgnnError`` carrying t
 import ctypes
 import os
 
+# torch owns device memory and streams, and its wheel bundles its own HIP runtime
+# (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  It must be loaded BEFORE libtspgnn.so so
+# that the dynamic loader resolves our NEEDED libamdhip64.so.7 to that same runtime; two HIP
+# runtimes in one process do not share devices, streams or allocations.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtspgnn.so")
 ABI_VERSION = 1
@@ -60,9 +66,22 @@ def _load():
 lib = _load()
 
 
+# Optional per-launch timing (bench.py): when set to a list, every call appends
+# (name, start_event, stop_event) recorded on torch's current stream -- the stream the kernels run on.
+TIMELINE = None
+
+
 def call(name, *args):
     """Invoke an entry point; raise TspgnnError on a non-zero status."""
-    status = getattr(lib, name)(*args)
+    if TIMELINE is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        status = getattr(lib, name)(*args)
+        e1.record()
+        TIMELINE.append((name, e0, e1))
+    else:
+        status = getattr(lib, name)(*args)
     if status != 0:
         raise TspgnnError(name, status, lib.tspgnn_last_error().decode("utf-8", "replace"))
 
@@ -73,6 +92,4 @@ def ptr(t):
 
 
 def current_stream():
-    import torch
-
     return torch.cuda.current_stream().cuda_stream

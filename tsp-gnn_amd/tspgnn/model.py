@@ -57,6 +57,10 @@ def global_variables_initializer(seed=0):
     return op
 
 
+class DeviceBatch(object):
+    """One packed batch resident on the device (see Session.prepare)."""
+
+
 class Network(dict):
     """The dict build_network returns, plus the objects Session needs."""
 
@@ -173,10 +177,10 @@ class Session(object):
         return adj
 
     # ------------------------------------------------------------------ forward
-    def forward(self, feed):
-        """Runs model.py:33-157 on the device; returns a dict of device tensors."""
-        m, d = self.model, self.model.d
-        st = _lib.current_stream()
+    def prepare(self, feed):
+        """Validates a feed_dict and makes the batch resident in HBM (adjacency in index/CSR form,
+        (W,C) pairs, labels, segment offsets).  The returned DeviceBatch can be run many times."""
+        m = self.model
         adj = self._adjacency(feed[m["EV"]])
         M, N = adj.shape
         W = np.asarray(feed[m["W"]], dtype=np.float32).reshape(-1)
@@ -191,21 +195,35 @@ class Session(object):
             raise ValueError("route_exists, n_vertices and n_edges must have one entry per problem")
         if int(n_edges.sum()) != M:
             raise ValueError("sum(n_edges)=%d does not match the %d rows of EV" % (int(n_edges.sum()), M))
-        T = int(feed[m["time_steps"]])
-        WC = self._f32(np.stack([W, C], axis=1))
-        E0 = m.edge_init_MLP(WC)                                              # model.py:43
-        V0 = torch.empty((N, d), dtype=torch.float32, device=self.device)   # model.py:48-51
+        if int(n_vertices.sum()) != N:
+            raise ValueError("sum(n_vertices)=%d does not match the %d columns of EV" % (int(n_vertices.sum()), N))
+        b = DeviceBatch()
+        b.adj, b.M, b.N, b.B = adj, M, N, B
+        b.T = int(feed[m["time_steps"]])
+        b.WC = self._f32(np.stack([W, C], axis=1))
+        b.labels = labels
+        b.seg = torch.from_numpy(np.concatenate([[0], np.cumsum(n_edges)]).astype(np.int32)).to(self.device)
+        return b
+
+    def forward(self, feed):
+        """Runs model.py:33-157 on the device; returns a dict of device tensors."""
+        return self.forward_device(feed if isinstance(feed, DeviceBatch) else self.prepare(feed))
+
+    def forward_device(self, b):
+        m, d = self.model, self.model.d
+        st = _lib.current_stream()
+        E0 = m.edge_init_MLP(b.WC)                                            # model.py:43
+        V0 = torch.empty((b.N, d), dtype=torch.float32, device=self.device)  # model.py:48-51
         _lib.call("tspgnn_tile_rows_f32", _lib.ptr(self.store.view("V_init")), 1.0 / math.sqrt(float(d)),
-                  _lib.ptr(V0), N, d, st)
-        last = m["gnn"]({"EV": adj}, {"V": V0, "E": E0}, T)                   # model.py:118-122
+                  _lib.ptr(V0), b.N, d, st)
+        last = m["gnn"]({"EV": b.adj}, {"V": V0, "E": E0}, b.T)               # model.py:118-122
         vote = m.E_vote_MLP(last["E"].h).view(-1)                             # model.py:128
-        seg = torch.from_numpy(np.concatenate([[0], np.cumsum(n_edges)]).astype(np.int32)).to(self.device)
-        logits = torch.empty(B, dtype=torch.float32, device=self.device)
-        _lib.call("tspgnn_segment_mean_f32", _lib.ptr(vote), _lib.ptr(seg), _lib.ptr(logits), B, st)
-        pred = torch.empty(B, dtype=torch.float32, device=self.device)
+        logits = torch.empty(b.B, dtype=torch.float32, device=self.device)
+        _lib.call("tspgnn_segment_mean_f32", _lib.ptr(vote), _lib.ptr(b.seg), _lib.ptr(logits), b.B, st)
+        pred = torch.empty(b.B, dtype=torch.float32, device=self.device)
         stats = torch.empty(6, dtype=torch.float32, device=self.device)
-        _lib.call("tspgnn_bce_metrics_f32", _lib.ptr(logits), _lib.ptr(labels), _lib.ptr(pred), _lib.ptr(stats), B,
-                  st)
+        _lib.call("tspgnn_bce_metrics_f32", _lib.ptr(logits), _lib.ptr(b.labels), _lib.ptr(pred), _lib.ptr(stats),
+                  b.B, st)
         return {"last_states": last, "E_vote": vote, "logits": logits, "predictions": pred, "stats": stats}
 
     # ------------------------------------------------------------------ run
