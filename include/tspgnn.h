@@ -70,11 +70,19 @@ int tspgnn_csr_spmm_f32(const int32_t* rowptr, const int32_t* col, const float* 
 /* ------------------------------------------------------------------ dense updates (MFMA) */
 
 /*
+ * P = W reordered into the MFMA A-fragment order the dense kernels stage into LDS (layout
+ * documented in csrc/dense.hip).  W:[krows,ncols] row-major; krows % 16 == 0; ncols == 32 or
+ * ncols % 64 == 0.  Run once per weight update (the reference re-reads its tf.Variables every
+ * sess.run; here the packed copy is refreshed after initialisation / restore / Adam).
+ */
+int tspgnn_pack_weights_f32(const float* W, float* P, int krows, int ncols, void* stream);
+
+/*
  * n_layers (1..4) chained tf.layers.Dense(d) layers: x <- act_l(x W_l + b_l); layer l applies
  * relu iff bit l of relu_mask is set.  Replaces Mlp.__call__ (mlp.py:57-63) as instantiated
  * for the message MLPs (graphnn.py:114-125,153) and the hidden part of E_vote
- * (model.py:107-115).  X,Y:[rows,d].  wb: per layer W[d,d] (in x out, row-major) followed by
- * b[d], layers back to back ((d*d+d) floats each).  If acts != NULL the post-activation
+ * (model.py:107-115).  X,Y:[rows,d].  wb: per layer pack_weights(W[d,d] (in x out)) followed
+ * by b[d], layers back to back ((d*d+d) floats each).  If acts != NULL the post-activation
  * output of every layer but the last is stored there as [n_layers-1][rows][d] (backward).
  */
 int tspgnn_mlp_fwd_f32(const float* X, const float* wb, float* Y, float* acts,
@@ -83,9 +91,9 @@ int tspgnn_mlp_fwd_f32(const float* X, const float* wb, float* Y, float* acts,
 /*
  * One tf.contrib.rnn.LayerNormBasicLSTMCell(d, activation=relu) step, the cell call at
  * graphnn.py:168-170:  z=[x,h]K; i,j,f,o = LN_k(split(z)); c'=LN_s(c*sig(f+1)+sig(i)*relu(j));
- * h'=relu(c')*sig(o).  x:[rows,dx]  h,c,h_out,c_out:[rows,d]  K:[dx+d,4d]
+ * h'=relu(c')*sig(o).  x:[rows,dx]  h,c,h_out,c_out:[rows,d]  K: pack_weights(kernel[dx+d,4d])
  * ln: [5][2][d] = (gamma,beta) for input, transform, forget, output, state.
- * h_out/c_out may not alias h/c.  dx must be a multiple of 4.
+ * h_out/c_out may not alias h/c.  dx must be a multiple of 16.
  */
 int tspgnn_lnlstm_fwd_f32(const float* x, int dx, const float* h, const float* c,
                           const float* K, const float* ln, float* h_out, float* c_out,

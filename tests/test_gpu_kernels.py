@@ -31,6 +31,32 @@ def _release_uploads():
     del _KEEP[:]
 
 
+def packed(W, device):
+    """tspgnn_pack_weights_f32 of a host matrix -> device tensor (kept alive by dev())."""
+    src = dev(W, device)
+    out = torch.empty_like(src)
+    _KEEP.append(out)
+    _lib.call("tspgnn_pack_weights_f32", _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], None)
+    return out
+
+
+def test_pack_weights_is_a_permutation(cuda_device):
+    for kr, nc in ((64, 64), (32, 32), (128, 256), (48, 128), (256, 512)):
+        W = np.arange(kr * nc, dtype=np.float32).reshape(kr, nc)
+        P_ = packed(W, cuda_device).cpu().numpy().reshape(-1)
+        assert np.array_equal(np.sort(P_), W.reshape(-1))
+        # spot check the documented formula
+        U = nc // 64 if nc != 32 else 0
+        for i in (0, 5, 77, kr * nc - 1):
+            if nc == 32:
+                tt, jl, u, sg = i & 1, (i >> 1) & 15, 0, i >> 5
+            else:
+                tt, jl, u, sg = i & 3, (i >> 2) & 15, (i >> 6) % U, (i >> 6) // U
+            g, s_ = sg & 3, sg >> 2
+            krow = ((s_ >> 2) << 4) + (g << 2) + (s_ & 3)
+            assert P_[i] == W[krow, (u * 4 + tt) * 16 + jl]
+
+
 def test_library_is_loaded_in_tree():
     import os
     assert os.path.samefile(os.path.dirname(_lib.LIB_PATH), os.path.dirname(_lib.__file__))
@@ -107,7 +133,7 @@ def test_mlp_fwd(cuda_device, d, n_layers, mask, rows):
         W = (rng.randn(d, d) / np.sqrt(d)).astype(np.float32)
         b = (0.1 * rng.randn(d)).astype(np.float32)
         layers.append((W.astype(np.float64), b.astype(np.float64)))
-        flat += [W.reshape(-1), b]
+        flat += [packed(W, cuda_device).cpu().numpy().reshape(-1), b]
     acts_flags = [bool((mask >> l) & 1) for l in range(n_layers)]
     Y = torch.empty((rows, d), dtype=torch.float32, device=cuda_device)
     acts = torch.empty((max(n_layers - 1, 1), rows, d), dtype=torch.float32, device=cuda_device)
@@ -122,7 +148,7 @@ def test_mlp_fwd(cuda_device, d, n_layers, mask, rows):
     assert rel_err(Y.cpu().numpy(), x) < F32_TOL
 
 
-@pytest.mark.parametrize("d,dx", [(64, 64), (32, 32), (32, 64), (64, 0), (32, 16)])
+@pytest.mark.parametrize("d,dx", [(64, 64), (32, 32), (32, 64), (64, 0), (32, 16), (128, 128), (64, 192)])
 @pytest.mark.parametrize("rows", [1, 17, 1000])
 def test_lnlstm_fwd(cuda_device, d, dx, rows):
     rng = np.random.RandomState(rows * 7 + d + dx)
@@ -135,7 +161,7 @@ def test_lnlstm_fwd(cuda_device, d, dx, rows):
     c_out = torch.empty((rows, d), dtype=torch.float32, device=cuda_device)
     xd = dev(x, cuda_device) if dx else None
     _lib.call("tspgnn_lnlstm_fwd_f32", _lib.ptr(xd), dx, _lib.ptr(dev(h, cuda_device)), _lib.ptr(dev(c, cuda_device)),
-              _lib.ptr(dev(K, cuda_device)), _lib.ptr(dev(ln, cuda_device)), _lib.ptr(h_out), _lib.ptr(c_out), rows, d, None)
+              _lib.ptr(packed(K, cuda_device)), _lib.ptr(dev(ln, cuda_device)), _lib.ptr(h_out), _lib.ptr(c_out), rows, d, None)
     torch.cuda.synchronize()
     names = ("input", "transform", "forget", "output", "state")
     lnd = {g: (ln[i, 0].astype(np.float64), ln[i, 1].astype(np.float64)) for i, g in enumerate(names)}

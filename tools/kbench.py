@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Kernel-level timing at the C2 sizes (M=99840 edge rows, N=5120 vertex rows, d=64): each
+entry point in a back-to-back loop between two HIP events.  Development aid (gpurun)."""
+import os
+import sys
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tsp-gnn_amd"))
+import tspgnn  # noqa: E402
+from tspgnn import _lib  # noqa: E402
+
+dev = torch.device("cuda:0")
+d = int(os.environ.get("D", "64"))
+nsz = int(os.environ.get("NSZ", "40"))
+B = int(os.environ.get("B", "128"))
+EV, *_ = tspgnn.synthetic_batch([nsz] * B, seed=1234)
+M, N = EV.shape
+adj = tspgnn.DeviceAdjacency.from_sparse_ev(EV, dev)
+
+
+def timeit(fn, iters=200, warm=20):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def pack(W):
+    out = torch.empty_like(W)
+    _lib.call("tspgnn_pack_weights_f32", _lib.ptr(W), _lib.ptr(out), W.shape[0], W.shape[1], None)
+    return out
+
+
+res = {}
+for rows, tag in ((M, "E"), (N, "V")):
+    X = torch.randn(rows, d, device=dev)
+    H = torch.randn(rows, d, device=dev)
+    C = torch.randn(rows, d, device=dev)
+    Ho, Co, Y = torch.empty_like(H), torch.empty_like(C), torch.empty_like(X)
+    wb = torch.cat([torch.cat([pack(torch.randn(d, d, device=dev) / 8).view(-1), torch.randn(d, device=dev)]) for _ in range(4)])
+    K = pack(torch.randn(2 * d, 4 * d, device=dev) / 11)
+    ln = torch.cat([torch.ones(d, device=dev), torch.zeros(d, device=dev)] * 5)
+    t = timeit(lambda: _lib.call("tspgnn_mlp_fwd_f32", _lib.ptr(X), _lib.ptr(wb), _lib.ptr(Y), None, rows, d, 4, 7, None))
+    fl = rows * 4 * 2 * d * d
+    res["mlp4_" + tag] = (t, fl / t / 1e6)
+    t = timeit(lambda: _lib.call("tspgnn_lnlstm_fwd_f32", _lib.ptr(X), d, _lib.ptr(H), _lib.ptr(C), _lib.ptr(K), _lib.ptr(ln),
+                                 _lib.ptr(Ho), _lib.ptr(Co), rows, d, None))
+    fl = rows * 2 * 2 * d * 4 * d
+    res["lnlstm_" + tag] = (t, fl / t / 1e6)
+Xv = torch.randn(N, d, device=dev); Ze = torch.randn(M, d, device=dev)
+Ye = torch.empty(M, d, device=dev); Yv = torch.empty(N, d, device=dev)
+rowptr, eid, _ = adj.csr_t
+gb = N * d * 4 + 2 * M * 4 + M * d * 4
+rb = M * d * 4 + (2 * M + N + 1) * 4 + N * d * 4
+t = timeit(lambda: _lib.call("tspgnn_gather2_sum_f32", _lib.ptr(adj.uv), _lib.ptr(Xv), _lib.ptr(Ye), M, N, d, None))
+res["gather2"] = (t, gb / t / 1e3)
+t = timeit(lambda: _lib.call("tspgnn_csr_rowsum_f32", _lib.ptr(rowptr), _lib.ptr(eid), _lib.ptr(Ze), _lib.ptr(Yv), N, M, d, None))
+res["rowsum"] = (t, rb / t / 1e3)
+for k, (t, r) in res.items():
+    unit = "GB/s" if k in ("gather2", "rowsum") else "TFLOP/s"
+    print("%-12s %8.2f us  %8.1f %s" % (k, t, r, unit))

@@ -12,6 +12,8 @@
 // f(s,g) = q*16 + g*4 + p.  The weights are stored in LDS with their rows permuted accordingly,
 // so activations never leave registers between layers and never cross lanes.  The same
 // fragment shape (float4 at column q*16+g*4 of a row) is used for global loads and stores.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace tspgnn {
@@ -21,43 +23,55 @@ namespace tspgnn {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-// Copies a [krows, ncols] row-major weight matrix into LDS in MFMA A-fragment order:
-//   dst[(((s*4+g)*U + u)*16 + jl)*4 + tt] = W[krow(s,g)][(u*4+tt)*16 + jl],
-//   krow(s,g) = (s>>2)*16 + g*4 + (s&3),  U = ncols/64.
-// One ds_read_b128 at dst + ((s*4+g)*U+u)*64 + jl*4 then feeds four MFMAs (tiles 4u..4u+3)
-// and is bank-conflict free (16 lanes x 16 B = one 256 B bank row per lane group).
-__device__ __forceinline__ void stage_weights_b128(float* dst, const float* __restrict__ W, int krows, int ncols,
-                                                   int tid, int nthreads) {
-    const int U = ncols >> 6;
-    const int n4 = (krows * ncols) >> 2;
-    for (int i = tid; i < n4; i += nthreads) {
-        const int jl = i & 15;
-        const int u = (i >> 4) % U;
-        const int sg = (i >> 4) / U;
+// MFMA A-fragment order of a [krows, ncols] row-major weight matrix W (the "packed" layout the
+// kernels keep in LDS; produced once per weight update by tspgnn_pack_weights_f32):
+//   ncols % 64 == 0:  P[(((s*4+g)*U + u)*16 + jl)*4 + tt] = W[krow(s,g)][(u*4+tt)*16 + jl],  U = ncols/64
+//   ncols == 32    :  P[((s*4+g)*16 + jl)*2 + tt]         = W[krow(s,g)][tt*16 + jl]
+//   krow(s,g) = (s>>2)*16 + g*4 + (s&3)      (k-step s of 4 rows, lane group g)
+// One ds_read_b128 at P + ((s*4+g)*U+u)*64 + jl*4 then feeds four MFMAs (tiles 4u..4u+3) and is
+// bank-conflict free (16 lanes x 16 B = one 256 B bank row per lane group).
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ W, float* __restrict__ P,
+                                                           int krows, int ncols) {
+    const int total = krows * ncols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int tt, jl, u, sg;
+        if (ncols == 32) {
+            tt = i & 1;
+            jl = (i >> 1) & 15;
+            u = 0;
+            sg = i >> 5;
+        } else {
+            const int U = ncols >> 6;
+            tt = i & 3;
+            jl = (i >> 2) & 15;
+            u = (i >> 6) % U;
+            sg = (i >> 6) / U;
+        }
         const int g = sg & 3, s = sg >> 2;
         const int krow = ((s >> 2) << 4) + (g << 2) + (s & 3);
-        const float* src = W + (size_t)krow * ncols + (u << 6) + jl;
-        f32x4 v;
-        v[0] = src[0];
-        v[1] = src[16];
-        v[2] = src[32];
-        v[3] = src[48];
-        st4(dst + (size_t)i * 4, v);
+        P[i] = W[(size_t)krow * ncols + (u * 4 + tt) * 16 + jl];
     }
 }
 
-// Same for ncols == 32 (two output tiles): dst[((s*4+g)*16 + jl)*2 + tt].
-__device__ __forceinline__ void stage_weights_b64(float* dst, const float* __restrict__ W, int krows, int tid,
-                                                  int nthreads) {
-    const int n2 = (krows * 32) >> 1;
-    for (int i = tid; i < n2; i += nthreads) {
-        const int jl = i & 15;
-        const int sg = i >> 4;
-        const int g = sg & 3, s = sg >> 2;
-        const int krow = ((s >> 2) << 4) + (g << 2) + (s & 3);
-        const float* src = W + (size_t)krow * 32 + jl;
-        dst[2 * i] = src[0];
-        dst[2 * i + 1] = src[16];
+// Straight float4 copy global -> LDS with 8 loads in flight per thread (the weights are already in
+// fragment order, so staging is a pure, fully coalesced stream).
+__device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int nfloats, int tid,
+                                            int nthreads) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+    const int n4 = nfloats >> 2;
+    for (int base = tid; base < n4; base += nthreads * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * nthreads;
+            if (idx < n4) v[u] = s4[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * nthreads;
+            if (idx < n4) d4[idx] = v[u];
+        }
     }
 }
 
@@ -88,6 +102,36 @@ __device__ __forceinline__ int frag_off(int s, int g, int jl) {
         return (s * 4 + g) * (NT / 4) * 64 + jl * 4;
 }
 
+// NSTEPS consecutive k-steps (fragment rows s0 .. s0+NSTEPS-1, contiguous in LDS) with the weight
+// fragments double-buffered in registers: the ds_reads of step s+1 are issued before the MFMAs
+// of step s.  b[s] is the B-operand value of step s.
+template <int NT, int NSTEPS>
+__device__ __forceinline__ void ksteps(f32x4 (&acc)[NT], const float* w0, const float (&b)[NSTEPS]) {
+    static_assert(NT % 4 == 0, "b128 fragment path");
+    constexpr int U = NT / 4;
+    constexpr int STRIDE = NT * 64;  // floats between the fragment rows of consecutive k-steps
+    f32x4 w[2][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[0][u] = ld4(w0 + u * 64);
+#pragma unroll
+    for (int s = 0; s < NSTEPS; ++s) {
+        if (s + 1 < NSTEPS) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[(s + 1) & 1][u] = ld4(w0 + (s + 1) * STRIDE + u * 64);
+        }
+        // Pin the order: the ds_reads of step s+1 stay ABOVE the MFMAs of step s (their s_waitcnt
+        // lands at their first use, one step later), so one wavefront alone keeps the matrix pipe
+        // busy instead of alternating "read, wait, 4 MFMA".
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[u * 4 + tt] = MFMA16(w[s & 1][u][tt], b[s], acc[u * 4 + tt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---------------------------------------------------------------------------------- MLP
 // Persistent workgroups: all layer weights (permuted) + biases live in LDS for the lifetime of
 // the block; each wavefront pulls 16-row tiles from the block's contiguous tile range through
@@ -105,10 +149,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(const float* __restrict__ 
     const int tid = threadIdx.x;
     for (int l = 0; l < n_layers; ++l) {
         const float* Wl = wb + (size_t)l * (D * D + D);
-        if constexpr (NT == 2)
-            stage_weights_b64(lds_w + l * D * D, Wl, D, tid, blockDim.x);
-        else
-            stage_weights_b128(lds_w + l * D * D, Wl, D, D, tid, blockDim.x);
+        copy_to_lds(lds_w + l * D * D, Wl, D * D, tid, blockDim.x);
         for (int i = tid; i < D; i += blockDim.x) lds_b[l * D + i] = Wl[D * D + i];
     }
     const int t_beg = (int)((long long)tiles_total * blockIdx.x / gridDim.x);
@@ -133,8 +174,18 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(const float* __restrict__ 
             f32x4 acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = ld4(lds_b + l * D + t * 16 + g * 4);
+            if constexpr (NT == 2) {
 #pragma unroll
-            for (int s = 0; s < D / 4; ++s) kstep<NT>(acc, wl + frag_off<NT>(s, g, rl), a[s >> 2][s & 3]);
+                for (int s = 0; s < D / 4; ++s) kstep<NT>(acc, wl + frag_off<NT>(s, g, rl), a[s >> 2][s & 3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NT; q += 4) {  // 16 k-steps per call
+                    float b[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) b[i] = a[q + (i >> 2)][i & 3];
+                    ksteps<NT, 16>(acc, wl + frag_off<NT>(q * 4, g, rl), b);
+                }
+            }
             const bool relu = (relu_mask >> l) & 1u;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -178,7 +229,7 @@ __device__ __forceinline__ void ln_gate(f32x4 (&v)[TPG], const float* gamma, con
     q = sum_over_lane_groups16(q);
     const float var = q / (float)D;
     // tf.contrib.layers.layer_norm: variance_epsilon = 1e-12; x*inv + (beta - mean*inv)
-    const float rstd = 1.0f / sqrtf(var + 1e-12f);
+    const float rstd = __builtin_amdgcn_rsqf(var + 1e-12f);  // v_rsq_f32, ~1 ulp
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
         const f32x4 ga = ld4(gamma + t * 16 + g * 4);
@@ -191,14 +242,95 @@ __device__ __forceinline__ void ln_gate(f32x4 (&v)[TPG], const float* gamma, con
     }
 }
 
-// K ([dx+D, 4D], permuted) and the five LayerNorm (gamma,beta) pairs stay resident in LDS;
-// requires (dx+D)*4D*4 + 10*D*4 + 16 bytes <= 160 KiB (D=64, dx=64: 130.5 KiB).
+// k-loop of one 16-row tile over the 16-row blocks q in [q_beg, q_end) of the concatenated [x|h]
+// operand; lds_k holds the fragment rows of k-steps starting at block q_base.  The B-operand
+// fragments are fetched four blocks (256 MFMAs, ~3.4 us of matrix work) ahead of their use so
+// that the global-load latency is hidden behind the MFMA stream of the same wavefront.
 template <int D>
-__global__ __launch_bounds__(512) void lnlstm_fwd_kernel(const float* __restrict__ x, int dx,
+__device__ __forceinline__ void lstm_kloop(f32x4 (&acc)[D / 4], const float* lds_k, int q_base, int q_beg, int q_end,
+                                           const float* xrow, const float* hrow, int QX, int g, int rl) {
+    constexpr int NT4 = D / 4;
+    constexpr int GQ = 4;
+    if (q_beg >= q_end) return;
+    auto frag = [&](int q) -> f32x4 {
+        const int qq = q < q_end ? q : q_end - 1;  // clamp: tail loads stay in bounds
+        return ld4(qq < QX ? xrow + qq * 16 : hrow + (qq - QX) * 16);
+    };
+    f32x4 cur[GQ], nxt[GQ];
+#pragma unroll
+    for (int i = 0; i < GQ; ++i) cur[i] = frag(q_beg + i);
+    for (int q0 = q_beg; q0 < q_end; q0 += GQ) {
+        if (q0 + GQ < q_end) {
+#pragma unroll
+            for (int i = 0; i < GQ; ++i) nxt[i] = frag(q0 + GQ + i);
+        }
+        if (q0 + GQ <= q_end) {
+            float b[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) b[i] = cur[i >> 2][i & 3];
+            ksteps<NT4, 16>(acc, lds_k + frag_off<NT4>((q0 - q_base) * 4, g, rl), b);
+        } else {
+#pragma unroll
+            for (int i = 0; i < GQ; ++i) {
+                if (q0 + i < q_end) {
+                    float b[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) b[p] = cur[i][p];
+                    ksteps<NT4, 4>(acc, lds_k + frag_off<NT4>((q0 + i - q_base) * 4, g, rl), b);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GQ; ++i) cur[i] = nxt[i];
+    }
+}
+
+// split(z) = i, j, f, o (that order); LN each; c' = LN(c*sig(f+1) + sig(i)*relu(j)); h' = relu(c')*sig(o)
+template <int D>
+__device__ __forceinline__ void lstm_epilogue(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 16], const float* lds_ln, int g,
+                                              bool valid, float* hd, float* cd) {
+    constexpr int TPG = D / 16;
+    f32x4 gi[TPG], gj[TPG], gf[TPG], go[TPG];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        gi[t] = acc[t];
+        gj[t] = acc[TPG + t];
+        gf[t] = acc[2 * TPG + t];
+        go[t] = acc[3 * TPG + t];
+    }
+    ln_gate<TPG>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D);
+    ln_gate<TPG>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D);
+    ln_gate<TPG>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D);
+    ln_gate<TPG>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D);
+    f32x4 nc[TPG];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            nc[t][r] = cf[t][r] * sigmoidf_(gf[t][r] + 1.0f) + sigmoidf_(gi[t][r]) * fmaxf(gj[t][r], 0.f);
+    }
+    ln_gate<TPG>(nc, lds_ln + 8 * D, lds_ln + 9 * D, g, D);
+    if (valid) {
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) {
+            f32x4 hn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hn[r] = fmaxf(nc[t][r], 0.f) * sigmoidf_(go[t][r]);
+            st4(hd + t * 16, hn);
+            st4(cd + t * 16, nc[t]);
+        }
+    }
+}
+
+// Resident variant: K ([dx+D, 4D], packed) and the five LayerNorm (gamma,beta) pairs stay in LDS
+// for the lifetime of the block; requires (dx+D)*4D*4 + 10*D*4 + 16 bytes <= 160 KiB
+// (D=64, dx=64: 130.5 KiB).  Wavefronts pull tiles through an LDS ticket counter.
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void lnlstm_fwd_kernel(const float* __restrict__ x, int dx,
                                                          const float* __restrict__ h, const float* __restrict__ c,
                                                          const float* __restrict__ K, const float* __restrict__ ln,
                                                          float* __restrict__ h_out, float* __restrict__ c_out,
-                                                         int rows, int tiles_total) {
+                                                         int rows, int tiles_total, int dbg) {
     constexpr int NT4 = D / 4;   // output tiles of z (4D columns)
     constexpr int TPG = D / 16;  // tiles per gate
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -208,7 +340,7 @@ __global__ __launch_bounds__(512) void lnlstm_fwd_kernel(const float* __restrict
     int* ticket = reinterpret_cast<int*>(lds_ln + 10 * D);
 
     const int tid = threadIdx.x;
-    stage_weights_b128(lds_k, K, krows, 4 * D, tid, blockDim.x);
+    if (!(dbg & 4)) copy_to_lds(lds_k, K, krows * 4 * D, tid, blockDim.x);
     for (int i = tid; i < 10 * D; i += blockDim.x) lds_ln[i] = ln[i];
     const int t_beg = (int)((long long)tiles_total * blockIdx.x / gridDim.x);
     const int t_end = (int)((long long)tiles_total * (blockIdx.x + 1) / gridDim.x);
@@ -217,6 +349,10 @@ __global__ __launch_bounds__(512) void lnlstm_fwd_kernel(const float* __restrict
 
     const int lane = tid & 63, rl = lane & 15, g = lane >> 4;
     const int QX = dx >> 4, QT = QX + TPG;
+    if ((dbg & 8) && __builtin_amdgcn_readfirstlane(tid >> 6) >= 4) {
+        __builtin_amdgcn_s_sleep(127);
+        if (dbg & 16) __builtin_amdgcn_s_sleep(127);
+    }
     for (;;) {
         int tile = 0;
         if (lane == 0) tile = atomicAdd(ticket, 1);
@@ -225,57 +361,66 @@ __global__ __launch_bounds__(512) void lnlstm_fwd_kernel(const float* __restrict
         const int row = tile * 16 + rl;
         const bool valid = row < rows;
         const size_t rc = (size_t)(valid ? row : rows - 1);
-        const float* xrow = x + rc * dx + g * 4;
-        const float* hrow = h + rc * D + g * 4;
         f32x4 cf[TPG];
 #pragma unroll
         for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + rc * D + g * 4 + t * 16);
-
         f32x4 acc[NT4];
 #pragma unroll
         for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 cur = ld4(QX > 0 ? xrow : hrow);
-        for (int q = 0; q < QT; ++q) {
-            const int qn = q + 1;
-            f32x4 nxt = cur;
-            if (qn < QT) nxt = ld4(qn < QX ? xrow + qn * 16 : hrow + (qn - QX) * 16);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) kstep<NT4>(acc, lds_k + frag_off<NT4>(q * 4 + p, g, rl), cur[p]);
-            cur = nxt;
-        }
-        // split(z) = i, j, f, o (that order); LN each; c' = LN(c*sig(f+1) + sig(i)*relu(j)); h' = relu(c')*sig(o)
-        f32x4 gi[TPG], gj[TPG], gf[TPG], go[TPG];
-#pragma unroll
-        for (int t = 0; t < TPG; ++t) {
-            gi[t] = acc[t];
-            gj[t] = acc[TPG + t];
-            gf[t] = acc[2 * TPG + t];
-            go[t] = acc[3 * TPG + t];
-        }
-        ln_gate<TPG>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D);
-        ln_gate<TPG>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D);
-        ln_gate<TPG>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D);
-        ln_gate<TPG>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D);
-        f32x4 nc[TPG];
-#pragma unroll
-        for (int t = 0; t < TPG; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                nc[t][r] = cf[t][r] * sigmoidf_(gf[t][r] + 1.0f) + sigmoidf_(gi[t][r]) * fmaxf(gj[t][r], 0.f);
-        }
-        ln_gate<TPG>(nc, lds_ln + 8 * D, lds_ln + 9 * D, g, D);
-        if (valid) {
-            float* hd = h_out + rc * D + g * 4;
-            float* cd = c_out + rc * D + g * 4;
+        if (!(dbg & 1)) lstm_kloop<D>(acc, lds_k, 0, 0, QT, x + rc * dx + g * 4, h + rc * D + g * 4, QX, g, rl);
+        if (!(dbg & 2)) {
+            lstm_epilogue<D>(acc, cf, lds_ln, g, valid, h_out + rc * D + g * 4, c_out + rc * D + g * 4);
+        } else if (valid) {
 #pragma unroll
             for (int t = 0; t < TPG; ++t) {
-                f32x4 hn;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hn[r] = fmaxf(nc[t][r], 0.f) * sigmoidf_(go[t][r]);
-                st4(hd + t * 16, hn);
-                st4(cd + t * 16, nc[t]);
+                st4(h_out + rc * D + g * 4 + t * 16, acc[t] + acc[t + TPG] + cf[t]);
+                st4(c_out + rc * D + g * 4 + t * 16, acc[t + 2 * TPG] + acc[t + 3 * TPG]);
             }
         }
+    }
+}
+
+// Chunked variant for a K that does not fit LDS (D=128: K is 512 KiB): the block's 8 wavefronts
+// take one tile each per round and walk K in chunks of `qc` 16-row blocks that are re-staged
+// into LDS between barriers (packed K is k-step major, so a chunk is one contiguous slice).
+template <int D>
+__global__ __launch_bounds__(512) void lnlstm_fwd_chunked_kernel(const float* __restrict__ x, int dx,
+                                                                 const float* __restrict__ h,
+                                                                 const float* __restrict__ c,
+                                                                 const float* __restrict__ K,
+                                                                 const float* __restrict__ ln,
+                                                                 float* __restrict__ h_out, float* __restrict__ c_out,
+                                                                 int rows, int tiles_total, int qc) {
+    constexpr int NT4 = D / 4;
+    constexpr int TPG = D / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lds_k = lds;
+    float* lds_ln = lds + (size_t)qc * 16 * 4 * D;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 10 * D; i += blockDim.x) lds_ln[i] = ln[i];
+    const int lane = tid & 63, rl = lane & 15, g = lane >> 4, wave = tid >> 6;
+    const int QX = dx >> 4, QT = QX + TPG;
+    const int rounds = (tiles_total + 7) / 8;
+    for (int r = blockIdx.x; r < rounds; r += gridDim.x) {
+        const int tile = r * 8 + wave;
+        const bool live = tile < tiles_total;  // wave-uniform
+        const int row = tile * 16 + rl;
+        const bool valid = live && row < rows;
+        const size_t rc = (size_t)(valid ? row : rows - 1);
+        f32x4 cf[TPG];
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + rc * D + g * 4 + t * 16);
+        f32x4 acc[NT4];
+#pragma unroll
+        for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q0 = 0; q0 < QT; q0 += qc) {
+            const int q1 = min(QT, q0 + qc);
+            __syncthreads();  // previous chunk fully consumed
+            copy_to_lds(lds_k, K + (size_t)q0 * 16 * 4 * D, (q1 - q0) * 16 * 4 * D, tid, blockDim.x);
+            __syncthreads();
+            if (live) lstm_kloop<D>(acc, lds_k, q0, q0, q1, x + rc * dx + g * 4, h + rc * D + g * 4, QX, g, rl);
+        }
+        lstm_epilogue<D>(acc, cf, lds_ln, g, valid, h_out + rc * D + g * 4, c_out + rc * D + g * 4);
     }
 }
 
@@ -296,33 +441,71 @@ static int launch_mlp(const float* X, const float* wb, float* Y, float* acts, in
     const int lds_bytes = MAXL * (D * D + D) * 4 + 16;
     const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
     int grid = n_cus() * per_cu;
-    const int max_grid = (tiles + 7) / 8;  // at least one tile per wave
+    const int nw = tiles <= grid * 4 ? 4 : 8;  // few tiles: one wavefront per SIMD, more workgroups
+    const int max_grid = (tiles + nw - 1) / nw;  // at least one tile per wave
     if (grid > max_grid) grid = max_grid;
-    mlp_fwd_kernel<D, MAXL><<<grid, 512, 0, st>>>(X, wb, Y, acts, rows, n_layers, relu_mask, tiles);
+    mlp_fwd_kernel<D, MAXL><<<grid, nw * 64, 0, st>>>(X, wb, Y, acts, rows, n_layers, relu_mask, tiles);
     return launched("tspgnn_mlp_fwd_f32");
 }
 
 template <int D>
 static int launch_lnlstm(const float* x, int dx, const float* h, const float* c, const float* K, const float* ln,
                          float* h_out, float* c_out, int rows, hipStream_t st) {
-    const size_t lds_bytes = ((size_t)(dx + D) * 4 * D + 10 * D + 4) * sizeof(float);
-    if (lds_bytes > 160 * 1024)
-        return fail(TSPGNN_EUNSUPPORTED, "lnlstm_fwd: K[%d,%d] does not fit LDS (%zu B)", dx + D, 4 * D, lds_bytes);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlstm_fwd_kernel<D>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return fail((int)e, "lnlstm_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int tiles = (rows + 15) / 16;
-    const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
-    int grid = n_cus() * per_cu;
-    const int max_grid = (tiles + 7) / 8;
-    if (grid > max_grid) grid = max_grid;
-    lnlstm_fwd_kernel<D><<<grid, 512, lds_bytes, st>>>(x, dx, h, c, K, ln, h_out, c_out, rows, tiles);
+    const size_t extra = (10 * D + 4) * sizeof(float);
+    const size_t resident = (size_t)(dx + D) * 4 * D * sizeof(float) + extra;
+    const size_t kLdsMax = 160 * 1024;
+    if (resident <= kLdsMax) {
+        static const int dbg = getenv("TSPGNN_DBG") ? atoi(getenv("TSPGNN_DBG")) : 0;  // development only
+        static const int nw_env = getenv("TSPGNN_NW") ? atoi(getenv("TSPGNN_NW")) : 0;  // development only
+        const int per_cu = resident > 80 * 1024 ? 1 : 2;
+        // Few tiles (the vertex side): one wavefront per SIMD and more, smaller workgroups, so every
+        // tile gets a matrix pipe to itself; many tiles (the edge side): two wavefronts per SIMD.
+        const int nw = nw_env ? nw_env : (tiles <= n_cus() * per_cu * 4 ? 4 : 8);
+        int grid = n_cus() * per_cu;
+        const int max_grid = (tiles + nw - 1) / nw;
+        if (grid > max_grid) grid = max_grid;
+        auto go = [&](auto kern, int threads) -> int {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident);
+            if (e != hipSuccess) return fail((int)e, "lnlstm_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            kern<<<grid, threads, resident, st>>>(x, dx, h, c, K, ln, h_out, c_out, rows, tiles, dbg);
+            return launched("tspgnn_lnlstm_fwd_f32");
+        };
+        if (nw == 4) return go(&lnlstm_fwd_kernel<D, 4>, 256);
+        if (nw == 12) return go(&lnlstm_fwd_kernel<D, 12>, 768);
+        if (nw == 16) return go(&lnlstm_fwd_kernel<D, 16>, 1024);
+        return go(&lnlstm_fwd_kernel<D, 8>, 512);
+    }
+    // chunk = as many 16-row blocks of K as fit 128 KiB
+    const int qc = (int)((128 * 1024) / (16 * 4 * D * sizeof(float)));
+    const size_t chunked = (size_t)qc * 16 * 4 * D * sizeof(float) + extra;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlstm_fwd_chunked_kernel<D>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)chunked);
+    if (e != hipSuccess) return fail((int)e, "lnlstm_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    int grid = n_cus();
+    const int rounds = (tiles + 7) / 8;
+    if (grid > rounds) grid = rounds;
+    lnlstm_fwd_chunked_kernel<D><<<grid, 512, chunked, st>>>(x, dx, h, c, K, ln, h_out, c_out, rows, tiles, qc);
     return launched("tspgnn_lnlstm_fwd_f32");
 }
 
 }  // namespace tspgnn
 
 using namespace tspgnn;
+
+extern "C" int tspgnn_pack_weights_f32(const float* W, float* P, int krows, int ncols, void* stream) {
+    TSPGNN_REQUIRE(krows >= 0 && krows % 16 == 0, "pack_weights: krows=%d must be a multiple of 16", krows);
+    TSPGNN_REQUIRE(ncols == 32 || (ncols > 0 && ncols % 64 == 0), "pack_weights: ncols=%d must be 32 or a multiple of 64",
+                   ncols);
+    if (krows == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(W && P && W != P, "pack_weights: null or aliased pointer");
+    const int total = krows * ncols;
+    int grid = (total + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    pack_weights_kernel<<<grid, 256, 0, as_stream(stream)>>>(W, P, krows, ncols);
+    return launched("tspgnn_pack_weights_f32");
+}
 
 extern "C" int tspgnn_mlp_fwd_f32(const float* X, const float* wb, float* Y, float* acts, int rows, int d,
                                   int n_layers, unsigned relu_mask, void* stream) {

@@ -128,6 +128,17 @@ class LayerNormBasicLSTMCell(object):
     def kernel(self):
         return self.store.view(self.base + "/kernel")
 
+    def kernel_packed(self):
+        """The kernel in MFMA fragment order (tspgnn_pack_weights_f32), cached per weight version."""
+        def build(out):
+            K = self.kernel()
+            if out is None:
+                out = torch.empty_like(K)
+            _lib.call("tspgnn_pack_weights_f32", _lib.ptr(K), _lib.ptr(out), self.dx + self.d, 4 * self.d,
+                      _lib.current_stream())
+            return out
+        return self.store.packed(("lstm", self.base), build)
+
     def ln(self):
         return self.store.span(self.base + "/input/gamma", self.base + "/state/beta")
 
@@ -140,7 +151,7 @@ class LayerNormBasicLSTMCell(object):
         x = inputs if inputs.is_contiguous() else inputs.contiguous()
         h_out = torch.empty_like(h)
         c_out = torch.empty_like(c)
-        _lib.call("tspgnn_lnlstm_fwd_f32", _lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(self.kernel()),
+        _lib.call("tspgnn_lnlstm_fwd_f32", _lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(self.kernel_packed()),
                   _lib.ptr(self.ln()), _lib.ptr(h_out), _lib.ptr(c_out), rows, self.d, _lib.current_stream())
         return h_out, LSTMStateTuple(c=c_out, h=h_out)
 

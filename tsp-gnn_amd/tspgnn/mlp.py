@@ -88,6 +88,22 @@ class Mlp(object):
         last = len(self.layer_names) - 1 if last is None else last
         return self.store.span(self.layer_names[first] + "/kernel", self.layer_names[last] + "/bias")
 
+    def wb_packed(self, first, last, d):
+        """[pack(W),b,...] for square layers first..last: the weights in MFMA fragment order
+        (tspgnn_pack_weights_f32), cached until the variables change."""
+        def build(out):
+            src = self.wb(first, last)
+            if out is None:
+                out = torch.empty_like(src)
+            st = _lib.current_stream()
+            per = d * d + d
+            for j in range(last - first + 1):
+                o = j * per
+                _lib.call("tspgnn_pack_weights_f32", _lib.ptr(src[o:o + d * d]), _lib.ptr(out[o:o + d * d]), d, d, st)
+                out[o + d * d:o + per].copy_(src[o + d * d:o + per])
+            return out
+        return self.store.packed(("mlp", self.name, first, last), build)
+
     # ------------------------------------------------------------------ forward
     def __call__(self, inputs, save=None):
         """inputs: fp32 device tensor [rows, input_size].  ``save`` (optional list) receives the
@@ -118,7 +134,7 @@ class Mlp(object):
             acts = None
             if save is not None and n > 1:
                 acts = torch.empty((n - 1, rows, d), dtype=torch.float32, device=x.device)
-            _lib.call("tspgnn_mlp_fwd_f32", _lib.ptr(x), _lib.ptr(self.wb(l0, l0 + n - 1)), _lib.ptr(out),
+            _lib.call("tspgnn_mlp_fwd_f32", _lib.ptr(x), _lib.ptr(self.wb_packed(l0, l0 + n - 1, d)), _lib.ptr(out),
                       _lib.ptr(acts), rows, d, n, mask, st)
             if save is not None:
                 save.append((l0, n, x, acts, out))

@@ -44,6 +44,8 @@ class VariableStore(object):
         self._offsets = None
         self.theta = None
         self.device = None
+        self.version = 0      # bumped whenever theta changes; keys the packed-weight cache
+        self._packed = {}
 
     # -- declaration phase -------------------------------------------------------------
     def declare(self, name, shape, initializer):
@@ -91,6 +93,21 @@ class VariableStore(object):
             off, n = self._offsets[name]
             host[off:off + n] = init(shape, gen).reshape(-1).to(torch.float32)
         self.theta.copy_(host)
+        self.touch()
+
+    def touch(self):
+        """Call after modifying theta in place (initialise / restore / optimiser step)."""
+        self.version += 1
+
+    def packed(self, key, build):
+        """Derived, kernel-ready copy of some variables (MFMA fragment order), rebuilt lazily when
+        theta has changed since it was made.  ``build(out_or_None)`` returns the tensor."""
+        ent = self._packed.get(key)
+        if ent is None or ent[0] != self.version:
+            t = build(None if ent is None else ent[1])
+            self._packed[key] = (self.version, t)
+            return t
+        return ent[1]
 
     def view(self, name):
         off, n = self._offsets[name]
@@ -115,6 +132,7 @@ class VariableStore(object):
                 raise ValueError("shape mismatch for %s: expected %s" % (name, self._decl[name][0]))
             host[off:off + n] = torch.from_numpy(arr.copy())
         self.theta.copy_(host)
+        self.touch()
 
     def state_dict(self):
         host = self.theta.detach().cpu().numpy()
