@@ -72,10 +72,11 @@ int tspgnn_csr_spmm_f32(const int32_t* rowptr, const int32_t* col, const float* 
 /*
  * P = W reordered into the MFMA A-fragment order the dense kernels stage into LDS (layout
  * documented in csrc/dense.hip).  W:[krows,ncols] row-major; krows % 16 == 0; ncols == 32 or
- * ncols % 64 == 0.  Run once per weight update (the reference re-reads its tf.Variables every
+ * ncols % 64 == 0.  transposed != 0: W is stored [ncols,krows] and P packs W^T (the backward
+ * kernels multiply by the transposed weights).  Run once per weight update (the reference re-reads its tf.Variables every
  * sess.run; here the packed copy is refreshed after initialisation / restore / Adam).
  */
-int tspgnn_pack_weights_f32(const float* W, float* P, int krows, int ncols, void* stream);
+int tspgnn_pack_weights_f32(const float* W, float* P, int krows, int ncols, int transposed, void* stream);
 
 /*
  * n_layers (1..4) chained tf.layers.Dense(d) layers: x <- act_l(x W_l + b_l); layer l applies
@@ -83,9 +84,10 @@ int tspgnn_pack_weights_f32(const float* W, float* P, int krows, int ncols, void
  * for the message MLPs (graphnn.py:114-125,153) and the hidden part of E_vote
  * (model.py:107-115).  X,Y:[rows,d].  wb: per layer pack_weights(W[d,d] (in x out)) followed
  * by b[d], layers back to back ((d*d+d) floats each).  If acts != NULL the post-activation
- * output of every layer but the last is stored there as [n_layers-1][rows][d] (backward).
+ * output of every layer but the last is stored at acts + l*acts_stride + row*d (backward);
+ * acts_stride (floats) = 0 means rows*d.
  */
-int tspgnn_mlp_fwd_f32(const float* X, const float* wb, float* Y, float* acts,
+int tspgnn_mlp_fwd_f32(const float* X, const float* wb, float* Y, float* acts, long long acts_stride,
                        int rows, int d, int n_layers, unsigned relu_mask, void* stream);
 
 /*
@@ -131,6 +133,91 @@ int tspgnn_segment_mean_f32(const float* vote, const int32_t* seg, float* logits
  */
 int tspgnn_bce_metrics_f32(const float* logits, const float* labels, float* pred, float* stats,
                            int B, void* stream);
+
+/* ------------------------------------------------------------------ backward (tf.gradients, model.py:166) */
+
+/*
+ * Y = X W for a weight matrix resident in LDS: X:[rows,kin], Wp = pack_weights(W[kin,n1+n2]);
+ * columns [0,n1) are written to Y1:[rows,n1], the rest to Y2:[rows,n2] (added to Y2 when
+ * accumulate2 != 0).  n1+n2 in {64,128,256}; kin % 16 == 0.  Used for the data gradient of the LSTM
+ * GEMM: [dx | dh] = dz K^T with Wp = pack_weights(K, transposed=1).
+ */
+int tspgnn_linear_f32(const float* X, int kin, const float* Wp, float* Y1, int n1, float* Y2, int n2,
+                      int accumulate2, int rows, void* stream);
+
+/* Workspace (floats) tspgnn_lnlstm_bwd_f32 needs for width d. */
+long long tspgnn_lnlstm_bwd_workspace_floats(int d);
+
+/*
+ * Backward of one LayerNormBasicLSTMCell step (the gradient of graphnn.py:168-170).  Inputs are the
+ * forward inputs (x,h,c,K packed,ln) plus dh_out/dc_out = gradients w.r.t. the step's outputs
+ * (h', c'); either may be NULL (= zero).  Recomputes z, then writes dz:[rows,4d] (gradient w.r.t.
+ * z = [x,h]K, consumed by tspgnn_linear_f32 and tspgnn_wgrad_f32), dc_in:[rows,d], and ADDS the
+ * LayerNorm parameter gradients to ln_grad ([5][2][d], same layout as ln).
+ */
+int tspgnn_lnlstm_bwd_f32(const float* x, int dx, const float* h, const float* c, const float* K,
+                          const float* ln, const float* dh_out, const float* dc_out, float* dz,
+                          float* dc_in, float* ln_grad, float* workspace, int rows, int d, void* stream);
+
+/*
+ * Data gradient of tspgnn_mlp_fwd_f32: g = dY; for l = n_layers-1..0: mask by the saved activation of
+ * layer l if it had relu (acts as written by mlp_fwd; Yout = forward output, only read when the
+ * last layer has relu); dpre + l*dpre_stride <- g (gradient w.r.t. the layer's pre-activation; NULL
+ * to skip); g <- g W_l^T.  Finally dX (+)= g (NULL to skip).  wt: per layer
+ * pack_weights(W_l, transposed=1), d*d floats each, back to back.
+ */
+int tspgnn_mlp_bwd_f32(const float* dY, const float* wt, const float* acts, long long acts_stride,
+                       const float* Yout, float* dpre, long long dpre_stride, float* dX,
+                       int accumulate_dx, int rows, int d, int n_layers, unsigned relu_mask, void* stream);
+
+/* Workspace (floats) tspgnn_wgrad_f32 needs. */
+long long tspgnn_wgrad_workspace_floats(long long rows, int kin, int nout);
+
+/*
+ * dW[kin,nout] += X^T dY and (db != NULL) db[nout] += colsum(dY); X:[rows,kin], dY:[rows,nout],
+ * kin and nout multiples of 16.  rows may span all time steps of a batch (the per-step
+ * activations and pre-activation gradients are stored contiguously), so each tf.Variable gets ONE
+ * reduction.  Deterministic: fixed row chunks, partials in the workspace, one pass over chunks.
+ */
+int tspgnn_wgrad_f32(const float* X, const float* dY, long long rows, int kin, int nout, float* dW,
+                     float* db, float* workspace, void* stream);
+
+/* dvote[e] = (sigmoid(logits[p]) - labels[p]) / (B * n_edges[p]) for e in problem p: the gradient of
+ * model.py:134-157 (mean cross entropy of per-problem mean votes) w.r.t. every edge vote. */
+int tspgnn_vote_grad_f32(const float* logits, const float* labels, const int32_t* seg, float* dvote,
+                         int B, void* stream);
+
+/* dX[r,:] = dy[r] * w: backward of tspgnn_rowdot_f32 through X. */
+int tspgnn_rowdot_bwd_f32(const float* dy, const float* w, float* dX, int rows, int d, void* stream);
+
+long long tspgnn_wcolsum_workspace_floats(long long rows, int d);
+
+/*
+ * out[f] += scale * sum_r wt[r] * X[r,f]  (wt == NULL: plain column sums) and, if out_wsum != NULL,
+ * out_wsum[0] += scale * sum_r wt[r].  Used for the gradients of the vote head's Dense(1) kernel /
+ * bias and of V_init (model.py:47-51).  Deterministic two-stage reduction.
+ */
+int tspgnn_wcolsum_f32(const float* X, const float* wt, long long rows, int d, float scale, float* out,
+                       float* out_wsum, float* workspace, void* stream);
+
+long long tspgnn_einit_bwd_workspace_floats(int M, int d);
+
+/* dwb += gradient of the E_init_MLP parameters (layout of tspgnn_einit_fwd_f32's wb) given
+ * dE0:[M,d]; recomputes the forward chain per edge. */
+int tspgnn_einit_bwd_f32(const float* WC, const float* wb, const float* dE0, float* dwb, float* workspace,
+                         int M, int d, void* stream);
+
+long long tspgnn_adam_workspace_floats(void);
+
+/*
+ * One optimiser step on the flat parameter buffer (model.py:160-167): g += l2_scale*theta (gradient
+ * of l2_scale * sum l2_loss(var)); global_norm = ||g||; g *= clip/max(global_norm, clip)
+ * (clip_norm <= 0: no clipping); Adam with the bias-corrected step lr_t.  gnorm_out[0] = global_norm.
+ * In data-parallel training g is the all-reduced (averaged) gradient.
+ */
+int tspgnn_adam_clip_step_f32(float* theta, float* g, float* m, float* v, int n, float l2_scale,
+                              float clip_norm, float lr_t, float beta1, float beta2, float eps,
+                              float* gnorm_out, float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(tspgnn_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(?:int|long long|const char\*)\s+(tspgnn_\w+)\s*\(([^)]*)\)\s*;", src):
         args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
         out[m.group(1)] = args
     return out
@@ -28,9 +28,10 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, name), "libtspgnn.so lacks %s" % name
         if name in ("tspgnn_version", "tspgnn_last_error"):
             continue
-        assert name in _lib.SIGNATURES, "no ctypes signature for %s" % name
-        assert len(_lib.SIGNATURES[name]) == len(args), name
-    for name in _lib.SIGNATURES:
+        table = _lib.SIZE_QUERIES if name in _lib.SIZE_QUERIES else _lib.SIGNATURES
+        assert name in table, "no ctypes signature for %s" % name
+        assert len(table[name]) == len(args), name
+    for name in list(_lib.SIGNATURES) + list(_lib.SIZE_QUERIES):
         assert name in decl, "%s bound but not declared in tspgnn.h" % name
 
 
@@ -40,7 +41,7 @@ def test_version_and_error_string():
     assert status == -1
     assert b"multiple of 4" in _lib.lib.tspgnn_last_error()
     try:
-        _lib.call("tspgnn_mlp_fwd_f32", None, None, None, None, 8, 48, 4, 7, None)
+        _lib.call("tspgnn_mlp_fwd_f32", None, None, None, None, 0, 8, 48, 4, 7, None)
         assert False
     except _lib.TspgnnError as e:
         assert e.status == -1 and "d=48" in str(e)

@@ -1,0 +1,252 @@
+"""Backward HIP kernels vs torch-autograd (float64, CPU) on the oracle's restatement of each op."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import torch_oracle as TO
+from tspgnn import _lib
+
+pytestmark = pytest.mark.gpu
+
+_KEEP = []
+TOL = 5e-6
+
+
+def dev(a, device, dtype=np.float32):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(device)
+    _KEEP.append(t)
+    return t
+
+
+def empty(shape, device, fill=None):
+    t = torch.empty(shape, dtype=torch.float32, device=device) if fill is None else \
+        torch.full(shape, fill, dtype=torch.float32, device=device)
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _release():
+    yield
+    torch.cuda.synchronize()
+    del _KEEP[:]
+
+
+def packed(W, device, transposed=0):
+    """pack(W) or, with transposed=1, pack(W^T) from the [out,in]... i.e. W given as stored."""
+    src = dev(W, device)
+    out = empty(src.shape, device)
+    kr, nc = (W.shape[1], W.shape[0]) if transposed else W.shape
+    _lib.call("tspgnn_pack_weights_f32", _lib.ptr(src), _lib.ptr(out), kr, nc, transposed, None)
+    return out
+
+
+def ws(name, *args, device):
+    n = getattr(_lib.lib, name)(*args)
+    return empty((max(int(n), 1),), device)
+
+
+@pytest.mark.parametrize("kin,n1,n2,rows,acc", [(256, 64, 64, 1000, 0), (128, 32, 32, 77, 1), (512, 128, 128, 300, 1),
+                                                (64, 0, 64, 50, 0), (256, 48, 16, 33, 0)])
+def test_linear(cuda_device, kin, n1, n2, rows, acc):
+    rng = np.random.RandomState(kin + rows)
+    X = rng.randn(rows, kin).astype(np.float32)
+    W = (rng.randn(kin, n1 + n2) / np.sqrt(kin)).astype(np.float32)
+    Y2_0 = rng.randn(rows, n2).astype(np.float32)
+    Y1 = empty((rows, max(n1, 1)), cuda_device)
+    Y2 = dev(Y2_0, cuda_device)
+    _lib.call("tspgnn_linear_f32", _lib.ptr(dev(X, cuda_device)), kin, _lib.ptr(packed(W, cuda_device)),
+              _lib.ptr(Y1) if n1 else None, n1, _lib.ptr(Y2), n2, acc, rows, None)
+    torch.cuda.synchronize()
+    ref = X.astype(np.float64) @ W.astype(np.float64)
+    if n1:
+        assert rel_err(Y1.cpu().numpy()[:, :n1], ref[:, :n1]) < TOL
+    assert rel_err(Y2.cpu().numpy(), ref[:, n1:] + (Y2_0 if acc else 0)) < TOL
+
+
+def test_pack_transposed(cuda_device):
+    W = np.random.RandomState(0).randn(128, 256).astype(np.float32)        # stored [ncols=128? no: stored as W]
+    a = packed(np.ascontiguousarray(W.T), cuda_device).cpu().numpy()         # pack(W^T) from an explicit transpose
+    b = packed(W, cuda_device, transposed=1).cpu().numpy()                   # pack(W^T) straight from W
+    assert np.array_equal(a.reshape(-1), b.reshape(-1))
+
+
+@pytest.mark.parametrize("d,dx,rows,null_grads", [(64, 64, 333, False), (32, 32, 50, False), (64, 64, 16, True),
+                                                   (128, 128, 120, False), (32, 96, 100, False)])
+def test_lnlstm_backward_chain(cuda_device, d, dx, rows, null_grads):
+    rng = np.random.RandomState(d + rows)
+    x = rng.randn(rows, dx); h = rng.randn(rows, d); c = rng.randn(rows, d)
+    K = rng.randn(dx + d, 4 * d) / np.sqrt(dx + d)
+    ln = np.stack([np.stack([1 + 0.2 * rng.randn(d), 0.2 * rng.randn(d)]) for _ in range(5)])
+    dh_o = rng.randn(rows, d); dc_o = rng.randn(rows, d)
+    f32 = lambda a: a.astype(np.float32)
+    x, h, c, K, ln, dh_o, dc_o = map(f32, (x, h, c, K, ln, dh_o, dc_o))
+    # --- oracle: autograd through torch_oracle.lnlstm_cell
+    tx, th, tc, tK = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, h, c, K))
+    tln = torch.tensor(ln, dtype=torch.float64, requires_grad=True)
+    names = ("input", "transform", "forget", "output", "state")
+    params = {"TSP/Q_cell/layer_norm_basic_lstm_cell/kernel": tK}
+    for i, g in enumerate(names):
+        params["TSP/Q_cell/layer_norm_basic_lstm_cell/%s/gamma" % g] = tln[i, 0]
+        params["TSP/Q_cell/layer_norm_basic_lstm_cell/%s/beta" % g] = tln[i, 1]
+    nh, nc = TO.lnlstm_cell(tx, th, tc, params, "Q")
+    if null_grads:
+        loss = (nh * torch.tensor(dh_o, dtype=torch.float64)).sum()
+    else:
+        loss = (nh * torch.tensor(dh_o, dtype=torch.float64)).sum() + (nc * torch.tensor(dc_o, dtype=torch.float64)).sum()
+    gx, gh, gc, gK, gln = torch.autograd.grad(loss, [tx, th, tc, tK, tln])
+    # --- HIP: lnlstm_bwd -> dz, dc; linear(dz, K^T) -> dx, dh; wgrad([x|h], dz) -> dK
+    dz = empty((rows, 4 * d), cuda_device); dc_in = empty((rows, d), cuda_device)
+    ln_grad = empty((10 * d,), cuda_device, 0.0)
+    wsl = ws("tspgnn_lnlstm_bwd_workspace_floats", d, device=cuda_device)
+    xd, hd, cd = dev(x, cuda_device), dev(h, cuda_device), dev(c, cuda_device)
+    _lib.call("tspgnn_lnlstm_bwd_f32", _lib.ptr(xd), dx, _lib.ptr(hd), _lib.ptr(cd), _lib.ptr(packed(K, cuda_device)),
+              _lib.ptr(dev(ln, cuda_device)), _lib.ptr(dev(dh_o, cuda_device)),
+              None if null_grads else _lib.ptr(dev(dc_o, cuda_device)), _lib.ptr(dz), _lib.ptr(dc_in), _lib.ptr(ln_grad),
+              _lib.ptr(wsl), rows, d, None)
+    dxo = empty((rows, dx), cuda_device); dho = empty((rows, d), cuda_device)
+    _lib.call("tspgnn_linear_f32", _lib.ptr(dz), 4 * d, _lib.ptr(packed(K, cuda_device, transposed=1)), _lib.ptr(dxo), dx,
+              _lib.ptr(dho), d, 0, rows, None)
+    dK = empty((dx + d, 4 * d), cuda_device, 0.0)
+    w1 = ws("tspgnn_wgrad_workspace_floats", rows, dx, 4 * d, device=cuda_device)
+    w2 = ws("tspgnn_wgrad_workspace_floats", rows, d, 4 * d, device=cuda_device)
+    _lib.call("tspgnn_wgrad_f32", _lib.ptr(xd), _lib.ptr(dz), rows, dx, 4 * d, _lib.ptr(dK[:dx]), None, _lib.ptr(w1), None)
+    _lib.call("tspgnn_wgrad_f32", _lib.ptr(hd), _lib.ptr(dz), rows, d, 4 * d, _lib.ptr(dK[dx:]), None, _lib.ptr(w2), None)
+    torch.cuda.synchronize()
+    assert rel_err(dc_in.cpu().numpy(), gc.numpy()) < TOL
+    assert rel_err(dxo.cpu().numpy(), gx.numpy()) < TOL
+    assert rel_err(dho.cpu().numpy(), gh.numpy()) < TOL
+    assert rel_err(dK.cpu().numpy(), gK.numpy()) < TOL
+    assert rel_err(ln_grad.cpu().numpy().reshape(5, 2, d), gln.numpy()) < TOL
+
+
+@pytest.mark.parametrize("d,L,mask,rows", [(64, 4, 0b0111, 500), (64, 3, 0b111, 333), (32, 4, 0b0111, 40), (32, 2, 0b01, 17),
+                                           (128, 2, 0b11, 100), (64, 1, 0, 64)])
+def test_mlp_backward_and_wgrad(cuda_device, d, L, mask, rows):
+    rng = np.random.RandomState(d * L + rows)
+    X = rng.randn(rows, d).astype(np.float32)
+    Ws = [(rng.randn(d, d) / np.sqrt(d)).astype(np.float32) for _ in range(L)]
+    bs = [(0.1 * rng.randn(d)).astype(np.float32) for _ in range(L)]
+    dY = rng.randn(rows, d).astype(np.float32)
+    dX0 = rng.randn(rows, d).astype(np.float32)
+    # oracle
+    tX = torch.tensor(X, dtype=torch.float64, requires_grad=True)
+    tW = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in Ws]
+    tb = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
+    a = tX
+    for l in range(L):
+        a = a @ tW[l] + tb[l]
+        if (mask >> l) & 1:
+            a = torch.relu(a)
+    grads = torch.autograd.grad((a * torch.tensor(dY, dtype=torch.float64)).sum(), [tX] + tW + tb)
+    gX, gW, gb = grads[0], grads[1:1 + L], grads[1 + L:]
+    # HIP forward (saves activations) then backward
+    wb = torch.cat([torch.cat([packed(w, cuda_device).view(-1), dev(b, cuda_device)]) for w, b in zip(Ws, bs)])
+    wt = torch.cat([packed(w, cuda_device, transposed=1).view(-1) for w in Ws])
+    _KEEP.extend([wb, wt])
+    Xd = dev(X, cuda_device)
+    Y = empty((rows, d), cuda_device); acts = empty((max(L - 1, 1), rows, d), cuda_device)
+    _lib.call("tspgnn_mlp_fwd_f32", _lib.ptr(Xd), _lib.ptr(wb), _lib.ptr(Y), _lib.ptr(acts), 0, rows, d, L, mask, None)
+    dpre = empty((L, rows, d), cuda_device); dX = dev(dX0, cuda_device)
+    _lib.call("tspgnn_mlp_bwd_f32", _lib.ptr(dev(dY, cuda_device)), _lib.ptr(wt), _lib.ptr(acts), 0, _lib.ptr(Y), _lib.ptr(dpre), 0,
+              _lib.ptr(dX), 1, rows, d, L, mask, None)
+    torch.cuda.synchronize()
+    assert rel_err(dX.cpu().numpy(), gX.numpy() + dX0) < TOL
+    wsz = ws("tspgnn_wgrad_workspace_floats", rows, d, d, device=cuda_device)
+    for l in range(L):
+        inp = Xd if l == 0 else acts[l - 1]
+        dW = empty((d, d), cuda_device, 0.0); db = empty((d,), cuda_device, 0.0)
+        _lib.call("tspgnn_wgrad_f32", _lib.ptr(inp), _lib.ptr(dpre[l]), rows, d, d, _lib.ptr(dW), _lib.ptr(db), _lib.ptr(wsz), None)
+        torch.cuda.synchronize()
+        assert rel_err(dW.cpu().numpy(), gW[l].numpy()) < TOL, l
+        assert rel_err(db.cpu().numpy(), gb[l].numpy()) < TOL, l
+
+
+def test_wgrad_accumulates_and_large_rows(cuda_device):
+    rng = np.random.RandomState(5)
+    rows, kin, nout = 70001, 64, 256
+    X = rng.randn(rows, kin).astype(np.float32); dY = rng.randn(rows, nout).astype(np.float32)
+    dW0 = rng.randn(kin, nout).astype(np.float32)
+    dW = dev(dW0, cuda_device)
+    w = ws("tspgnn_wgrad_workspace_floats", rows, kin, nout, device=cuda_device)
+    _lib.call("tspgnn_wgrad_f32", _lib.ptr(dev(X, cuda_device)), _lib.ptr(dev(dY, cuda_device)), rows, kin, nout, _lib.ptr(dW), None,
+              _lib.ptr(w), None)
+    torch.cuda.synchronize()
+    ref = X.astype(np.float64).T @ dY.astype(np.float64) + dW0
+    assert rel_err(dW.cpu().numpy(), ref) < TOL
+
+
+def test_vote_head_backward_pieces(cuda_device):
+    rng = np.random.RandomState(9)
+    n_edges = np.array([3, 780, 21, 190]); B = len(n_edges)
+    seg = np.concatenate([[0], np.cumsum(n_edges)]).astype(np.int32); M = int(seg[-1]); d = 64
+    logits = rng.randn(B).astype(np.float32); labels = np.array([0, 1, 1, 0], dtype=np.float32)
+    dvote = empty((M,), cuda_device)
+    _lib.call("tspgnn_vote_grad_f32", _lib.ptr(dev(logits, cuda_device)), _lib.ptr(dev(labels, cuda_device)),
+              _lib.ptr(dev(seg, cuda_device, np.int32)), _lib.ptr(dvote), B, None)
+    torch.cuda.synchronize()
+    sig = 1 / (1 + np.exp(-logits.astype(np.float64)))
+    ref = np.concatenate([np.full(n, (sig[p] - labels[p]) / (B * n)) for p, n in enumerate(n_edges)])
+    assert rel_err(dvote.cpu().numpy(), ref) < 1e-6
+    X = rng.randn(M, d).astype(np.float32); w = rng.randn(d).astype(np.float32)
+    dX = empty((M, d), cuda_device)
+    _lib.call("tspgnn_rowdot_bwd_f32", _lib.ptr(dvote), _lib.ptr(dev(w, cuda_device)), _lib.ptr(dX), M, d, None)
+    dw = empty((d,), cuda_device, 0.0); dbias = empty((1,), cuda_device, 0.0)
+    wsz = ws("tspgnn_wcolsum_workspace_floats", M, d, device=cuda_device)
+    _lib.call("tspgnn_wcolsum_f32", _lib.ptr(dev(X, cuda_device)), _lib.ptr(dvote), M, d, 1.0, _lib.ptr(dw), _lib.ptr(dbias),
+              _lib.ptr(wsz), None)
+    col = empty((d,), cuda_device, 1.0)
+    _lib.call("tspgnn_wcolsum_f32", _lib.ptr(dev(X, cuda_device)), None, M, d, 0.125, _lib.ptr(col), None, _lib.ptr(wsz), None)
+    torch.cuda.synchronize()
+    assert rel_err(dX.cpu().numpy(), ref[:, None] * w[None].astype(np.float64)) < 1e-6
+    assert rel_err(dw.cpu().numpy(), (ref[:, None] * X).sum(0)) < TOL
+    assert abs(dbias.item() - ref.sum()) < 1e-6
+    assert rel_err(col.cpu().numpy(), 1.0 + 0.125 * X.astype(np.float64).sum(0)) < TOL
+
+
+@pytest.mark.parametrize("d", [32, 64, 128])
+def test_einit_backward(cuda_device, d):
+    rng = np.random.RandomState(d)
+    M = 333
+    WC = rng.rand(M, 2).astype(np.float32)
+    dims = [2, d // 8, d // 4, d // 2, d]
+    Ws = [rng.randn(a, b).astype(np.float32) for a, b in zip(dims[:-1], dims[1:])]
+    bs = [(0.3 * rng.randn(b)).astype(np.float32) for b in dims[1:]]
+    dE0 = rng.randn(M, d).astype(np.float32)
+    tW = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in Ws]
+    tb = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
+    a = torch.tensor(WC, dtype=torch.float64)
+    for l in range(4):
+        a = a @ tW[l] + tb[l]
+        if l < 3:
+            a = torch.relu(a)
+    grads = torch.autograd.grad((a * torch.tensor(dE0, dtype=torch.float64)).sum(), [v for pair in zip(tW, tb) for v in pair])
+    ref = np.concatenate([g.numpy().reshape(-1) for g in grads])
+    wb = np.concatenate([v.reshape(-1) for pair in zip(Ws, bs) for v in pair])
+    dwb = empty((wb.size,), cuda_device, 0.0)
+    wsz = ws("tspgnn_einit_bwd_workspace_floats", M, d, device=cuda_device)
+    _lib.call("tspgnn_einit_bwd_f32", _lib.ptr(dev(WC, cuda_device)), _lib.ptr(dev(wb, cuda_device)), _lib.ptr(dev(dE0, cuda_device)),
+              _lib.ptr(dwb), _lib.ptr(wsz), M, d, None)
+    torch.cuda.synchronize()
+    assert rel_err(dwb.cpu().numpy(), ref) < TOL
+
+
+def test_adam_clip_step(cuda_device):
+    rng = np.random.RandomState(1)
+    n = 115529
+    theta = rng.randn(n).astype(np.float32); g = (0.01 * rng.randn(n)).astype(np.float32)
+    m = (0.001 * rng.randn(n)).astype(np.float32); v = (1e-4 * rng.rand(n)).astype(np.float32)
+    step = 7
+    lr_t = TO.LEARNING_RATE * np.sqrt(1 - TO.ADAM_B2 ** step) / (1 - TO.ADAM_B1 ** step)
+    td, gd, md, vd = (dev(a, cuda_device) for a in (theta, g, m, v))
+    gn = empty((1,), cuda_device); wsz = ws("tspgnn_adam_workspace_floats", device=cuda_device)
+    _lib.call("tspgnn_adam_clip_step_f32", _lib.ptr(td), _lib.ptr(gd), _lib.ptr(md), _lib.ptr(vd), n, TO.L2NORM_SCALING, TO.CLIP_NORM,
+              float(lr_t), TO.ADAM_B1, TO.ADAM_B2, TO.ADAM_EPS, _lib.ptr(gn), _lib.ptr(wsz), None)
+    torch.cuda.synchronize()
+    g64 = g.astype(np.float64) + TO.L2NORM_SCALING * theta
+    clipped, gnorm = TO.clip_by_global_norm({"a": g64})
+    p, m2, v2 = TO.adam_step({"a": theta.astype(np.float64)}, clipped, {"a": m.astype(np.float64)}, {"a": v.astype(np.float64)}, step)
+    assert abs(gn.item() - gnorm) < 1e-5 * gnorm and gnorm > TO.CLIP_NORM     # the clip is active in this case
+    assert rel_err(md.cpu().numpy(), m2["a"]) < 1e-6 and rel_err(vd.cpu().numpy(), v2["a"]) < 1e-6
+    assert np.abs(td.cpu().numpy() - p["a"]).max() < 1e-6 * np.abs(p["a"]).max()

@@ -36,7 +36,7 @@ def packed(W, device):
     src = dev(W, device)
     out = torch.empty_like(src)
     _KEEP.append(out)
-    _lib.call("tspgnn_pack_weights_f32", _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], None)
+    _lib.call("tspgnn_pack_weights_f32", _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], 0, None)
     return out
 
 
@@ -138,7 +138,7 @@ def test_mlp_fwd(cuda_device, d, n_layers, mask, rows):
     Y = torch.empty((rows, d), dtype=torch.float32, device=cuda_device)
     acts = torch.empty((max(n_layers - 1, 1), rows, d), dtype=torch.float32, device=cuda_device)
     _lib.call("tspgnn_mlp_fwd_f32", _lib.ptr(dev(X, cuda_device)), _lib.ptr(dev(np.concatenate(flat), cuda_device)),
-              _lib.ptr(Y), _lib.ptr(acts), rows, d, n_layers, mask, None)
+              _lib.ptr(Y), _lib.ptr(acts), 0, rows, d, n_layers, mask, None)
     torch.cuda.synchronize()
     x = X.astype(np.float64)
     for l, ((W, b), a) in enumerate(zip(layers, acts_flags)):

@@ -34,7 +34,7 @@ def timeit(fn, iters=200, warm=20):
 
 def pack(W):
     out = torch.empty_like(W)
-    _lib.call("tspgnn_pack_weights_f32", _lib.ptr(W), _lib.ptr(out), W.shape[0], W.shape[1], None)
+    _lib.call("tspgnn_pack_weights_f32", _lib.ptr(W), _lib.ptr(out), W.shape[0], W.shape[1], 0, None)
     return out
 
 
@@ -47,7 +47,7 @@ for rows, tag in ((M, "E"), (N, "V")):
     wb = torch.cat([torch.cat([pack(torch.randn(d, d, device=dev) / 8).view(-1), torch.randn(d, device=dev)]) for _ in range(4)])
     K = pack(torch.randn(2 * d, 4 * d, device=dev) / 11)
     ln = torch.cat([torch.ones(d, device=dev), torch.zeros(d, device=dev)] * 5)
-    t = timeit(lambda: _lib.call("tspgnn_mlp_fwd_f32", _lib.ptr(X), _lib.ptr(wb), _lib.ptr(Y), None, rows, d, 4, 7, None))
+    t = timeit(lambda: _lib.call("tspgnn_mlp_fwd_f32", _lib.ptr(X), _lib.ptr(wb), _lib.ptr(Y), None, 0, rows, d, 4, 7, None))
     fl = rows * 4 * 2 * d * d
     res["mlp4_" + tag] = (t, fl / t / 1e6)
     t = timeit(lambda: _lib.call("tspgnn_lnlstm_fwd_f32", _lib.ptr(X), d, _lib.ptr(H), _lib.ptr(C), _lib.ptr(K), _lib.ptr(ln),

@@ -23,6 +23,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// Compute units of the current device (256 on MI355X); sizes the persistent grids.
+inline int n_cus(void) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return cus;
+}
+
 // 1/(1+e^-x) on the hardware transcendental units: v_exp_f32 (via exp2(x*log2 e)) and v_rcp_f32,
 // each ~1 ulp -> ~2e-7 relative error, two orders inside the 1e-5 parity budget, at a fraction of
 // the ~60 VALU instructions of the IEEE expf + division sequence.

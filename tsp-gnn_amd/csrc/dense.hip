@@ -15,13 +15,9 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "mfma_tile.h"
 
 namespace tspgnn {
-
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // MFMA A-fragment order of a [krows, ncols] row-major weight matrix W (the "packed" layout the
 // kernels keep in LDS; produced once per weight update by tspgnn_pack_weights_f32):
@@ -30,8 +26,9 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 //   krow(s,g) = (s>>2)*16 + g*4 + (s&3)      (k-step s of 4 rows, lane group g)
 // One ds_read_b128 at P + ((s*4+g)*U+u)*64 + jl*4 then feeds four MFMAs (tiles 4u..4u+3) and is
 // bank-conflict free (16 lanes x 16 B = one 256 B bank row per lane group).
+// transposed != 0: W is stored [ncols, krows] row-major and P packs its transpose.
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ W, float* __restrict__ P,
-                                                           int krows, int ncols) {
+                                                           int krows, int ncols, int transposed) {
     const int total = krows * ncols;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         int tt, jl, u, sg;
@@ -49,86 +46,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         }
         const int g = sg & 3, s = sg >> 2;
         const int krow = ((s >> 2) << 4) + (g << 2) + (s & 3);
-        P[i] = W[(size_t)krow * ncols + (u * 4 + tt) * 16 + jl];
-    }
-}
-
-// Straight float4 copy global -> LDS with 8 loads in flight per thread (the weights are already in
-// fragment order, so staging is a pure, fully coalesced stream).
-__device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int nfloats, int tid,
-                                            int nthreads) {
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-    const int n4 = nfloats >> 2;
-    for (int base = tid; base < n4; base += nthreads * 8) {
-        f32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * nthreads;
-            if (idx < n4) v[u] = s4[idx];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * nthreads;
-            if (idx < n4) d4[idx] = v[u];
-        }
-    }
-}
-
-// acc[t] (t in [0,NT)) += W_frag(step s, tile t) * bval for all output tiles of one k-step.
-// wrow points at the LDS fragment row of (s, g) for this lane (already offset by jl).
-template <int NT>
-__device__ __forceinline__ void kstep(f32x4 (&acc)[NT], const float* wrow, float bval) {
-    if constexpr (NT == 2) {
-        const float2 aw = *reinterpret_cast<const float2*>(wrow);
-        acc[0] = MFMA16(aw.x, bval, acc[0]);
-        acc[1] = MFMA16(aw.y, bval, acc[1]);
-    } else {
-#pragma unroll
-        for (int u = 0; u < NT / 4; ++u) {
-            const f32x4 aw = ld4(wrow + u * 64);
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) acc[u * 4 + tt] = MFMA16(aw[tt], bval, acc[u * 4 + tt]);
-        }
-    }
-}
-
-// LDS float offset of the fragment row (s,g) for lane jl, for a matrix with NT output tiles.
-template <int NT>
-__device__ __forceinline__ int frag_off(int s, int g, int jl) {
-    if constexpr (NT == 2)
-        return ((s * 4 + g) * 16 + jl) * 2;
-    else
-        return (s * 4 + g) * (NT / 4) * 64 + jl * 4;
-}
-
-// NSTEPS consecutive k-steps (fragment rows s0 .. s0+NSTEPS-1, contiguous in LDS) with the weight
-// fragments double-buffered in registers: the ds_reads of step s+1 are issued before the MFMAs
-// of step s.  b[s] is the B-operand value of step s.
-template <int NT, int NSTEPS>
-__device__ __forceinline__ void ksteps(f32x4 (&acc)[NT], const float* w0, const float (&b)[NSTEPS]) {
-    static_assert(NT % 4 == 0, "b128 fragment path");
-    constexpr int U = NT / 4;
-    constexpr int STRIDE = NT * 64;  // floats between the fragment rows of consecutive k-steps
-    f32x4 w[2][U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) w[0][u] = ld4(w0 + u * 64);
-#pragma unroll
-    for (int s = 0; s < NSTEPS; ++s) {
-        if (s + 1 < NSTEPS) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) w[(s + 1) & 1][u] = ld4(w0 + (s + 1) * STRIDE + u * 64);
-        }
-        // Pin the order: the ds_reads of step s+1 stay ABOVE the MFMAs of step s (their s_waitcnt
-        // lands at their first use, one step later), so one wavefront alone keeps the matrix pipe
-        // busy instead of alternating "read, wait, 4 MFMA".
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) acc[u * 4 + tt] = MFMA16(w[s & 1][u][tt], b[s], acc[u * 4 + tt]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        const int col = (u * 4 + tt) * 16 + jl;
+        P[i] = transposed ? W[(size_t)col * krows + krow] : W[(size_t)krow * ncols + col];
     }
 }
 
@@ -138,8 +57,9 @@ __device__ __forceinline__ void ksteps(f32x4 (&acc)[NT], const float* w0, const 
 // an LDS ticket counter (keeps the four SIMDs of a CU evenly loaded at the tail).
 template <int D, int MAXL>
 __global__ __launch_bounds__(512) void mlp_fwd_kernel(const float* __restrict__ X, const float* __restrict__ wb,
-                                                      float* __restrict__ Y, float* __restrict__ acts, int rows,
-                                                      int n_layers, unsigned relu_mask, int tiles_total) {
+                                                      float* __restrict__ Y, float* __restrict__ acts,
+                                                      long long acts_stride, int rows, int n_layers,
+                                                      unsigned relu_mask, int tiles_total) {
     constexpr int NT = D / 16;
     __shared__ __attribute__((aligned(16))) float lds[MAXL * (D * D + D) + 4];
     float* lds_w = lds;
@@ -196,7 +116,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(const float* __restrict__ 
                 a[t] = acc[t];
             }
             if (acts != nullptr && l < n_layers - 1 && valid) {
-                float* dst = acts + (size_t)l * rows * D + rbase;
+                float* dst = acts + (size_t)l * acts_stride + rbase;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) st4(dst + t * 16, a[t]);
             }
@@ -209,82 +129,6 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------- LN-LSTM
-// Sum of the lane's D/4 values of one gate, reduced over the 4 lane groups that share a row.
-template <int TPG>
-__device__ __forceinline__ void ln_gate(f32x4 (&v)[TPG], const float* gamma, const float* beta, int g, int D) {
-    float s = 0.f;
-#pragma unroll
-    for (int t = 0; t < TPG; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
-    s = sum_over_lane_groups16(s);
-    const float mean = s / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int t = 0; t < TPG; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float dlt = v[t][r] - mean;
-            q = fmaf(dlt, dlt, q);
-        }
-    }
-    q = sum_over_lane_groups16(q);
-    const float var = q / (float)D;
-    // tf.contrib.layers.layer_norm: variance_epsilon = 1e-12; x*inv + (beta - mean*inv)
-    const float rstd = __builtin_amdgcn_rsqf(var + 1e-12f);  // v_rsq_f32, ~1 ulp
-#pragma unroll
-    for (int t = 0; t < TPG; ++t) {
-        const f32x4 ga = ld4(gamma + t * 16 + g * 4);
-        const f32x4 be = ld4(beta + t * 16 + g * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float inv = rstd * ga[r];
-            v[t][r] = fmaf(v[t][r], inv, be[r] - mean * inv);
-        }
-    }
-}
-
-// k-loop of one 16-row tile over the 16-row blocks q in [q_beg, q_end) of the concatenated [x|h]
-// operand; lds_k holds the fragment rows of k-steps starting at block q_base.  The B-operand
-// fragments are fetched four blocks (256 MFMAs, ~3.4 us of matrix work) ahead of their use so
-// that the global-load latency is hidden behind the MFMA stream of the same wavefront.
-template <int D>
-__device__ __forceinline__ void lstm_kloop(f32x4 (&acc)[D / 4], const float* lds_k, int q_base, int q_beg, int q_end,
-                                           const float* xrow, const float* hrow, int QX, int g, int rl) {
-    constexpr int NT4 = D / 4;
-    constexpr int GQ = 4;
-    if (q_beg >= q_end) return;
-    auto frag = [&](int q) -> f32x4 {
-        const int qq = q < q_end ? q : q_end - 1;  // clamp: tail loads stay in bounds
-        return ld4(qq < QX ? xrow + qq * 16 : hrow + (qq - QX) * 16);
-    };
-    f32x4 cur[GQ], nxt[GQ];
-#pragma unroll
-    for (int i = 0; i < GQ; ++i) cur[i] = frag(q_beg + i);
-    for (int q0 = q_beg; q0 < q_end; q0 += GQ) {
-        if (q0 + GQ < q_end) {
-#pragma unroll
-            for (int i = 0; i < GQ; ++i) nxt[i] = frag(q0 + GQ + i);
-        }
-        if (q0 + GQ <= q_end) {
-            float b[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) b[i] = cur[i >> 2][i & 3];
-            ksteps<NT4, 16>(acc, lds_k + frag_off<NT4>((q0 - q_base) * 4, g, rl), b);
-        } else {
-#pragma unroll
-            for (int i = 0; i < GQ; ++i) {
-                if (q0 + i < q_end) {
-                    float b[4];
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) b[p] = cur[i][p];
-                    ksteps<NT4, 4>(acc, lds_k + frag_off<NT4>((q0 + i - q_base) * 4, g, rl), b);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < GQ; ++i) cur[i] = nxt[i];
-    }
-}
-
 // split(z) = i, j, f, o (that order); LN each; c' = LN(c*sig(f+1) + sig(i)*relu(j)); h' = relu(c')*sig(o)
 template <int D>
 __device__ __forceinline__ void lstm_epilogue(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 16], const float* lds_ln, int g,
@@ -424,18 +268,9 @@ __global__ __launch_bounds__(512) void lnlstm_fwd_chunked_kernel(const float* __
     }
 }
 
-static int n_cus(void) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-    return cus;
-}
-
 template <int D, int MAXL>
-static int launch_mlp(const float* X, const float* wb, float* Y, float* acts, int rows, int n_layers,
-                      unsigned relu_mask, hipStream_t st) {
+static int launch_mlp(const float* X, const float* wb, float* Y, float* acts, long long acts_stride, int rows,
+                      int n_layers, unsigned relu_mask, hipStream_t st) {
     const int tiles = (rows + 15) / 16;
     // LDS per block decides residency: D=64 -> 65 KiB -> 2 blocks (16 waves) per CU.
     const int lds_bytes = MAXL * (D * D + D) * 4 + 16;
@@ -444,7 +279,7 @@ static int launch_mlp(const float* X, const float* wb, float* Y, float* acts, in
     const int nw = tiles <= grid * 4 ? 4 : 8;  // few tiles: one wavefront per SIMD, more workgroups
     const int max_grid = (tiles + nw - 1) / nw;  // at least one tile per wave
     if (grid > max_grid) grid = max_grid;
-    mlp_fwd_kernel<D, MAXL><<<grid, nw * 64, 0, st>>>(X, wb, Y, acts, rows, n_layers, relu_mask, tiles);
+    mlp_fwd_kernel<D, MAXL><<<grid, nw * 64, 0, st>>>(X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask, tiles);
     return launched("tspgnn_mlp_fwd_f32");
 }
 
@@ -494,7 +329,7 @@ static int launch_lnlstm(const float* x, int dx, const float* h, const float* c,
 
 using namespace tspgnn;
 
-extern "C" int tspgnn_pack_weights_f32(const float* W, float* P, int krows, int ncols, void* stream) {
+extern "C" int tspgnn_pack_weights_f32(const float* W, float* P, int krows, int ncols, int transposed, void* stream) {
     TSPGNN_REQUIRE(krows >= 0 && krows % 16 == 0, "pack_weights: krows=%d must be a multiple of 16", krows);
     TSPGNN_REQUIRE(ncols == 32 || (ncols > 0 && ncols % 64 == 0), "pack_weights: ncols=%d must be 32 or a multiple of 64",
                    ncols);
@@ -503,25 +338,26 @@ extern "C" int tspgnn_pack_weights_f32(const float* W, float* P, int krows, int 
     const int total = krows * ncols;
     int grid = (total + 255) / 256;
     if (grid > 1024) grid = 1024;
-    pack_weights_kernel<<<grid, 256, 0, as_stream(stream)>>>(W, P, krows, ncols);
+    pack_weights_kernel<<<grid, 256, 0, as_stream(stream)>>>(W, P, krows, ncols, transposed);
     return launched("tspgnn_pack_weights_f32");
 }
 
-extern "C" int tspgnn_mlp_fwd_f32(const float* X, const float* wb, float* Y, float* acts, int rows, int d,
-                                  int n_layers, unsigned relu_mask, void* stream) {
+extern "C" int tspgnn_mlp_fwd_f32(const float* X, const float* wb, float* Y, float* acts, long long acts_stride,
+                                  int rows, int d, int n_layers, unsigned relu_mask, void* stream) {
     TSPGNN_REQUIRE(rows >= 0, "mlp_fwd: rows=%d", rows);
     TSPGNN_REQUIRE(n_layers >= 1 && n_layers <= 4, "mlp_fwd: n_layers=%d must be in 1..4", n_layers);
     TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "mlp_fwd: d=%d must be 32, 64 or 128", d);
     if (rows == 0) return TSPGNN_OK;
     TSPGNN_REQUIRE(X && wb && Y, "mlp_fwd: null pointer");
+    if (acts && acts_stride == 0) acts_stride = (long long)rows * d;
     hipStream_t st = as_stream(stream);
     switch (d) {
-        case 32: return launch_mlp<32, 4>(X, wb, Y, acts, rows, n_layers, relu_mask, st);
-        case 64: return launch_mlp<64, 4>(X, wb, Y, acts, rows, n_layers, relu_mask, st);
+        case 32: return launch_mlp<32, 4>(X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask, st);
+        case 64: return launch_mlp<64, 4>(X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask, st);
         default:
             if (n_layers > 2)
                 return fail(TSPGNN_EUNSUPPORTED, "mlp_fwd: d=128 holds at most 2 layers in LDS (got %d)", n_layers);
-            return launch_mlp<128, 2>(X, wb, Y, acts, rows, n_layers, relu_mask, st);
+            return launch_mlp<128, 2>(X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask, st);
     }
 }
 

@@ -1,0 +1,725 @@
+// Backward of the dense per-row updates (tf.gradients through graphnn.py:142-173, model.py:166) on the
+// gfx950 matrix cores, exact fp32, same "transposed chaining" layout as dense.hip:
+//   * linear      : Y = X W with W resident in LDS (used for dz K^T -> (dx, dh) of the LSTM cell)
+//   * lnlstm_bwd  : recomputes z = [x,h]K, then LayerNorm / gate backward -> dz, dc, LN-parameter grads
+//   * mlp_bwd     : chained data gradient of a square Dense stack, emitting every layer's d(pre-activation)
+//   * wgrad       : dW += X^T dY, db += colsum(dY): rows are the contraction, split over wavefronts with
+//                   a deterministic two-stage reduction (per-chunk partials, then one pass over chunks)
+#include "common.h"
+#include "mfma_tile.h"
+
+namespace tspgnn {
+
+// ------------------------------------------------------------------------------------ linear
+// Y[rows, NT*16] = X[rows, kin] * W (packed [kin, NT*16]).  Columns [0,n1) go to Y1, the rest to Y2
+// (optionally accumulated).  qc = 16-row blocks of W per LDS chunk: qc >= kin/16 keeps W resident and
+// lets wavefronts pull tiles through a ticket; otherwise the workgroup walks W chunk by chunk in
+// lock step, one tile per wavefront per round.
+template <int NT>
+__global__ __launch_bounds__(512) void linear_kernel(const float* __restrict__ X, int kin,
+                                                     const float* __restrict__ Wp, float* __restrict__ Y1, int n1,
+                                                     float* __restrict__ Y2, int n2, int acc2, int rows,
+                                                     int tiles_total, int qc) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int QT = kin >> 4;
+    const bool resident = qc >= QT;
+    float* lds_w = lds;
+    int* ticket = reinterpret_cast<int*>(lds + (size_t)(resident ? QT : qc) * 16 * NT * 16);
+    const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4, wave = tid >> 6;
+    const int nw = blockDim.x >> 6;
+
+    auto store = [&](f32x4 (&acc)[NT], size_t rc) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 16;
+            if (col < n1) {
+                st4(Y1 + rc * n1 + col + g * 4, acc[t]);
+            } else {
+                float* p = Y2 + rc * n2 + (col - n1) + g * 4;
+                st4(p, acc2 ? ld4(p) + acc[t] : acc[t]);
+            }
+        }
+    };
+
+    if (resident) {
+        copy_to_lds(lds_w, Wp, kin * NT * 16, tid, blockDim.x);
+        const int t_beg = (int)((long long)tiles_total * blockIdx.x / gridDim.x);
+        const int t_end = (int)((long long)tiles_total * (blockIdx.x + 1) / gridDim.x);
+        if (tid == 0) *ticket = t_beg;
+        __syncthreads();
+        for (;;) {
+            int tile = 0;
+            if (lane == 0) tile = atomicAdd(ticket, 1);
+            tile = __builtin_amdgcn_readfirstlane(tile);
+            if (tile >= t_end) break;
+            const int row = tile * 16 + rl;
+            const bool valid = row < rows;
+            const size_t rc = (size_t)(valid ? row : rows - 1);
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* xr = X + rc * kin + g * 4;
+            gemm_kloop<NT>(acc, lds_w, 0, 0, QT, xr, xr, QT, g, rl);
+            if (valid) store(acc, rc);
+        }
+    } else {
+        const int rounds = (tiles_total + nw - 1) / nw;
+        for (int r = blockIdx.x; r < rounds; r += gridDim.x) {
+            const int tile = r * nw + wave;
+            const bool live = tile < tiles_total;
+            const int row = tile * 16 + rl;
+            const bool valid = live && row < rows;
+            const size_t rc = (size_t)(valid ? row : rows - 1);
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* xr = X + rc * kin + g * 4;
+            for (int q0 = 0; q0 < QT; q0 += qc) {
+                const int q1 = min(QT, q0 + qc);
+                __syncthreads();
+                copy_to_lds(lds_w, Wp + (size_t)q0 * 16 * NT * 16, (q1 - q0) * 16 * NT * 16, tid, blockDim.x);
+                __syncthreads();
+                if (live) gemm_kloop<NT>(acc, lds_w, q0, q0, q1, xr, xr, QT, g, rl);
+            }
+            if (valid) store(acc, rc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ LN-LSTM backward
+// LayerNorm forward statistics of one gate held in the D-layout (TPG tiles x 4 regs per lane, the rest
+// of the row in the lanes l^16, l^32, l^48): v <- xhat = (v - mean) * rstd, returns rstd.
+template <int TPG>
+__device__ __forceinline__ float ln_normalize(f32x4 (&v)[TPG], int D) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+    s = sum_over_lane_groups16(s);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[t][r] -= mean;
+            q = fmaf(v[t][r], v[t][r], q);
+        }
+    }
+    q = sum_over_lane_groups16(q);
+    const float rstd = __builtin_amdgcn_rsqf(q / (float)D + 1e-12f);
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[t][r] *= rstd;
+    }
+    return rstd;
+}
+
+// LayerNorm backward of one gate: dn = gradient w.r.t. the LN output, xhat = normalised input.
+// Overwrites dn with the gradient w.r.t. the LN input and adds this tile's contribution to the
+// wavefront's (dgamma, dbeta) slab: sums over the tile's 16 rows by DPP row rotation, one ds_add per
+// feature from the lanes rl == 0.
+template <int TPG>
+__device__ __forceinline__ void ln_backward(f32x4 (&dn)[TPG], const f32x4 (&xhat)[TPG], float rstd,
+                                            const float* gamma, float* slab_dgamma, float* slab_dbeta, int g, int rl,
+                                            bool valid, int D) {
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        const f32x4 ga = ld4(gamma + t * 16 + g * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d_ = valid ? dn[t][r] : 0.f;
+            const float sg = row16_sum(d_ * xhat[t][r]);
+            const float sb = row16_sum(d_);
+            if (rl == 0) {
+                atomicAdd(slab_dgamma + t * 16 + g * 4 + r, sg);  // ds_add_f32, wavefront-private slab
+                atomicAdd(slab_dbeta + t * 16 + g * 4 + r, sb);
+            }
+            const float dxh = dn[t][r] * ga[r];
+            dn[t][r] = dxh;
+            m1 += dxh;
+            m2 = fmaf(dxh, xhat[t][r], m2);
+        }
+    }
+    m1 = sum_over_lane_groups16(m1) / (float)D;
+    m2 = sum_over_lane_groups16(m2) / (float)D;
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dn[t][r] = rstd * (dn[t][r] - m1 - xhat[t][r] * m2);
+    }
+}
+
+// Elementwise backward of one tile once z (the four pre-LayerNorm gates) is in acc.
+//   forward (graphnn.py:168-170 / LayerNormBasicLSTMCell.call):
+//     n_g = LN_g(z_g); c~ = c*sig(n_f+1) + sig(n_i)*relu(n_j); c' = LN_s(c~); h' = relu(c')*sig(n_o)
+//   given dh', dc' (read from global here, nullable -> 0): leaves dz in acc, dc in dc_out.
+// Gate activations are recomputed from the normalised gates where they are needed instead of being
+// kept live (registers: 4D/16 xhat + a few D/16-wide temporaries).
+template <int D>
+__device__ __forceinline__ void lstm_tile_backward(f32x4 (&acc)[D / 4], const float* c_row, const float* dh_row,
+                                                   const float* dcn_row, f32x4 (&dc_out)[D / 16],
+                                                   const float* lds_ln, float* slab, int g, int rl, bool valid) {
+    constexpr int TPG = D / 16;
+    f32x4 xi[TPG], xj[TPG], xf[TPG], xo[TPG];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        xi[t] = acc[t];
+        xj[t] = acc[TPG + t];
+        xf[t] = acc[2 * TPG + t];
+        xo[t] = acc[3 * TPG + t];
+    }
+    const float rstd_i = ln_normalize<TPG>(xi, D);
+    const float rstd_j = ln_normalize<TPG>(xj, D);
+    const float rstd_f = ln_normalize<TPG>(xf, D);
+    const float rstd_o = ln_normalize<TPG>(xo, D);
+    auto gate = [&](const f32x4 (&xh)[TPG], int gi, int t, int r) -> float {  // LN output of gate gi
+        return fmaf(xh[t][r], lds_ln[(2 * gi) * D + t * 16 + g * 4 + r], lds_ln[(2 * gi + 1) * D + t * 16 + g * 4 + r]);
+    };
+    f32x4 cf[TPG], xs[TPG];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        cf[t] = ld4(c_row + t * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float si = sigmoidf_(gate(xi, 0, t, r));
+            const float sf = sigmoidf_(gate(xf, 2, t, r) + 1.0f);
+            xs[t][r] = cf[t][r] * sf + si * fmaxf(gate(xj, 1, t, r), 0.f);
+        }
+    }
+    const float rstd_s = ln_normalize<TPG>(xs, D);
+    // through h' = relu(c')*sig(n_o) and c' = LN_s(c~)
+    f32x4 dcn[TPG], don[TPG];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        const f32x4 dh = dh_row ? ld4(dh_row + t * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 dci = dcn_row ? ld4(dcn_row + t * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float cn = gate(xs, 4, t, r);
+            const float so = sigmoidf_(gate(xo, 3, t, r));
+            dcn[t][r] = dci[r] + (cn > 0.f ? dh[r] * so : 0.f);
+            don[t][r] = dh[r] * fmaxf(cn, 0.f) * so * (1.0f - so);
+        }
+    }
+    ln_backward<TPG>(dcn, xs, rstd_s, lds_ln + 8 * D, slab + 8 * D, slab + 9 * D, g, rl, valid, D);  // dcn <- dc~
+    ln_backward<TPG>(don, xo, rstd_o, lds_ln + 6 * D, slab + 6 * D, slab + 7 * D, g, rl, valid, D);  // don <- dz_o
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) acc[3 * TPG + t] = don[t];
+    // gates f, i, j: reuse xs/don as temporaries
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sf = sigmoidf_(gate(xf, 2, t, r) + 1.0f);
+            dc_out[t][r] = dcn[t][r] * sf;
+            don[t][r] = dcn[t][r] * cf[t][r] * sf * (1.0f - sf);  // d n_f
+        }
+    }
+    ln_backward<TPG>(don, xf, rstd_f, lds_ln + 4 * D, slab + 4 * D, slab + 5 * D, g, rl, valid, D);
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) acc[2 * TPG + t] = don[t];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float si = sigmoidf_(gate(xi, 0, t, r));
+            const float nj = gate(xj, 1, t, r);
+            don[t][r] = dcn[t][r] * fmaxf(nj, 0.f) * si * (1.0f - si);  // d n_i
+            xs[t][r] = nj > 0.f ? dcn[t][r] * si : 0.f;                  // d n_j
+        }
+    }
+    ln_backward<TPG>(don, xi, rstd_i, lds_ln + 0 * D, slab + 0 * D, slab + 1 * D, g, rl, valid, D);
+    ln_backward<TPG>(xs, xj, rstd_j, lds_ln + 2 * D, slab + 2 * D, slab + 3 * D, g, rl, valid, D);
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        acc[t] = don[t];
+        acc[TPG + t] = xs[t];
+    }
+}
+
+// LDS: [K chunk or all of K] [ln 10*D] [NW slabs of 10*D] [ticket].
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const float* __restrict__ x, int dx,
+                                                             const float* __restrict__ h, const float* __restrict__ c,
+                                                             const float* __restrict__ K, const float* __restrict__ ln,
+                                                             const float* __restrict__ dh_out,
+                                                             const float* __restrict__ dc_out_in,
+                                                             float* __restrict__ dz, float* __restrict__ dc_in,
+                                                             float* __restrict__ ln_partial, int rows, int tiles_total,
+                                                             int qc) {
+    constexpr int NT4 = D / 4, TPG = D / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int QX = dx >> 4, QT = QX + TPG;
+    const bool resident = qc >= QT;
+    const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4, wave = tid >> 6;
+    const int nw = blockDim.x >> 6;
+    float* lds_k = lds;
+    float* lds_ln = lds + (size_t)(resident ? QT : qc) * 16 * 4 * D;
+    float* slabs = lds_ln + 10 * D;
+    int* ticket = reinterpret_cast<int*>(slabs + nw * 10 * D);
+    float* slab = slabs + wave * 10 * D;
+    for (int i = tid; i < 10 * D; i += blockDim.x) lds_ln[i] = ln[i];
+    for (int i = tid; i < nw * 10 * D; i += blockDim.x) slabs[i] = 0.f;
+
+    auto finish = [&](f32x4 (&acc)[NT4], size_t rc, bool valid) {
+        f32x4 dco[TPG];
+        const size_t o = rc * D + g * 4;
+        lstm_tile_backward<D>(acc, c + o, dh_out ? dh_out + o : nullptr, dc_out_in ? dc_out_in + o : nullptr, dco,
+                              lds_ln, slab, g, rl, valid);
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) st4(dz + rc * 4 * D + t * 16 + g * 4, acc[t]);
+#pragma unroll
+            for (int t = 0; t < TPG; ++t) st4(dc_in + o + t * 16, dco[t]);
+        }
+    };
+
+    if (resident) {
+        copy_to_lds(lds_k, K, (dx + D) * 4 * D, tid, blockDim.x);
+        const int t_beg = (int)((long long)tiles_total * blockIdx.x / gridDim.x);
+        const int t_end = (int)((long long)tiles_total * (blockIdx.x + 1) / gridDim.x);
+        if (tid == 0) *ticket = t_beg;
+        __syncthreads();
+        for (;;) {
+            int tile = 0;
+            if (lane == 0) tile = atomicAdd(ticket, 1);
+            tile = __builtin_amdgcn_readfirstlane(tile);
+            if (tile >= t_end) break;
+            const int row = tile * 16 + rl;
+            const bool valid = row < rows;
+            const size_t rc = (size_t)(valid ? row : rows - 1);
+            f32x4 acc[NT4];
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_kloop<NT4>(acc, lds_k, 0, 0, QT, x + rc * dx + g * 4, h + rc * D + g * 4, QX, g, rl);
+            finish(acc, rc, valid);
+        }
+    } else {
+        __syncthreads();
+        const int rounds = (tiles_total + nw - 1) / nw;
+        for (int r = blockIdx.x; r < rounds; r += gridDim.x) {
+            const int tile = r * nw + wave;
+            const bool live = tile < tiles_total;
+            const int row = tile * 16 + rl;
+            const bool valid = live && row < rows;
+            const size_t rc = (size_t)(valid ? row : rows - 1);
+            f32x4 acc[NT4];
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q0 = 0; q0 < QT; q0 += qc) {
+                const int q1 = min(QT, q0 + qc);
+                __syncthreads();
+                copy_to_lds(lds_k, K + (size_t)q0 * 16 * 4 * D, (q1 - q0) * 16 * 4 * D, tid, blockDim.x);
+                __syncthreads();
+                if (live) gemm_kloop<NT4>(acc, lds_k, q0, q0, q1, x + rc * dx + g * 4, h + rc * D + g * 4, QX, g, rl);
+            }
+            finish(acc, rc, valid);
+        }
+    }
+    // workgroup partial of the LayerNorm parameter gradients: fixed-order sum over the wavefront slabs
+    __syncthreads();
+    for (int i = tid; i < 10 * D; i += blockDim.x) {
+        float s = 0.f;
+        for (int w = 0; w < nw; ++w) s += slabs[w * 10 * D + i];
+        ln_partial[(size_t)blockIdx.x * 10 * D + i] = s;
+    }
+}
+
+// out[i] (+)= sum_{c < n_chunks} partial[c*stride + i]   -- second stage of every split reduction here.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n_chunks,
+                                                              long long stride, float* __restrict__ out, int n,
+                                                              int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < n_chunks; ++c) s += partial[(size_t)c * stride + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+// ------------------------------------------------------------------------------------ MLP backward (data)
+// g = dY; for l = L-1 .. 0:  g *= [A_l > 0] if layer l had relu;  dPre_l = g;  g = g W_l^T.   dX (+)= g.
+// A_l for l < L-1 comes from the saved activations, A_{L-1} (only if the last layer has relu) from Yout.
+template <int D, int MAXL>
+__global__ __launch_bounds__(512) void mlp_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ wt,
+                                                      const float* __restrict__ acts, long long acts_stride,
+                                                      const float* __restrict__ Yout, float* __restrict__ dpre,
+                                                      long long dpre_stride, float* __restrict__ dX, int acc_dx,
+                                                      int rows, int n_layers, unsigned relu_mask, int tiles_total) {
+    constexpr int NT = D / 16;
+    __shared__ __attribute__((aligned(16))) float lds[MAXL * D * D + 4];
+    int* ticket = reinterpret_cast<int*>(lds + MAXL * D * D);
+    const int tid = threadIdx.x;
+    copy_to_lds(lds, wt, n_layers * D * D, tid, blockDim.x);
+    const int t_beg = (int)((long long)tiles_total * blockIdx.x / gridDim.x);
+    const int t_end = (int)((long long)tiles_total * (blockIdx.x + 1) / gridDim.x);
+    if (tid == 0) *ticket = t_beg;
+    __syncthreads();
+    const int lane = tid & 63, rl = lane & 15, g = lane >> 4;
+    for (;;) {
+        int tile = 0;
+        if (lane == 0) tile = atomicAdd(ticket, 1);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= t_end) break;
+        const int row = tile * 16 + rl;
+        const bool valid = row < rows;
+        const size_t rbase = (size_t)(valid ? row : rows - 1) * D + g * 4;
+        f32x4 a[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) a[q] = ld4(dY + rbase + q * 16);
+        for (int l = n_layers - 1; l >= 0; --l) {
+            if ((relu_mask >> l) & 1u) {
+                const float* A = (l == n_layers - 1) ? Yout : acts + (size_t)l * acts_stride;
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    const f32x4 av = ld4(A + rbase + q * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[q][r] = av[r] > 0.f ? a[q][r] : 0.f;
+                }
+            }
+            if (dpre != nullptr && valid) {
+                float* dst = dpre + (size_t)l * dpre_stride + rbase;
+#pragma unroll
+                for (int q = 0; q < NT; ++q) st4(dst + q * 16, a[q]);
+            }
+            const float* wl = lds + l * D * D;
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (NT == 2) {
+#pragma unroll
+                for (int s = 0; s < D / 4; ++s) kstep<NT>(acc, wl + frag_off<NT>(s, g, rl), a[s >> 2][s & 3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NT; q += 4) {
+                    float b[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) b[i] = a[q + (i >> 2)][i & 3];
+                    ksteps<NT, 16>(acc, wl + frag_off<NT>(q * 4, g, rl), b);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[t] = acc[t];
+        }
+        if (dX != nullptr && valid) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float* p = dX + rbase + t * 16;
+                st4(p, acc_dx ? ld4(p) + a[t] : a[t]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ weight gradient
+// P[c][xf][yf] = sum_{r in chunk c} X[r][xf] * dY[r][yf]  for the (16*AV) x (16*BV) output block of this
+// wavefront;  MFMA 16x16x4 with the ROWS as the contraction: lane (fl = l&15, k = l>>4) loads AV
+// consecutive X features and BV consecutive dY features of row r0+k -- one fully coalesced 16*AV*4-byte
+// row segment per lane group -- and feeds them to AV*BV MFMAs.  Output tile (m,n), lane (j,g), reg r:
+//   X feature ib*16*AV + (4g+r)*AV + m,   dY feature jb*16*BV + j*BV + n.
+template <int V>
+struct VecLoad;
+template <>
+struct VecLoad<4> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+        const f32x4 t = ld4(p);
+        v[0] = t[0], v[1] = t[1], v[2] = t[2], v[3] = t[3];
+    }
+};
+template <>
+struct VecLoad<2> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[2]) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x, v[1] = t.y;
+    }
+};
+template <>
+struct VecLoad<1> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[1]) { v[0] = *p; }
+};
+
+template <int AV, int BV>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                    long long rows, int kin, int nout, float* __restrict__ P,
+                                                    float* __restrict__ Pb, int n_chunks, long long chunk_rows) {
+    const int lane = threadIdx.x & 63, fl = lane & 15, k = lane >> 4;
+    const int nbi = kin / (16 * AV), nbj = nout / (16 * BV), nob = nbi * nbj;
+    const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= (long long)n_chunks * nob) return;  // wave-uniform
+    const int c = (int)(w / nob), ob = (int)(w % nob), ib = ob / nbj, jb = ob % nbj;
+    const long long r_beg = c * chunk_rows, r_end = min(rows, r_beg + chunk_rows);
+    const float* xp = X + (size_t)ib * 16 * AV + fl * AV;
+    const float* yp = dY + (size_t)jb * 16 * BV + fl * BV;
+    f32x4 acc[AV][BV];
+#pragma unroll
+    for (int m = 0; m < AV; ++m)
+#pragma unroll
+        for (int n = 0; n < BV; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs[BV];
+#pragma unroll
+    for (int n = 0; n < BV; ++n) cs[n] = 0.f;
+    constexpr int UN = 4;  // k-steps (of 4 rows) in flight
+    for (long long r0 = r_beg; r0 < r_end; r0 += 4 * UN) {
+        float a[UN][AV], b[UN][BV];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long r = r0 + 4 * u + k;
+            const bool ok = r < r_end;
+            const long long rr = ok ? r : r_beg;
+            VecLoad<AV>::ld(xp + rr * kin, a[u]);
+            VecLoad<BV>::ld(yp + rr * nout, b[u]);
+            if (!ok) {
+#pragma unroll
+                for (int m = 0; m < AV; ++m) a[u][m] = 0.f;
+#pragma unroll
+                for (int n = 0; n < BV; ++n) b[u][n] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+            for (int n = 0; n < BV; ++n) cs[n] += b[u][n];
+#pragma unroll
+            for (int m = 0; m < AV; ++m)
+#pragma unroll
+                for (int n = 0; n < BV; ++n) acc[m][n] = MFMA16(a[u][m], b[u][n], acc[m][n]);
+        }
+    }
+    float* Pc = P + (size_t)c * kin * nout;
+#pragma unroll
+    for (int m = 0; m < AV; ++m)
+#pragma unroll
+        for (int n = 0; n < BV; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xf = ib * 16 * AV + (4 * k + r) * AV + m;
+                const int yf = jb * 16 * BV + fl * BV + n;
+                Pc[(size_t)xf * nout + yf] = acc[m][n][r];
+            }
+    if (Pb != nullptr && ib == 0) {
+#pragma unroll
+        for (int n = 0; n < BV; ++n) {
+            float s = cs[n];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (k == 0) Pb[(size_t)c * nout + jb * 16 * BV + fl * BV + n] = s;
+        }
+    }
+}
+
+static int pick_vec(int width) { return width % 64 == 0 ? 4 : (width % 32 == 0 ? 2 : 1); }
+
+// Split of the row range used by tspgnn_wgrad_f32 (and its workspace size).
+static void wgrad_plan(long long rows, int kin, int nout, int* n_chunks, long long* chunk_rows) {
+    const int av = pick_vec(kin), bv = pick_vec(nout);
+    const int nob = (kin / (16 * av)) * (nout / (16 * bv));
+    long long target = (long long)n_cus() * 8 / nob;  // ~8 wavefronts per CU in total
+    if (target < 1) target = 1;
+    long long by_rows = (rows + 255) / 256;             // at least 256 rows per chunk
+    long long nc = target < by_rows ? target : by_rows;
+    if (nc < 1) nc = 1;
+    long long cr = (rows + nc - 1) / nc;
+    cr = (cr + 15) / 16 * 16;
+    if (cr < 16) cr = 16;
+    nc = (rows + cr - 1) / cr;
+    if (nc < 1) nc = 1;
+    *n_chunks = (int)nc;
+    *chunk_rows = cr;
+}
+
+template <int NT>
+static int launch_linear(const float* X, int kin, const float* Wp, float* Y1, int n1, float* Y2, int n2, int acc2,
+                         int rows, hipStream_t st) {
+    const int tiles = (rows + 15) / 16;
+    const int QT = kin / 16;
+    const size_t per_q = (size_t)16 * NT * 16 * sizeof(float);
+    int qc = QT;
+    if ((size_t)QT * per_q + 16 > 150 * 1024) qc = (int)((128 * 1024) / per_q);
+    const size_t lds_bytes = (size_t)qc * per_q + 16;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return fail((int)e, "linear: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
+    int grid = n_cus() * per_cu;
+    const int nw = (qc >= QT && tiles <= grid * 4) ? 4 : 8;
+    const int max_grid = (tiles + nw - 1) / nw;
+    if (grid > max_grid) grid = max_grid;
+    linear_kernel<NT><<<grid, nw * 64, lds_bytes, st>>>(X, kin, Wp, Y1, n1, Y2, n2, acc2, rows, tiles, qc);
+    return launched("tspgnn_linear_f32");
+}
+
+template <int D>
+static int launch_lnlstm_bwd(const float* x, int dx, const float* h, const float* c, const float* K, const float* ln,
+                             const float* dh_out, const float* dc_out, float* dz, float* dc_in, float* ln_grad,
+                             float* workspace, int rows, hipStream_t st) {
+    // D=128 keeps 4D/16 + temporaries > 256 registers live: one wavefront per SIMD (512-register budget).
+    constexpr int NWMAX = D >= 128 ? 4 : 8;
+    const int tiles = (rows + 15) / 16;
+    const int QT = (dx + D) / 16;
+    const size_t per_q = (size_t)16 * 4 * D * sizeof(float);
+    int nw = NWMAX;
+    auto extra = [&](int nw_) { return (size_t)(10 * D + nw_ * 10 * D + 4) * sizeof(float); };
+    int qc = QT;
+    if ((size_t)QT * per_q + extra(NWMAX) > 160 * 1024) {
+        qc = (int)((160 * 1024 - extra(NWMAX)) / per_q);
+        if (qc < 1) return fail(TSPGNN_EUNSUPPORTED, "lnlstm_bwd: d=%d does not fit LDS", D);
+    } else if (tiles <= n_cus() * 4) {
+        nw = 4;
+    }
+    const size_t lds_bytes = (size_t)qc * per_q + extra(nw);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlstm_bwd_kernel<D, NWMAX>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return fail((int)e, "lnlstm_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    int grid = n_cus();
+    const int max_grid = (tiles + nw - 1) / nw;
+    if (grid > max_grid) grid = max_grid;
+    lnlstm_bwd_kernel<D, NWMAX><<<grid, nw * 64, lds_bytes, st>>>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in,
+                                                                  workspace, rows, tiles, qc);
+    int rc = launched("tspgnn_lnlstm_bwd_f32");
+    if (rc) return rc;
+    reduce_partials_kernel<<<(10 * D + 255) / 256, 256, 0, st>>>(workspace, grid, 10 * D, ln_grad, 10 * D, 1);
+    return launched("tspgnn_lnlstm_bwd_f32(reduce)");
+}
+
+template <int D, int MAXL>
+static int launch_mlp_bwd(const float* dY, const float* wt, const float* acts, long long acts_stride,
+                          const float* Yout, float* dpre, long long dpre_stride, float* dX, int acc_dx, int rows,
+                          int n_layers, unsigned relu_mask, hipStream_t st) {
+    const int tiles = (rows + 15) / 16;
+    const int lds_bytes = MAXL * D * D * 4 + 16;
+    const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
+    int grid = n_cus() * per_cu;
+    const int nw = tiles <= grid * 4 ? 4 : 8;
+    const int max_grid = (tiles + nw - 1) / nw;
+    if (grid > max_grid) grid = max_grid;
+    mlp_bwd_kernel<D, MAXL><<<grid, nw * 64, 0, st>>>(dY, wt, acts, acts_stride, Yout, dpre, dpre_stride, dX, acc_dx,
+                                                       rows, n_layers, relu_mask, tiles);
+    return launched("tspgnn_mlp_bwd_f32");
+}
+
+template <int AV, int BV>
+static int launch_wgrad(const float* X, const float* dY, long long rows, int kin, int nout, float* P, float* Pb,
+                        int n_chunks, long long chunk_rows, hipStream_t st) {
+    const int nob = (kin / (16 * AV)) * (nout / (16 * BV));
+    const long long waves = (long long)n_chunks * nob;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    wgrad_kernel<AV, BV><<<grid, 256, 0, st>>>(X, dY, rows, kin, nout, P, Pb, n_chunks, chunk_rows);
+    return launched("tspgnn_wgrad_f32");
+}
+
+}  // namespace tspgnn
+
+using namespace tspgnn;
+
+extern "C" int tspgnn_linear_f32(const float* X, int kin, const float* Wp, float* Y1, int n1, float* Y2, int n2,
+                                 int accumulate2, int rows, void* stream) {
+    TSPGNN_REQUIRE(rows >= 0, "linear: rows=%d", rows);
+    TSPGNN_REQUIRE(kin > 0 && kin % 16 == 0, "linear: kin=%d must be a positive multiple of 16", kin);
+    TSPGNN_REQUIRE(n1 >= 0 && n2 >= 0 && n1 % 16 == 0 && n2 % 16 == 0, "linear: n1=%d n2=%d must be multiples of 16", n1,
+                   n2);
+    const int nout = n1 + n2;
+    TSPGNN_REQUIRE(nout == 64 || nout == 128 || nout == 256, "linear: n1+n2=%d must be 64, 128 or 256", nout);
+    if (rows == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(X && Wp && (n1 == 0 || Y1) && (n2 == 0 || Y2), "linear: null pointer");
+    hipStream_t st = as_stream(stream);
+    switch (nout) {
+        case 64: return launch_linear<4>(X, kin, Wp, Y1, n1, Y2, n2, accumulate2, rows, st);
+        case 128: return launch_linear<8>(X, kin, Wp, Y1, n1, Y2, n2, accumulate2, rows, st);
+        default: return launch_linear<16>(X, kin, Wp, Y1, n1, Y2, n2, accumulate2, rows, st);
+    }
+}
+
+extern "C" long long tspgnn_lnlstm_bwd_workspace_floats(int d) { return (long long)n_cus() * 10 * d; }
+
+extern "C" int tspgnn_lnlstm_bwd_f32(const float* x, int dx, const float* h, const float* c, const float* K,
+                                     const float* ln, const float* dh_out, const float* dc_out, float* dz,
+                                     float* dc_in, float* ln_grad, float* workspace, int rows, int d, void* stream) {
+    TSPGNN_REQUIRE(rows >= 0, "lnlstm_bwd: rows=%d", rows);
+    TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "lnlstm_bwd: d=%d must be 32, 64 or 128", d);
+    TSPGNN_REQUIRE(dx >= 0 && dx % 16 == 0, "lnlstm_bwd: dx=%d must be a non-negative multiple of 16", dx);
+    if (rows == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(h && c && K && ln && dz && dc_in && ln_grad && workspace && (dx == 0 || x),
+                   "lnlstm_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    switch (d) {
+        case 32: return launch_lnlstm_bwd<32>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, st);
+        case 64: return launch_lnlstm_bwd<64>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, st);
+        default:
+            return launch_lnlstm_bwd<128>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, st);
+    }
+}
+
+extern "C" int tspgnn_mlp_bwd_f32(const float* dY, const float* wt, const float* acts, long long acts_stride,
+                                  const float* Yout, float* dpre, long long dpre_stride, float* dX, int accumulate_dx,
+                                  int rows, int d, int n_layers, unsigned relu_mask, void* stream) {
+    TSPGNN_REQUIRE(rows >= 0, "mlp_bwd: rows=%d", rows);
+    TSPGNN_REQUIRE(n_layers >= 1 && n_layers <= 4, "mlp_bwd: n_layers=%d must be in 1..4", n_layers);
+    TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "mlp_bwd: d=%d must be 32, 64 or 128", d);
+    if (rows == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(dY && wt, "mlp_bwd: null pointer");
+    const unsigned inner = relu_mask & ((1u << (n_layers - 1)) - 1u);
+    TSPGNN_REQUIRE(!inner || acts, "mlp_bwd: relu layers need the saved activations");
+    TSPGNN_REQUIRE(!((relu_mask >> (n_layers - 1)) & 1u) || Yout, "mlp_bwd: relu on the last layer needs Yout");
+    if (acts && acts_stride == 0) acts_stride = (long long)rows * d;
+    if (dpre && dpre_stride == 0) dpre_stride = (long long)rows * d;
+    hipStream_t st = as_stream(stream);
+    switch (d) {
+        case 32:
+            return launch_mlp_bwd<32, 4>(dY, wt, acts, acts_stride, Yout, dpre, dpre_stride, dX, accumulate_dx, rows,
+                                         n_layers, relu_mask, st);
+        case 64:
+            return launch_mlp_bwd<64, 4>(dY, wt, acts, acts_stride, Yout, dpre, dpre_stride, dX, accumulate_dx, rows,
+                                         n_layers, relu_mask, st);
+        default:
+            if (n_layers > 2)
+                return fail(TSPGNN_EUNSUPPORTED, "mlp_bwd: d=128 holds at most 2 layers in LDS (got %d)", n_layers);
+            return launch_mlp_bwd<128, 2>(dY, wt, acts, acts_stride, Yout, dpre, dpre_stride, dX, accumulate_dx, rows,
+                                          n_layers, relu_mask, st);
+    }
+}
+
+extern "C" long long tspgnn_wgrad_workspace_floats(long long rows, int kin, int nout) {
+    if (rows <= 0 || kin <= 0 || nout <= 0 || kin % 16 || nout % 16) return 0;
+    int nc;
+    long long cr;
+    wgrad_plan(rows, kin, nout, &nc, &cr);
+    return (long long)nc * ((long long)kin * nout + nout);
+}
+
+extern "C" int tspgnn_wgrad_f32(const float* X, const float* dY, long long rows, int kin, int nout, float* dW,
+                                float* db, float* workspace, void* stream) {
+    TSPGNN_REQUIRE(rows >= 0, "wgrad: rows=%lld", rows);
+    TSPGNN_REQUIRE(kin > 0 && kin % 16 == 0 && nout > 0 && nout % 16 == 0,
+                   "wgrad: kin=%d and nout=%d must be positive multiples of 16", kin, nout);
+    if (rows == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(X && dY && dW && workspace, "wgrad: null pointer");
+    int nc;
+    long long cr;
+    wgrad_plan(rows, kin, nout, &nc, &cr);
+    float* P = workspace;
+    float* Pb = db ? workspace + (size_t)nc * kin * nout : nullptr;
+    hipStream_t st = as_stream(stream);
+    const int av = pick_vec(kin), bv = pick_vec(nout);
+    int rc;
+#define TSPGNN_WG(A, B) rc = launch_wgrad<A, B>(X, dY, rows, kin, nout, P, Pb, nc, cr, st)
+    if (av == 4 && bv == 4) TSPGNN_WG(4, 4);
+    else if (av == 4 && bv == 2) TSPGNN_WG(4, 2);
+    else if (av == 4 && bv == 1) TSPGNN_WG(4, 1);
+    else if (av == 2 && bv == 4) TSPGNN_WG(2, 4);
+    else if (av == 2 && bv == 2) TSPGNN_WG(2, 2);
+    else if (av == 2 && bv == 1) TSPGNN_WG(2, 1);
+    else if (av == 1 && bv == 4) TSPGNN_WG(1, 4);
+    else if (av == 1 && bv == 2) TSPGNN_WG(1, 2);
+    else TSPGNN_WG(1, 1);
+#undef TSPGNN_WG
+    if (rc) return rc;
+    const int n = kin * nout;
+    reduce_partials_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, nc, n, dW, n, 1);
+    if ((rc = launched("tspgnn_wgrad_f32(reduce)"))) return rc;
+    if (db) {
+        reduce_partials_kernel<<<(nout + 255) / 256, 256, 0, st>>>(Pb, nc, nout, db, nout, 1);
+        rc = launched("tspgnn_wgrad_f32(reduce bias)");
+    }
+    return rc;
+}

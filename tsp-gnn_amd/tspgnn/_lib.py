@@ -16,8 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtspgnn.so")
 ABI_VERSION = 1
 
-c_int, c_uint, c_float, c_void_p, c_char_p = (ctypes.c_int, ctypes.c_uint, ctypes.c_float, ctypes.c_void_p,
-                                              ctypes.c_char_p)
+c_int, c_uint, c_float, c_void_p, c_char_p, c_longlong = (ctypes.c_int, ctypes.c_uint, ctypes.c_float,
+                                                          ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong)
 
 # name -> argtypes; every function returns int.  Mirrors include/tspgnn.h one to one
 # (tests/test_abi.py parses the header and checks this table against it).
@@ -25,8 +25,8 @@ SIGNATURES = {
     "tspgnn_gather2_sum_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tspgnn_csr_rowsum_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tspgnn_csr_spmm_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    "tspgnn_pack_weights_f32": [c_void_p, c_void_p, c_int, c_int, c_void_p],
-    "tspgnn_mlp_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_uint, c_void_p],
+    "tspgnn_pack_weights_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tspgnn_mlp_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_uint, c_void_p],
     "tspgnn_lnlstm_fwd_f32": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                               c_int, c_void_p],
     "tspgnn_einit_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
@@ -34,6 +34,27 @@ SIGNATURES = {
     "tspgnn_rowdot_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_segment_mean_f32": [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "tspgnn_bce_metrics_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "tspgnn_linear_f32": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tspgnn_lnlstm_bwd_f32": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_mlp_bwd_f32": [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
+                           c_int, c_int, c_int, c_uint, c_void_p],
+    "tspgnn_wgrad_f32": [c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "tspgnn_vote_grad_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "tspgnn_rowdot_bwd_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_wcolsum_f32": [c_void_p, c_void_p, c_longlong, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "tspgnn_einit_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_adam_clip_step_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
+                                  c_float, c_float, c_void_p, c_void_p, c_void_p],
+}
+
+# size queries: name -> argtypes; these return long long (floats of workspace)
+SIZE_QUERIES = {
+    "tspgnn_lnlstm_bwd_workspace_floats": [c_int],
+    "tspgnn_wgrad_workspace_floats": [c_longlong, c_int, c_int],
+    "tspgnn_wcolsum_workspace_floats": [c_longlong, c_int],
+    "tspgnn_einit_bwd_workspace_floats": [c_int, c_int],
+    "tspgnn_adam_workspace_floats": [],
 }
 
 
@@ -60,6 +81,10 @@ def _load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = c_int
+        fn.argtypes = argtypes
+    for name, argtypes in SIZE_QUERIES.items():
+        fn = getattr(lib, name)
+        fn.restype = c_longlong
         fn.argtypes = argtypes
     return lib
 

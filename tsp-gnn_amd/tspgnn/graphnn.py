@@ -135,7 +135,7 @@ class LayerNormBasicLSTMCell(object):
             if out is None:
                 out = torch.empty_like(K)
             _lib.call("tspgnn_pack_weights_f32", _lib.ptr(K), _lib.ptr(out), self.dx + self.d, 4 * self.d,
-                      _lib.current_stream())
+                      0, _lib.current_stream())
             return out
         return self.store.packed(("lstm", self.base), build)
 

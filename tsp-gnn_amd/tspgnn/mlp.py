@@ -99,7 +99,7 @@ class Mlp(object):
             per = d * d + d
             for j in range(last - first + 1):
                 o = j * per
-                _lib.call("tspgnn_pack_weights_f32", _lib.ptr(src[o:o + d * d]), _lib.ptr(out[o:o + d * d]), d, d, st)
+                _lib.call("tspgnn_pack_weights_f32", _lib.ptr(src[o:o + d * d]), _lib.ptr(out[o:o + d * d]), d, d, 0, st)
                 out[o + d * d:o + per].copy_(src[o + d * d:o + per])
             return out
         return self.store.packed(("mlp", self.name, first, last), build)
@@ -135,7 +135,7 @@ class Mlp(object):
             if save is not None and n > 1:
                 acts = torch.empty((n - 1, rows, d), dtype=torch.float32, device=x.device)
             _lib.call("tspgnn_mlp_fwd_f32", _lib.ptr(x), _lib.ptr(self.wb_packed(l0, l0 + n - 1, d)), _lib.ptr(out),
-                      _lib.ptr(acts), rows, d, n, mask, st)
+                      _lib.ptr(acts), 0, rows, d, n, mask, st)
             if save is not None:
                 save.append((l0, n, x, acts, out))
             x = out
