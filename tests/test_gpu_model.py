@@ -151,3 +151,73 @@ def test_c2_full_size_properties(cuda_device):
     t2 = (tspgnn.SparseEV(np.concatenate(uv2), EV.shape[1]), np.concatenate(W2), np.concatenate(C2), r[order], nv[order], ne[order])
     out2 = run_hip(64, params, t2, 32, fetch=("predictions",))
     assert rel_err(out2["predictions"], out["predictions"][order]) < 2e-6
+
+
+# ----------------------------------------------------------------------------- training path
+def grads_hip(d, params, batch_tuple, T):
+    model = tspgnn.build_network(d)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    EV, W, C, route_exists, n_vertices, n_edges = batch_tuple
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    out = sess.loss_and_grads(feed)
+    torch.cuda.synchronize()
+    return model, sess, feed, out, model.store.grad_dict()
+
+
+@pytest.mark.parametrize("name,d,T", [("n5_B2", 32, 3), ("ragged_B6", 64, 4), ("sparse_B4", 64, 6), ("n20_B32", 64, 8),
+                                      ("ragged_B6", 128, 2), ("n5_B2", 32, 0)])
+def test_gradient_parity_with_autograd_oracle(cuda_device, name, d, T):
+    """tf.gradients(loss) restated by torch autograd on the float64 oracle vs the HIP backward."""
+    t = pack_tuple(name, 1)
+    params = P.init_params(d, seed=21, perturb=True)
+    model, sess, feed, out, g = grads_hip(d, params, t, T)
+    batch = {"ev_uv": t[0].uv, "W": t[1], "C": t[2], "route_exists": t[3], "n_vertices": t[4], "n_edges": t[5]}
+    ref_out, ref_g = TO.loss_and_grads(params, batch, T, dtype=torch.float64)
+    _, f32_g = TO.loss_and_grads(params, batch, T, dtype=torch.float32, dense=True)   # the fp32 error budget
+    assert abs(float(out["stats"][0].item()) - ref_out["loss"].item()) < REL_TOL
+    l2 = {k: TO.L2NORM_SCALING * params[k] for k in params}          # the oracle's grads include the L2 term
+    worst, worst32 = 0.0, 0.0
+    gscale = max(np.abs(ref_g[k] - l2[k]).max() for k in ref_g)
+    for k in ref_g:
+        ref = ref_g[k] - l2[k]
+        # per-variable relative error, floored at 1e-3 of the largest gradient entry overall
+        scale = max(np.abs(ref).max(), 1e-3 * gscale)
+        err = np.abs(g[k] - ref).max() / scale
+        err32 = np.abs(f32_g[k] - ref_g[k]).max() / scale
+        worst, worst32 = max(worst, err), max(worst32, err32)
+        # 2e-5, or -- for sums with heavy cancellation -- what an op-for-op fp32 autograd run loses itself
+        assert err < max(2e-5, 3 * err32), (k, err, err32)
+    print("\n[%s d=%d T=%d] worst per-variable gradient rel err: HIP %.2e, fp32 restatement %.2e"
+          % (name, d, T, worst, worst32))
+
+
+def test_train_steps_follow_the_oracle(cuda_device):
+    """Three sess.run(train_step) calls (L2 + clip-by-global-norm 0.65 + Adam lr 2e-5) vs the oracle's."""
+    t = pack_tuple("ragged_B6", 0)
+    d, T = 64, 4
+    params = P.init_params(d, seed=2, perturb=True)
+    model = tspgnn.build_network(d)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    EV, W, C, route_exists, n_vertices, n_edges = t
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    batch = {"ev_uv": EV.uv, "W": W, "C": C, "route_exists": route_exists, "n_vertices": n_vertices, "n_edges": n_edges}
+    p = {k: v.copy() for k, v in params.items()}
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(v) for k, v in p.items()}
+    for step in (1, 2, 3):
+        vals = sess.run([model["train_step"], model["loss"], model["acc"], model["predictions"]], feed_dict=feed)
+        ref_out, p, m, v, gn = TO.train_step(p, batch, T, m, v, step)
+        assert vals[0] is None and abs(float(vals[1]) - ref_out["loss"].item()) < REL_TOL
+        assert abs(float(sess._adam["gnorm"].item()) - gn) < 2e-5 * gn
+    now = model.store.state_dict()
+    for k in p:
+        # three Adam steps move every weight by ~6e-5; compare the MOVEMENT, not just the value
+        moved_ref = p[k] - params[k]
+        moved = now[k].astype(np.float64) - params[k]
+        assert np.abs(moved - moved_ref).max() < 2e-7 + 0.02 * np.abs(moved_ref).max(), k

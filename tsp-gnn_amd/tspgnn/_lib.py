@@ -119,3 +119,9 @@ def ptr(t):
 
 def current_stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(query, *args, device=None):
+    """A scratch tensor sized by one of the tspgnn_*_workspace_floats queries."""
+    n = int(getattr(lib, query)(*args))
+    return torch.empty(max(n, 1), dtype=torch.float32, device=device)

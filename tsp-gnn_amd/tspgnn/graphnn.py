@@ -79,7 +79,7 @@ class DeviceAdjacency(object):
             return DeviceAdjacency.from_sparse_ev(mat, device)
         return DeviceAdjacency.from_dense(mat, device)
 
-    def matmul(self, y, transpose=False):
+    def matmul(self, y, transpose=False, out=None):
         """mat (x) y  or  mat^T (x) y  (tf.matmul(..., adjoint_a=transpose), graphnn.py:156-160)."""
         R, C = self.shape
         rows_in = R if transpose else C
@@ -89,7 +89,8 @@ class DeviceAdjacency(object):
         d = y.shape[1]
         if d % 4 != 0:
             raise NotImplementedError("aggregation kernels need d %% 4 == 0 (got %d)" % d)
-        out = torch.empty((rows_out, d), dtype=torch.float32, device=y.device)
+        if out is None:
+            out = torch.empty((rows_out, d), dtype=torch.float32, device=y.device)
         st = _lib.current_stream()
         if not transpose and self.uv is not None:
             _lib.call("tspgnn_gather2_sum_f32", _lib.ptr(self.uv), _lib.ptr(y), _lib.ptr(out), R, C, d, st)
@@ -142,18 +143,58 @@ class LayerNormBasicLSTMCell(object):
     def ln(self):
         return self.store.span(self.base + "/input/gamma", self.base + "/state/beta")
 
-    def __call__(self, inputs, state):
-        """Returns (new_h, LSTMStateTuple(new_c, new_h)) like the TF cell."""
+    def __call__(self, inputs, state, out=None):
+        """Returns (new_h, LSTMStateTuple(new_c, new_h)) like the TF cell.  ``out`` = (h_out, c_out)
+        lets the caller own the output buffers (training keeps every step's state)."""
         c, h = state.c, state.h
         rows = h.shape[0]
         if inputs.shape[0] != rows or inputs.shape[1] != self.dx:
             raise ValueError("cell input must be [%d,%d], got %s" % (rows, self.dx, tuple(inputs.shape)))
         x = inputs if inputs.is_contiguous() else inputs.contiguous()
-        h_out = torch.empty_like(h)
-        c_out = torch.empty_like(c)
+        h_out, c_out = out if out is not None else (torch.empty_like(h), torch.empty_like(c))
         _lib.call("tspgnn_lnlstm_fwd_f32", _lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(self.kernel_packed()),
                   _lib.ptr(self.ln()), _lib.ptr(h_out), _lib.ptr(c_out), rows, self.d, _lib.current_stream())
         return h_out, LSTMStateTuple(c=c_out, h=h_out)
+
+    # ------------------------------------------------------------------ backward
+    def kernel_t_packed(self):
+        """pack(K^T) ([4d, dx+d]) for the data gradient [dx | dh] = dz K^T."""
+        if (self.dx + self.d) not in (64, 128, 256):
+            raise NotImplementedError("LSTM backward needs dx+d in {64,128,256} (got %d)" % (self.dx + self.d))
+
+        def build(out):
+            K = self.kernel()
+            if out is None:
+                out = torch.empty_like(K)
+            _lib.call("tspgnn_pack_weights_f32", _lib.ptr(K), _lib.ptr(out), 4 * self.d, self.dx + self.d, 1,
+                      _lib.current_stream())
+            return out
+        return self.store.packed(("lstmT", self.base), build)
+
+    def ln_grad(self):
+        return self.store.grad_span(self.base + "/input/gamma", self.base + "/state/beta")
+
+    def backward(self, x, h, c, dh_out, dc_out, dz, dc_in, dx_out, dh_in, ws):
+        """One step: (dh_out, dc_out) -> dz (kept for the weight gradient), dc_in, dx_out, dh_in; the
+        LayerNorm parameter gradients are accumulated into the store's gradient buffer."""
+        rows, st = h.shape[0], _lib.current_stream()
+        _lib.call("tspgnn_lnlstm_bwd_f32", _lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(self.kernel_packed()),
+                  _lib.ptr(self.ln()), _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in),
+                  _lib.ptr(self.ln_grad()), _lib.ptr(ws), rows, self.d, st)
+        _lib.call("tspgnn_linear_f32", _lib.ptr(dz), 4 * self.d, _lib.ptr(self.kernel_t_packed()), _lib.ptr(dx_out),
+                  self.dx, _lib.ptr(dh_in), self.d, 0, rows, st)
+
+    def backward_weights(self, x_all, h_all, dz_all, rows):
+        """dK += [x|h]^T dz over all time steps at once (rows = T * rows_per_step)."""
+        gK = self.store.grad_view(self.base + "/kernel")
+        st = _lib.current_stream()
+        if self.dx:
+            ws = _lib.workspace("tspgnn_wgrad_workspace_floats", rows, self.dx, 4 * self.d, device=dz_all.device)
+            _lib.call("tspgnn_wgrad_f32", _lib.ptr(x_all), _lib.ptr(dz_all), rows, self.dx, 4 * self.d,
+                      _lib.ptr(gK[:self.dx]), None, _lib.ptr(ws), st)
+        ws = _lib.workspace("tspgnn_wgrad_workspace_floats", rows, self.d, 4 * self.d, device=dz_all.device)
+        _lib.call("tspgnn_wgrad_f32", _lib.ptr(h_all), _lib.ptr(dz_all), rows, self.d, 4 * self.d,
+                  _lib.ptr(gK[self.dx:]), None, _lib.ptr(ws), st)
 
 
 class GraphNN(object):
@@ -315,3 +356,118 @@ class GraphNN(object):
                 _, new_states[v] = self._RNN_cells[v](x, states[v])
             states = new_states
         return states
+
+    # ---------------------------------------------------------------- training: forward with a tape
+    def forward_train(self, adjacency_matrices, initial_embeddings, time_steps):
+        """Same computation as __call__, keeping what the backward pass needs: every step's states,
+        cell inputs and hidden MLP activations, each stored [T, rows, width] contiguous so that a
+        variable's weight gradient is ONE reduction over all time steps (sized for 288 GB of HBM:
+        ~10 GB at n=40, batch 128, T=32).  Returns (states, tape)."""
+        T = int(time_steps)
+        self.check_run(adjacency_matrices, initial_embeddings, T, {})
+        device = next(iter(initial_embeddings.values())).device
+        f32 = dict(dtype=torch.float32, device=device)
+        mats = {}
+        for v in self.var:
+            for u in self.loop[v]:
+                if "fun" in u or "var" not in u:
+                    raise NotImplementedError("training supports loop entries made of var / msg / mat only")
+                if "mat" in u and u["mat"] not in mats:
+                    mats[u["mat"]] = DeviceAdjacency.wrap(adjacency_matrices[u["mat"]], device)
+        tape = type("Tape", (), {})()
+        tape.T, tape.mats = T, mats
+        n = {v: initial_embeddings[v].shape[0] for v in self.var}
+        tape.H = {v: torch.empty((T + 1, n[v], d), **f32) for v, d in self.var.items()}
+        tape.C = {v: torch.empty((T + 1, n[v], d), **f32) for v, d in self.var.items()}
+        tape.X = {v: torch.empty((T, n[v], self._RNN_cells[v].dx), **f32) for v in self.var}
+        tape.acts = {}
+        for v in self.var:
+            tape.H[v][0].copy_(initial_embeddings[v])
+            tape.C[v][0].zero_()
+            for i, u in enumerate(self.loop[v]):
+                if "msg" in u:
+                    mlp = self._msg_MLPs[u["msg"]]
+                    src = u["var"]
+                    tape.acts[(v, i)] = torch.empty((max(mlp.n_square - 1, 1), T, n[src], self.var[src]), **f32)
+        for t in range(T):
+            for v in self.var:
+                single = len(self.loop[v]) == 1
+                inputs = []
+                for i, u in enumerate(self.loop[v]):
+                    src = u["var"]
+                    y = tape.H[src][t]
+                    direct = tape.X[v][t] if single else None     # last op of the entry writes the cell input
+                    if "msg" in u:
+                        mlp = self._msg_MLPs[u["msg"]]
+                        acts = tape.acts[(v, i)]
+                        out = direct if (direct is not None and "mat" not in u) else \
+                            torch.empty((n[src], mlp.sizes[-1]), **f32)
+                        y = mlp.forward_saving(y, out, acts[:, t], acts.stride(0))  # acts[:, t][l] = layer l at step t
+                    if "mat" in u:
+                        y = mats[u["mat"]].matmul(y, transpose=u.get("transpose?", False), out=direct)
+                    elif "msg" not in u and direct is not None:
+                        direct.copy_(y)
+                        y = direct
+                    inputs.append(y)
+                if not single:
+                    torch.cat(inputs, dim=1, out=tape.X[v][t])
+                self._RNN_cells[v](tape.X[v][t], LSTMStateTuple(c=tape.C[v][t], h=tape.H[v][t]),
+                                   out=(tape.H[v][t + 1], tape.C[v][t + 1]))
+        states = {v: LSTMStateTuple(c=tape.C[v][T], h=tape.H[v][T]) for v in self.var}
+        return states, tape
+
+    def backward(self, tape, dstates):
+        """Back-propagation through time of forward_train.  dstates: {var: (dh, dc)} gradients w.r.t. the
+        final states (None = zero).  Parameter gradients are ADDED to the store's flat gradient buffer;
+        returns {var: (d h0, d c0)} (gradients w.r.t. the initial embeddings / cell states)."""
+        T, mats = tape.T, tape.mats
+        device = self.store.theta.device
+        f32 = dict(dtype=torch.float32, device=device)
+        n = {v: tape.H[v].shape[1] for v in self.var}
+        DZ = {v: torch.empty((T, n[v], 4 * d), **f32) for v, d in self.var.items()}
+        DPRE = {}
+        for (v, i), acts in tape.acts.items():
+            u = self.loop[v][i]
+            mlp = self._msg_MLPs[u["msg"]]
+            DPRE[(v, i)] = torch.empty((mlp.n_square, T, n[u["var"]], self.var[u["var"]]), **f32)
+        ws = {v: _lib.workspace("tspgnn_lnlstm_bwd_workspace_floats", d, device=device) for v, d in self.var.items()}
+        dH = {v: (dstates.get(v, (None, None))[0]) for v in self.var}
+        dC = {v: (dstates.get(v, (None, None))[1]) for v in self.var}
+        for t in range(T - 1, -1, -1):
+            ndH = {v: torch.empty((n[v], d), **f32) for v, d in self.var.items()}
+            ndC = {v: torch.empty((n[v], d), **f32) for v, d in self.var.items()}
+            dX = {v: torch.empty((n[v], self._RNN_cells[v].dx), **f32) for v in self.var}
+            for v in self.var:   # all cells first: they WRITE dh; the message paths below ACCUMULATE into it
+                self._RNN_cells[v].backward(tape.X[v][t], tape.H[v][t], tape.C[v][t], dH[v], dC[v], DZ[v][t], ndC[v],
+                                            dX[v], ndH[v], ws[v])
+            for v in self.var:
+                off = 0
+                for i, u in enumerate(self.loop[v]):
+                    w = self._update_width(u)
+                    dy = dX[v] if len(self.loop[v]) == 1 else dX[v][:, off:off + w].contiguous()
+                    off += w
+                    src = u["var"]
+                    if "mat" in u:   # adjoint of mat (x) y is mat^T (x) dy and vice versa
+                        dy = mats[u["mat"]].matmul(dy, transpose=not u.get("transpose?", False))
+                    if "msg" in u:
+                        mlp = self._msg_MLPs[u["msg"]]
+                        acts, dpre = tape.acts[(v, i)], DPRE[(v, i)]
+                        mlp.backward_data(dy, acts[:, t], acts.stride(0), None, dpre[:, t], dpre.stride(0), ndH[src],
+                                          accumulate=True)
+                    else:
+                        ndH[src].add_(dy)
+            dH, dC = ndH, ndC
+        # weight gradients: one reduction per variable over all T steps
+        for v, d in self.var.items():
+            cell = self._RNN_cells[v]
+            cell.backward_weights(tape.X[v].view(-1, cell.dx), tape.H[v][:T].reshape(-1, d), DZ[v].view(-1, 4 * d),
+                                  T * n[v])
+        for (v, i), dpre in DPRE.items():
+            u = self.loop[v][i]
+            mlp = self._msg_MLPs[u["msg"]]
+            src, dsrc = u["var"], self.var[u["var"]]
+            rows = T * n[src]
+            acts = tape.acts[(v, i)]
+            inputs = [tape.H[src][:T].reshape(-1, dsrc)] + [acts[l].view(-1, dsrc) for l in range(mlp.n_square - 1)]
+            mlp.backward_weights(inputs, [dpre[l].view(-1, dsrc) for l in range(mlp.n_square)], rows)
+        return {v: (dH[v], dC[v]) for v in self.var}

@@ -104,6 +104,78 @@ class Mlp(object):
             return out
         return self.store.packed(("mlp", self.name, first, last), build)
 
+    def wt_packed(self, first, last, d):
+        """pack(W_l^T) for square layers first..last back to back (data-gradient kernels)."""
+        def build(out):
+            if out is None:
+                out = torch.empty((last - first + 1) * d * d, dtype=torch.float32, device=self.store.theta.device)
+            st = _lib.current_stream()
+            for j in range(last - first + 1):
+                W = self.store.view(self.layer_names[first + j] + "/kernel")
+                _lib.call("tspgnn_pack_weights_f32", _lib.ptr(W), _lib.ptr(out[j * d * d:(j + 1) * d * d]), d, d, 1, st)
+            return out
+        return self.store.packed(("mlpT", self.name, first, last), build)
+
+    @property
+    def n_square(self):
+        return self._plan[2] if self._plan[0] == "square" else 0
+
+    def relu_mask(self, first, n):
+        mask = 0
+        for j in range(n):
+            if self.relu[first + j]:
+                mask |= 1 << j
+        return mask
+
+    def _chunks(self):
+        kind, d, n_sq, head = self._plan
+        step = 2 if d == 128 else 4   # layers whose weights fit LDS together
+        return [(l0, min(step, n_sq - l0)) for l0 in range(0, n_sq, step)]
+
+    def forward_saving(self, x, out, acts, acts_stride):
+        """Square chain forward writing into caller-owned buffers: ``out`` [rows,d] and the hidden
+        activations at acts + l*acts_stride (layer-major, so that all time steps of one layer are
+        contiguous for the batched weight gradient).  ``acts`` is a tensor whose dim 0 indexes the layer."""
+        kind, d, n_sq, head = self._plan
+        if kind != "square":
+            raise NotImplementedError("forward_saving: square Dense chains only")
+        st, rows = _lib.current_stream(), x.shape[0]
+        chunks = self._chunks()
+        for l0, n in chunks:
+            last = l0 + n == n_sq
+            src = x if l0 == 0 else acts[l0 - 1]
+            dst = out if last else acts[l0 + n - 1]
+            _lib.call("tspgnn_mlp_fwd_f32", _lib.ptr(src), _lib.ptr(self.wb_packed(l0, l0 + n - 1, d)), _lib.ptr(dst),
+                      _lib.ptr(acts[l0]) if n > 1 else None, acts_stride, rows, d, n, self.relu_mask(l0, n), st)
+        return out
+
+    def backward_data(self, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate):
+        """Data gradient of the square chain (tspgnn_mlp_bwd_f32), chunk by chunk in reverse."""
+        kind, d, n_sq, head = self._plan
+        st, rows = _lib.current_stream(), dY.shape[0]
+        g = dY
+        for l0, n in reversed(self._chunks()):
+            last = l0 + n == n_sq
+            first = l0 == 0
+            yo = y_out if last else acts[l0 + n - 1]
+            dst = dX if first else torch.empty_like(dY)
+            _lib.call("tspgnn_mlp_bwd_f32", _lib.ptr(g), _lib.ptr(self.wt_packed(l0, l0 + n - 1, d)),
+                      _lib.ptr(acts[l0]) if n > 1 else None, acts_stride, _lib.ptr(yo), _lib.ptr(dpre[l0]), dpre_stride,
+                      _lib.ptr(dst), 1 if (accumulate and first) else 0, rows, d, n, self.relu_mask(l0, n), st)
+            g = dst
+
+    def backward_weights(self, layer_inputs, layer_dpre, rows):
+        """dW_l += X_l^T dPre_l, db_l += colsum(dPre_l) for the square layers; ``rows`` may span all
+        time steps (inputs / dpre are [T*rows_per_step, d] contiguous)."""
+        kind, d, n_sq, head = self._plan
+        ws = _lib.workspace("tspgnn_wgrad_workspace_floats", rows, d, d, device=layer_dpre[0].device)
+        st = _lib.current_stream()
+        for l in range(n_sq):
+            name = self.layer_names[l]
+            _lib.call("tspgnn_wgrad_f32", _lib.ptr(layer_inputs[l]), _lib.ptr(layer_dpre[l]), rows, d, d,
+                      _lib.ptr(self.store.grad_view(name + "/kernel")), _lib.ptr(self.store.grad_view(name + "/bias")),
+                      _lib.ptr(ws), st)
+
     # ------------------------------------------------------------------ forward
     def __call__(self, inputs, save=None):
         """inputs: fp32 device tensor [rows, input_size].  ``save`` (optional list) receives the

@@ -132,7 +132,7 @@ class Session(object):
     ``Session(model=None, device='cuda:0')``: without ``model`` it binds to the most recently
     built network (the TF default-graph behaviour train.py:202-206 relies on)."""
 
-    def __init__(self, model=None, device=None):
+    def __init__(self, model=None, device=None, process_group=None):
         self.model = model if model is not None else build_network.last
         if self.model is None:
             raise RuntimeError("Session: call build_network(d) first")
@@ -145,6 +145,8 @@ class Session(object):
         if not self.store.finalized:
             self.store.finalize(self.device)
         self._adj_cache = (None, None)
+        self._adam = None
+        self.process_group = process_group
 
     def __enter__(self):
         return self
@@ -264,5 +266,100 @@ class Session(object):
                 results.append(np.float32(stats[idx]))
         return results[0] if single else results
 
+    # ------------------------------------------------------------------ training (model.py:160-167)
+    def loss_and_grads(self, feed):
+        """Forward + backward of ``loss`` (the L2 term is added by the optimiser kernel).  Leaves the
+        gradient of the local mean loss in ``store.grad``; returns the forward outputs."""
+        m, d, st = self.model, self.model.d, _lib.current_stream()
+        b = feed if isinstance(feed, DeviceBatch) else self.prepare(feed)
+        store = self.store
+        store.zero_grad()
+        f32 = dict(dtype=torch.float32, device=self.device)
+        E0 = m.edge_init_MLP(b.WC)
+        V0 = torch.empty((b.N, d), **f32)
+        _lib.call("tspgnn_tile_rows_f32", _lib.ptr(store.view("V_init")), 1.0 / math.sqrt(float(d)), _lib.ptr(V0),
+                  b.N, d, st)
+        last, tape = m["gnn"].forward_train({"EV": b.adj}, {"V": V0, "E": E0}, b.T)
+        # vote head: three relu Dense(d) + Dense(1) (model.py:107-115,128), keeping the hidden activations
+        mv = m.E_vote_MLP
+        n_sq = mv.n_square
+        EhT = last["E"].h
+        Y3 = torch.empty((b.M, d), **f32)
+        acts = torch.empty((max(n_sq - 1, 1), b.M, d), **f32)
+        mv.forward_saving(EhT, Y3, acts, acts.stride(0))
+        head = mv.layer_names[-1]
+        vote = torch.empty(b.M, **f32)
+        _lib.call("tspgnn_rowdot_f32", _lib.ptr(Y3), _lib.ptr(store.view(head + "/kernel")),
+                  _lib.ptr(store.view(head + "/bias")), _lib.ptr(vote), b.M, d, st)
+        logits = torch.empty(b.B, **f32)
+        _lib.call("tspgnn_segment_mean_f32", _lib.ptr(vote), _lib.ptr(b.seg), _lib.ptr(logits), b.B, st)
+        pred = torch.empty(b.B, **f32)
+        stats = torch.empty(6, **f32)
+        _lib.call("tspgnn_bce_metrics_f32", _lib.ptr(logits), _lib.ptr(b.labels), _lib.ptr(pred), _lib.ptr(stats), b.B,
+                  st)
+        # ---- backward: loss -> votes -> vote head -> message passing -> initial embeddings
+        dvote = torch.empty(b.M, **f32)
+        _lib.call("tspgnn_vote_grad_f32", _lib.ptr(logits), _lib.ptr(b.labels), _lib.ptr(b.seg), _lib.ptr(dvote), b.B,
+                  st)
+        dY3 = torch.empty((b.M, d), **f32)
+        _lib.call("tspgnn_rowdot_bwd_f32", _lib.ptr(dvote), _lib.ptr(store.view(head + "/kernel")), _lib.ptr(dY3), b.M,
+                  d, st)
+        ws = _lib.workspace("tspgnn_wcolsum_workspace_floats", b.M, d, device=self.device)
+        _lib.call("tspgnn_wcolsum_f32", _lib.ptr(Y3), _lib.ptr(dvote), b.M, d, 1.0,
+                  _lib.ptr(store.grad_view(head + "/kernel")), _lib.ptr(store.grad_view(head + "/bias")), _lib.ptr(ws),
+                  st)
+        dpre = torch.empty((n_sq, b.M, d), **f32)
+        dEh = torch.empty((b.M, d), **f32)
+        mv.backward_data(dY3, acts, acts.stride(0), Y3, dpre, dpre.stride(0), dEh, accumulate=False)
+        mv.backward_weights([EhT] + [acts[l] for l in range(n_sq - 1)], [dpre[l] for l in range(n_sq)], b.M)
+        d0 = m["gnn"].backward(tape, {"E": (dEh, None)})
+        dE0, dV0 = d0["E"][0], d0["V"][0]
+        mi = m.edge_init_MLP
+        ws = _lib.workspace("tspgnn_einit_bwd_workspace_floats", b.M, d, device=self.device)
+        _lib.call("tspgnn_einit_bwd_f32", _lib.ptr(b.WC), _lib.ptr(mi.wb()), _lib.ptr(dE0),
+                  _lib.ptr(store.grad_span(mi.layer_names[0] + "/kernel", mi.layer_names[-1] + "/bias")), _lib.ptr(ws),
+                  b.M, d, st)
+        if dV0 is not None:   # None: zero message-passing steps, the loss does not see V_init
+            ws = _lib.workspace("tspgnn_wcolsum_workspace_floats", b.N, d, device=self.device)
+            _lib.call("tspgnn_wcolsum_f32", _lib.ptr(dV0), None, b.N, d, 1.0 / math.sqrt(float(d)),
+                      _lib.ptr(store.grad_view("V_init")), None, _lib.ptr(ws), st)
+        return {"last_states": last, "E_vote": vote, "logits": logits, "predictions": pred, "stats": stats, "batch": b}
+
+    def allreduce_grads(self, local_batch):
+        """Data-parallel step: the loss is a mean over the GLOBAL batch, so each
+        rank's gradient of its local mean is weighted by B_r / B and summed with ONE all-reduce of the
+        flat gradient bucket (RCCL over xGMI when the backend is 'nccl').  No-op without a process group."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.process_group) == 1:
+            return 1.0
+        tot = torch.tensor([float(local_batch)], dtype=torch.float64, device=self.store.grad.device)
+        dist.all_reduce(tot, group=self.process_group)
+        w = float(local_batch) / float(tot.item())
+        self.store.grad.mul_(w)
+        dist.all_reduce(self.store.grad, group=self.process_group)
+        return w
+
+    def apply_gradients(self):
+        """g += 1e-10*theta; clip_by_global_norm(0.65); Adam(lr=2e-5) -- one fused pass over theta."""
+        store = self.store
+        if self._adam is None:
+            self._adam = {"m": torch.zeros_like(store.theta), "v": torch.zeros_like(store.theta), "step": 0,
+                          "gnorm": torch.zeros(1, dtype=torch.float32, device=self.device),
+                          "ws": _lib.workspace("tspgnn_adam_workspace_floats", device=self.device)}
+        a = self._adam
+        a["step"] += 1
+        t = a["step"]
+        b1, b2, eps = 0.9, 0.999, 1e-8     # tf.train.AdamOptimizer defaults
+        lr_t = LEARNING_RATE * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+        _lib.call("tspgnn_adam_clip_step_f32", _lib.ptr(store.theta), _lib.ptr(store.grad), _lib.ptr(a["m"]),
+                  _lib.ptr(a["v"]), store.theta.numel(), L2NORM_SCALING, GLOBAL_NORM_CLIP, lr_t, b1, b2, eps,
+                  _lib.ptr(a["gnorm"]), _lib.ptr(a["ws"]), _lib.current_stream())
+        store.touch()
+        return a["gnorm"]
+
     def train_step(self, feed):
-        raise NotImplementedError("train_step: backward kernels are not built yet")
+        """One ``sess.run(train_step)``: forward, backward, (all-reduce), L2 + clip + Adam."""
+        out = self.loss_and_grads(feed)
+        self.allreduce_grads(out["batch"].B)
+        out["global_norm"] = self.apply_gradients()
+        return out

@@ -46,6 +46,7 @@ class VariableStore(object):
         self.device = None
         self.version = 0      # bumped whenever theta changes; keys the packed-weight cache
         self._packed = {}
+        self.grad = None      # flat gradient buffer, same layout as theta (allocated on first use)
 
     # -- declaration phase -------------------------------------------------------------
     def declare(self, name, shape, initializer):
@@ -121,6 +122,28 @@ class VariableStore(object):
 
     def offset(self, name):
         return self._offsets[name][0]
+
+    # -- gradients (same flat layout as theta: one buffer to all-reduce, clip and apply) ----
+    def zero_grad(self):
+        if self.grad is None:
+            self.grad = torch.zeros_like(self.theta)
+        else:
+            self.grad.zero_()
+        return self.grad
+
+    def grad_view(self, name):
+        off, n = self._offsets[name]
+        return self.grad[off:off + n].view(self._decl[name][0])
+
+    def grad_span(self, first, last):
+        o0, _ = self._offsets[first]
+        o1, n1 = self._offsets[last]
+        return self.grad[o0:o1 + n1]
+
+    def grad_dict(self):
+        host = self.grad.detach().cpu().numpy()
+        return OrderedDict((name, host[off:off + n].reshape(self._decl[name][0]).copy())
+                           for name, (off, n) in self._offsets.items())
 
     def load(self, values):
         """Assign variables from a {name: array} mapping (checkpoint restore / parity tests)."""
