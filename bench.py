@@ -55,6 +55,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"],
+                    help="what one timed step is: a forward pass (default, the metric's definition) or a full "
+                         "training step (forward + backward + gradient all-reduce + L2/clip/Adam)")
+    ap.add_argument("--train-steps", type=int, default=3, help="extra (untimed-by-the-driver) training steps reported "
+                                                               "under 'train' when --mode forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (bounded sample)")
     args = ap.parse_args()
@@ -93,21 +98,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = sess.forward_device(dev_batch)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = sess.forward_device(dev_batch)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    step_fn = sess.forward_device if args.mode == "forward" else sess.train_step
+
+    def timed(fn, n_warm, n_steps):
+        o = None
+        for _ in range(n_warm):
+            o = fn(dev_batch)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            o = fn(dev_batch)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, o
+
+    elapsed, out = timed(step_fn, args.warmup, args.steps)
     loss = float(out["stats"][0].item())
     if not np.isfinite(loss):
         raise SystemExit("non-finite loss in the timed region")
+    train = None
+    if args.mode == "forward" and args.train_steps > 0:
+        # the training step (backward + RCCL all-reduce of the 462 KB gradient bucket + fused optimiser)
+        dt_train, tout = timed(sess.train_step, 1, args.train_steps)
+        train = {"ms_per_batch": round(1e3 * dt_train / args.train_steps, 3),
+                 "mp_steps_per_s": round(world * args.train_steps * T / dt_train, 2),
+                 "steps": args.train_steps, "loss": float(tout["stats"][0].item()),
+                 "global_norm": float(tout["global_norm"].item()),
+                 "what": "forward + backward through T steps + gradient all-reduce (world %d) + L2/clip/Adam" % world}
+        sess.run(tspgnn.global_variables_initializer(seed=0))   # restore the benchmark weights
 
     result = None
     if rank == 0:
@@ -188,8 +210,9 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d complete Euclidean graphs n=%d, d=%d, T=%d, fp32, forward pass "
-                                   "(E_init -> T x {msg MLPs, SpMM pair, LN-LSTMs} -> vote -> loss)"
-                                   % (args.workload, len(sizes), sizes[0], d, T),
+                                   "(E_init -> T x {msg MLPs, SpMM pair, LN-LSTMs} -> vote -> loss)%s"
+                                   % (args.workload, len(sizes), sizes[0], d, T,
+                                      "" if args.mode == "forward" else " + backward + all-reduce + Adam"),
                        "per_gpu_batch": len(sizes), "global_batch": len(sizes) * world, "N": N, "M": M,
                        "parallelism": "shard-by-instance x%d, no data-path collective" % world},
             "edges_per_s": round(mp_steps_per_s * M, 1),
@@ -197,6 +220,8 @@ def main():
             "roofline": roofline,
             "roofline_dense": roofline_dense,
             "cpu_baseline": cpu_baseline,
+            "mode": args.mode,
+            "train": train,
             "kernels_us": {k: {"n": v["n"], "avg_us": round(v["avg_us"], 2)} for k, v in kernels_us.items()},
             "host_pack_s": round(t_pack, 4),
             "loss": loss,
