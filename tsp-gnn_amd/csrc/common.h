@@ -16,6 +16,11 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// out[i] (+)= scale * sum_{c<n_chunks} partial[c*stride+i]: fixed-order second stage of the split reductions
+// (dense_bwd.hip).
+void reduce_partials(const float* partial, int n_chunks, long long stride, float* out, int n, float scale,
+                     int accumulate, hipStream_t st);
+
 #define TSPGNN_REQUIRE(cond, ...) \
     do {                          \
         if (!(cond)) return ::tspgnn::fail(TSPGNN_EINVAL, __VA_ARGS__); \

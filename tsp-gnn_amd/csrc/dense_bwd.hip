@@ -328,14 +328,35 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const float* __rest
 }
 
 // out[i] (+)= sum_{c < n_chunks} partial[c*stride + i]   -- second stage of every split reduction here.
+// Thread (i, slice) first sums the chunks c = slice, slice+S, ... (S = blockDim.y slices, loads of
+// different slices in flight together, each coalesced over i), then the slices are folded through LDS
+// in a fixed order: deterministic, and parallel enough for n = 4096 outputs x 2048 chunks.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n_chunks,
                                                               long long stride, float* __restrict__ out, int n,
-                                                              int accumulate) {
+                                                              float scale, int accumulate) {
+    __shared__ float red[256];
+    const int S = blockDim.y;  // slices; blockDim.x * S == 256
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     float s = 0.f;
-    for (int c = 0; c < n_chunks; ++c) s += partial[(size_t)c * stride + i];
-    out[i] = accumulate ? out[i] + s : s;
+    if (i < n) {
+        for (int c = threadIdx.y; c < n_chunks; c += S) s += partial[(size_t)c * stride + i];
+    }
+    red[threadIdx.y * blockDim.x + threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && i < n) {
+        float t = red[threadIdx.x];
+        for (int k = 1; k < S; ++k) t += red[k * blockDim.x + threadIdx.x];
+        out[i] = accumulate ? fmaf(scale, t, out[i]) : scale * t;
+    }
+}
+
+void reduce_partials(const float* partial, int n_chunks, long long stride, float* out, int n, float scale,
+                     int accumulate, hipStream_t st) {
+    // many chunks: 16 outputs x 16 slices per workgroup; few chunks: 256 outputs x 1 slice
+    const int S = n_chunks >= 64 ? 16 : (n_chunks >= 8 ? 4 : 1);
+    const dim3 block(256 / S, S);
+    reduce_partials_kernel<<<(n + block.x - 1) / block.x, block, 0, st>>>(partial, n_chunks, stride, out, n, scale,
+                                                                          accumulate);
 }
 
 // ------------------------------------------------------------------------------------ MLP backward (data)
@@ -514,7 +535,7 @@ static int pick_vec(int width) { return width % 64 == 0 ? 4 : (width % 32 == 0 ?
 static void wgrad_plan(long long rows, int kin, int nout, int* n_chunks, long long* chunk_rows) {
     const int av = pick_vec(kin), bv = pick_vec(nout);
     const int nob = (kin / (16 * av)) * (nout / (16 * bv));
-    long long target = (long long)n_cus() * 8 / nob;  // ~8 wavefronts per CU in total
+    long long target = (long long)n_cus() * 4 / nob;  // ~4 wavefronts per CU in total
     if (target < 1) target = 1;
     long long by_rows = (rows + 255) / 256;             // at least 256 rows per chunk
     long long nc = target < by_rows ? target : by_rows;
@@ -578,7 +599,7 @@ static int launch_lnlstm_bwd(const float* x, int dx, const float* h, const float
                                                                   workspace, rows, tiles, qc);
     int rc = launched("tspgnn_lnlstm_bwd_f32");
     if (rc) return rc;
-    reduce_partials_kernel<<<(10 * D + 255) / 256, 256, 0, st>>>(workspace, grid, 10 * D, ln_grad, 10 * D, 1);
+    reduce_partials(workspace, grid, 10 * D, ln_grad, 10 * D, 1.0f, 1, st);
     return launched("tspgnn_lnlstm_bwd_f32(reduce)");
 }
 
@@ -715,10 +736,10 @@ extern "C" int tspgnn_wgrad_f32(const float* X, const float* dY, long long rows,
 #undef TSPGNN_WG
     if (rc) return rc;
     const int n = kin * nout;
-    reduce_partials_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, nc, n, dW, n, 1);
+    reduce_partials(P, nc, n, dW, n, 1.0f, 1, st);
     if ((rc = launched("tspgnn_wgrad_f32(reduce)"))) return rc;
     if (db) {
-        reduce_partials_kernel<<<(nout + 255) / 256, 256, 0, st>>>(Pb, nc, nout, db, nout, 1);
+        reduce_partials(Pb, nc, nout, db, nout, 1.0f, 1, st);
         rc = launched("tspgnn_wgrad_f32(reduce bias)");
     }
     return rc;

@@ -68,16 +68,6 @@ __global__ __launch_bounds__(256) void wcolsum_kernel(const float4* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void reduce_scaled_kernel(const float* __restrict__ partial, int n_chunks,
-                                                            long long stride, float* __restrict__ out, int n,
-                                                            float scale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int c = 0; c < n_chunks; ++c) s += partial[(size_t)c * stride + i];
-    out[i] += scale * s;
-}
-
 // ------------------------------------------------------------- E_init_MLP weight gradients
 // Workgroup = 64 edges.  Phase 1 (one thread per edge): recompute the forward chain, back-propagate
 // dE0 through it, park activations and d(pre-activations) in LDS.  Phase 2 (all 256 threads): every
@@ -289,10 +279,10 @@ extern "C" int tspgnn_wcolsum_f32(const float* X, const float* wt, long long row
                                                  d / 4, cr);
     int rc = launched("tspgnn_wcolsum_f32");
     if (rc) return rc;
-    reduce_scaled_kernel<<<(d + 255) / 256, 256, 0, st>>>(workspace, nc, d, out, d, scale);
+    reduce_partials(workspace, nc, d, out, d, scale, 1, st);
     if ((rc = launched("tspgnn_wcolsum_f32(reduce)"))) return rc;
     if (out_wsum) {
-        reduce_scaled_kernel<<<1, 256, 0, st>>>(Pw, nc, 1, out_wsum, 1, scale);
+        reduce_partials(Pw, nc, 1, out_wsum, 1, scale, 1, st);
         rc = launched("tspgnn_wcolsum_f32(reduce w)");
     }
     return rc;
@@ -324,7 +314,7 @@ extern "C" int tspgnn_einit_bwd_f32(const float* WC, const float* wb, const floa
     int rc = launched("tspgnn_einit_bwd_f32");
     if (rc) return rc;
     const int np = einit_np(d);
-    reduce_scaled_kernel<<<(np + 255) / 256, 256, 0, st>>>(workspace, (int)grid, np, dwb, np, 1.0f);
+    reduce_partials(workspace, (int)grid, np, dwb, np, 1.0f, 1, st);
     return launched("tspgnn_einit_bwd_f32(reduce)");
 }
 
