@@ -60,6 +60,8 @@ def main():
                          "training step (forward + backward + gradient all-reduce + L2/clip/Adam)")
     ap.add_argument("--train-steps", type=int, default=3, help="extra (untimed-by-the-driver) training steps reported "
                                                                "under 'train' when --mode forward")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
+                                                            "the captured HIP graph of the forward pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (bounded sample)")
     args = ap.parse_args()
@@ -98,7 +100,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step_fn = sess.forward_device if args.mode == "forward" else sess.train_step
+    use_graph = args.mode == "forward" and not args.no_graph
+    if use_graph:
+        replay = sess.capture_forward(dev_batch)     # hipGraph of the whole T-step forward pass
+        step_fn = lambda _b: replay()
+    else:
+        step_fn = sess.forward_device if args.mode == "forward" else sess.train_step
 
     def timed(fn, n_warm, n_steps):
         o = None
@@ -220,7 +227,7 @@ def main():
             "roofline": roofline,
             "roofline_dense": roofline_dense,
             "cpu_baseline": cpu_baseline,
-            "mode": args.mode,
+            "mode": args.mode, "hip_graph": bool(use_graph),
             "train": train,
             "kernels_us": {k: {"n": v["n"], "avg_us": round(v["avg_us"], 2)} for k, v in kernels_us.items()},
             "host_pack_s": round(t_pack, 4),

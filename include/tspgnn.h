@@ -101,6 +101,16 @@ int tspgnn_lnlstm_fwd_f32(const float* x, int dx, const float* h, const float* c
                           const float* K, const float* ln, float* h_out, float* c_out,
                           int rows, int d, void* stream);
 
+/*
+ * The same cell step with the adjacency product folded through the GEMM (fast path of the E update,
+ * graphnn.py:156-170): z = Zx[uv[e,0]] + Zx[uv[e,1]] + h Kh, where Zx = V_msg_E(V.h) Kx is formed once
+ * per VERTEX by tspgnn_linear_f32 ((EV y) Kx = EV (y Kx): the x-half of the GEMM moves from the M edge
+ * rows to the N vertex rows).  Zx:[n_src,4d]  Kh: pack_weights(kernel[dx:, :]) = [d,4d].
+ */
+int tspgnn_lnlstm_gather_fwd_f32(const int32_t* uv, const float* Zx, const float* h, const float* c,
+                                 const float* Kh, const float* ln, float* h_out, float* c_out,
+                                 int rows, int n_src, int d, void* stream);
+
 /* ------------------------------------------------------------------ pre / post loop */
 
 /*
@@ -158,6 +168,14 @@ long long tspgnn_lnlstm_bwd_workspace_floats(int d);
 int tspgnn_lnlstm_bwd_f32(const float* x, int dx, const float* h, const float* c, const float* K,
                           const float* ln, const float* dh_out, const float* dc_out, float* dz,
                           float* dc_in, float* ln_grad, float* workspace, int rows, int d, void* stream);
+
+/* Backward of tspgnn_lnlstm_gather_fwd_f32: same outputs as tspgnn_lnlstm_bwd_f32 (dz, dc_in, LN grads);
+ * the caller turns dz into dh = dz Kh^T (tspgnn_linear_f32), dZx = EV^T dz (tspgnn_csr_rowsum_f32, d=4d)
+ * and the vertex-side gradients. */
+int tspgnn_lnlstm_gather_bwd_f32(const int32_t* uv, const float* Zx, const float* h, const float* c,
+                                 const float* Kh, const float* ln, const float* dh_out, const float* dc_out,
+                                 float* dz, float* dc_in, float* ln_grad, float* workspace, int rows, int d,
+                                 void* stream);
 
 /*
  * Data gradient of tspgnn_mlp_fwd_f32: g = dY; for l = n_layers-1..0: mask by the saved activation of

@@ -221,3 +221,26 @@ def test_train_steps_follow_the_oracle(cuda_device):
         moved_ref = p[k] - params[k]
         moved = now[k].astype(np.float64) - params[k]
         assert np.abs(moved - moved_ref).max() < 2e-7 + 0.02 * np.abs(moved_ref).max(), k
+
+
+def test_captured_graph_replay_matches_eager(cuda_device):
+    t = pack_tuple("ragged_B6", 2)
+    params = P.init_params(64, seed=4, perturb=True)
+    model = tspgnn.build_network(64)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    EV, W, C, route_exists, n_vertices, n_edges = t
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: 5,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    b = sess.prepare(feed)
+    eager = sess.forward_device(b)
+    e_pred, e_h = eager["predictions"].clone(), eager["last_states"]["E"].h.clone()
+    replay = sess.capture_forward(b)
+    for _ in range(3):
+        out = replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out["predictions"], e_pred) and torch.equal(out["last_states"]["E"].h, e_h)
+    model.store.load(params)                      # bumps the variable version
+    with pytest.raises(RuntimeError, match="capture again"):
+        replay()

@@ -54,6 +54,17 @@ for rows, tag in ((M, "E"), (N, "V")):
                                  _lib.ptr(Ho), _lib.ptr(Co), rows, d, None))
     fl = rows * 2 * 2 * d * 4 * d
     res["lnlstm_" + tag] = (t, fl / t / 1e6)
+# folded E update: z = Zx[u] + Zx[v] + h Kh  (and the same GEMM without the gather, dx = 0)
+H = torch.randn(M, d, device=dev); C = torch.randn(M, d, device=dev); Ho, Co = torch.empty_like(H), torch.empty_like(C)
+Kh = pack(torch.randn(d, 4 * d, device=dev) / 8)
+Zx = torch.randn(N, 4 * d, device=dev)
+ln = torch.cat([torch.ones(d, device=dev), torch.zeros(d, device=dev)] * 5)
+t = timeit(lambda: _lib.call("tspgnn_lnlstm_gather_fwd_f32", _lib.ptr(adj.uv), _lib.ptr(Zx), _lib.ptr(H), _lib.ptr(C), _lib.ptr(Kh),
+                             _lib.ptr(ln), _lib.ptr(Ho), _lib.ptr(Co), M, N, d, None))
+res["lstm_gather_E"] = (t, M * 2 * d * 4 * d / t / 1e6)
+t = timeit(lambda: _lib.call("tspgnn_lnlstm_fwd_f32", None, 0, _lib.ptr(H), _lib.ptr(C), _lib.ptr(Kh), _lib.ptr(ln),
+                             _lib.ptr(Ho), _lib.ptr(Co), M, d, None))
+res["lstm_dx0_E"] = (t, M * 2 * d * 4 * d / t / 1e6)
 Xv = torch.randn(N, d, device=dev); Ze = torch.randn(M, d, device=dev)
 Ye = torch.empty(M, d, device=dev); Yv = torch.empty(N, d, device=dev)
 rowptr, eid, _ = adj.csr_t

@@ -12,8 +12,6 @@
 // f(s,g) = q*16 + g*4 + p.  The weights are stored in LDS with their rows permuted accordingly,
 // so activations never leave registers between layers and never cross lanes.  The same
 // fragment shape (float4 at column q*16+g*4 of a row) is used for global loads and stores.
-#include <stdlib.h>
-
 #include "common.h"
 #include "mfma_tile.h"
 
@@ -169,12 +167,19 @@ __device__ __forceinline__ void lstm_epilogue(f32x4 (&acc)[D / 4], f32x4 (&cf)[D
 // Resident variant: K ([dx+D, 4D], packed) and the five LayerNorm (gamma,beta) pairs stay in LDS
 // for the lifetime of the block; requires (dx+D)*4D*4 + 10*D*4 + 16 bytes <= 160 KiB
 // (D=64, dx=64: 130.5 KiB).  Wavefronts pull tiles through an LDS ticket counter.
+//
+// Gather-init mode (uv != NULL, dx == 0): z = Zx[uv[e,0]] + Zx[uv[e,1]] + h K_h, where
+// Zx = Y_V K_x was formed once per VERTEX ([N,4D], L2-resident).  Because the adjacency product is
+// linear, (EV Y) K_x = EV (Y K_x): the x-half of the cell's GEMM moves from the M edge rows to the
+// N = M/19.5 vertex rows, halving this kernel's MFMA work and LDS footprint and removing the
+// [M,d] aggregate from HBM altogether.
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_kernel(const float* __restrict__ x, int dx,
-                                                         const float* __restrict__ h, const float* __restrict__ c,
-                                                         const float* __restrict__ K, const float* __restrict__ ln,
-                                                         float* __restrict__ h_out, float* __restrict__ c_out,
-                                                         int rows, int tiles_total, int dbg) {
+                                                             const float* __restrict__ h, const float* __restrict__ c,
+                                                             const float* __restrict__ K, const float* __restrict__ ln,
+                                                             float* __restrict__ h_out, float* __restrict__ c_out,
+                                                             int rows, int tiles_total, const int2* __restrict__ uv,
+                                                             const float* __restrict__ Zx) {
     constexpr int NT4 = D / 4;   // output tiles of z (4D columns)
     constexpr int TPG = D / 16;  // tiles per gate
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_kernel(const float* __rest
     int* ticket = reinterpret_cast<int*>(lds_ln + 10 * D);
 
     const int tid = threadIdx.x;
-    if (!(dbg & 4)) copy_to_lds(lds_k, K, krows * 4 * D, tid, blockDim.x);
+    copy_to_lds(lds_k, K, krows * 4 * D, tid, blockDim.x);
     for (int i = tid; i < 10 * D; i += blockDim.x) lds_ln[i] = ln[i];
     const int t_beg = (int)((long long)tiles_total * blockIdx.x / gridDim.x);
     const int t_end = (int)((long long)tiles_total * (blockIdx.x + 1) / gridDim.x);
@@ -193,10 +198,6 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_kernel(const float* __rest
 
     const int lane = tid & 63, rl = lane & 15, g = lane >> 4;
     const int QX = dx >> 4, QT = QX + TPG;
-    if ((dbg & 8) && __builtin_amdgcn_readfirstlane(tid >> 6) >= 4) {
-        __builtin_amdgcn_s_sleep(127);
-        if (dbg & 16) __builtin_amdgcn_s_sleep(127);
-    }
     for (;;) {
         int tile = 0;
         if (lane == 0) tile = atomicAdd(ticket, 1);
@@ -205,22 +206,24 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_kernel(const float* __rest
         const int row = tile * 16 + rl;
         const bool valid = row < rows;
         const size_t rc = (size_t)(valid ? row : rows - 1);
+        f32x4 acc[NT4];
+        if (uv != nullptr) {
+            const int2 ends = uv[rc];
+            const float* zu = Zx + (size_t)ends.x * 4 * D + g * 4;
+            const float* zv = Zx + (size_t)ends.y * 4 * D + g * 4;
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] = ld4(zu + t * 16);
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] += ld4(zv + t * 16);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         f32x4 cf[TPG];
 #pragma unroll
         for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + rc * D + g * 4 + t * 16);
-        f32x4 acc[NT4];
-#pragma unroll
-        for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(dbg & 1)) lstm_kloop<D>(acc, lds_k, 0, 0, QT, x + rc * dx + g * 4, h + rc * D + g * 4, QX, g, rl);
-        if (!(dbg & 2)) {
-            lstm_epilogue<D>(acc, cf, lds_ln, g, valid, h_out + rc * D + g * 4, c_out + rc * D + g * 4);
-        } else if (valid) {
-#pragma unroll
-            for (int t = 0; t < TPG; ++t) {
-                st4(h_out + rc * D + g * 4 + t * 16, acc[t] + acc[t + TPG] + cf[t]);
-                st4(c_out + rc * D + g * 4 + t * 16, acc[t + 2 * TPG] + acc[t + 3 * TPG]);
-            }
-        }
+        lstm_kloop<D>(acc, lds_k, 0, 0, QT, x + rc * dx + g * 4, h + rc * D + g * 4, QX, g, rl);
+        lstm_epilogue<D>(acc, cf, lds_ln, g, valid, h_out + rc * D + g * 4, c_out + rc * D + g * 4);
     }
 }
 
@@ -285,33 +288,27 @@ static int launch_mlp(const float* X, const float* wb, float* Y, float* acts, lo
 
 template <int D>
 static int launch_lnlstm(const float* x, int dx, const float* h, const float* c, const float* K, const float* ln,
-                         float* h_out, float* c_out, int rows, hipStream_t st) {
+                         float* h_out, float* c_out, int rows, const int32_t* uv, const float* Zx, hipStream_t st) {
     const int tiles = (rows + 15) / 16;
     const size_t extra = (10 * D + 4) * sizeof(float);
     const size_t resident = (size_t)(dx + D) * 4 * D * sizeof(float) + extra;
     const size_t kLdsMax = 160 * 1024;
     if (resident <= kLdsMax) {
-        static const int dbg = getenv("TSPGNN_DBG") ? atoi(getenv("TSPGNN_DBG")) : 0;  // development only
-        static const int nw_env = getenv("TSPGNN_NW") ? atoi(getenv("TSPGNN_NW")) : 0;  // development only
-        const int per_cu = resident > 80 * 1024 ? 1 : 2;
         // Few tiles (the vertex side): one wavefront per SIMD and more, smaller workgroups, so every
-        // tile gets a matrix pipe to itself; many tiles (the edge side): two wavefronts per SIMD.
-        const int nw = nw_env ? nw_env : (tiles <= n_cus() * per_cu * 4 ? 4 : 8);
-        int grid = n_cus() * per_cu;
+        // tile gets a matrix pipe to itself; many tiles (the edge side): one workgroup per CU, two
+        // wavefronts per SIMD.
+        int grid = n_cus();
+        const int nw = tiles <= grid * 4 ? 4 : 8;
         const int max_grid = (tiles + nw - 1) / nw;
         if (grid > max_grid) grid = max_grid;
-        auto go = [&](auto kern, int threads) -> int {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident);
-            if (e != hipSuccess) return fail((int)e, "lnlstm_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            kern<<<grid, threads, resident, st>>>(x, dx, h, c, K, ln, h_out, c_out, rows, tiles, dbg);
-            return launched("tspgnn_lnlstm_fwd_f32");
-        };
-        if (nw == 4) return go(&lnlstm_fwd_kernel<D, 4>, 256);
-        if (nw == 12) return go(&lnlstm_fwd_kernel<D, 12>, 768);
-        if (nw == 16) return go(&lnlstm_fwd_kernel<D, 16>, 1024);
-        return go(&lnlstm_fwd_kernel<D, 8>, 512);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlstm_fwd_kernel<D, 8>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident);
+        if (e != hipSuccess) return fail((int)e, "lnlstm_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        lnlstm_fwd_kernel<D, 8><<<grid, nw * 64, resident, st>>>(x, dx, h, c, K, ln, h_out, c_out, rows, tiles,
+                                                                  reinterpret_cast<const int2*>(uv), Zx);
+        return launched("tspgnn_lnlstm_fwd_f32");
     }
+    if (uv != nullptr) return fail(TSPGNN_EUNSUPPORTED, "lnlstm_gather_fwd: K_h[%d,%d] does not fit LDS", D, 4 * D);
     // chunk = as many 16-row blocks of K as fit 128 KiB
     const int qc = (int)((128 * 1024) / (16 * 4 * D * sizeof(float)));
     const size_t chunked = (size_t)qc * 16 * 4 * D * sizeof(float) + extra;
@@ -371,8 +368,21 @@ extern "C" int tspgnn_lnlstm_fwd_f32(const float* x, int dx, const float* h, con
     TSPGNN_REQUIRE(h_out != h && c_out != c, "lnlstm_fwd: outputs may not alias inputs");
     hipStream_t st = as_stream(stream);
     switch (d) {
-        case 32: return launch_lnlstm<32>(x, dx, h, c, K, ln, h_out, c_out, rows, st);
-        case 64: return launch_lnlstm<64>(x, dx, h, c, K, ln, h_out, c_out, rows, st);
-        default: return launch_lnlstm<128>(x, dx, h, c, K, ln, h_out, c_out, rows, st);
+        case 32: return launch_lnlstm<32>(x, dx, h, c, K, ln, h_out, c_out, rows, nullptr, nullptr, st);
+        case 64: return launch_lnlstm<64>(x, dx, h, c, K, ln, h_out, c_out, rows, nullptr, nullptr, st);
+        default: return launch_lnlstm<128>(x, dx, h, c, K, ln, h_out, c_out, rows, nullptr, nullptr, st);
     }
+}
+
+extern "C" int tspgnn_lnlstm_gather_fwd_f32(const int32_t* uv, const float* Zx, const float* h, const float* c,
+                                            const float* Kh, const float* ln, float* h_out, float* c_out, int rows,
+                                            int n_src, int d, void* stream) {
+    TSPGNN_REQUIRE(rows >= 0 && n_src >= 0, "lnlstm_gather_fwd: rows=%d n_src=%d", rows, n_src);
+    TSPGNN_REQUIRE(d == 32 || d == 64, "lnlstm_gather_fwd: d=%d must be 32 or 64", d);
+    if (rows == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(uv && Zx && h && c && Kh && ln && h_out && c_out, "lnlstm_gather_fwd: null pointer");
+    TSPGNN_REQUIRE(h_out != h && c_out != c, "lnlstm_gather_fwd: outputs may not alias inputs");
+    hipStream_t st = as_stream(stream);
+    if (d == 32) return launch_lnlstm<32>(nullptr, 0, h, c, Kh, ln, h_out, c_out, rows, uv, Zx, st);
+    return launch_lnlstm<64>(nullptr, 0, h, c, Kh, ln, h_out, c_out, rows, uv, Zx, st);
 }

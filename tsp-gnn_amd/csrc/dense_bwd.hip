@@ -248,7 +248,8 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const float* __rest
                                                              const float* __restrict__ dc_out_in,
                                                              float* __restrict__ dz, float* __restrict__ dc_in,
                                                              float* __restrict__ ln_partial, int rows, int tiles_total,
-                                                             int qc) {
+                                                             int qc, const int2* __restrict__ uv,
+                                                             const float* __restrict__ Zx) {
     constexpr int NT4 = D / 4, TPG = D / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int QX = dx >> 4, QT = QX + TPG;
@@ -291,8 +292,18 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const float* __rest
             const bool valid = row < rows;
             const size_t rc = (size_t)(valid ? row : rows - 1);
             f32x4 acc[NT4];
+            if (uv != nullptr) {  // gather-init mode, see lnlstm_fwd_kernel
+                const int2 ends = uv[rc];
+                const float* zu = Zx + (size_t)ends.x * 4 * D + g * 4;
+                const float* zv = Zx + (size_t)ends.y * 4 * D + g * 4;
 #pragma unroll
-            for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < NT4; ++t) acc[t] = ld4(zu + t * 16);
+#pragma unroll
+                for (int t = 0; t < NT4; ++t) acc[t] += ld4(zv + t * 16);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             gemm_kloop<NT4>(acc, lds_k, 0, 0, QT, x + rc * dx + g * 4, h + rc * D + g * 4, QX, g, rl);
             finish(acc, rc, valid);
         }
@@ -573,7 +584,7 @@ static int launch_linear(const float* X, int kin, const float* Wp, float* Y1, in
 template <int D>
 static int launch_lnlstm_bwd(const float* x, int dx, const float* h, const float* c, const float* K, const float* ln,
                              const float* dh_out, const float* dc_out, float* dz, float* dc_in, float* ln_grad,
-                             float* workspace, int rows, hipStream_t st) {
+                             float* workspace, int rows, const int32_t* uv, const float* Zx, hipStream_t st) {
     // D=128 keeps 4D/16 + temporaries > 256 registers live: one wavefront per SIMD (512-register budget).
     constexpr int NWMAX = D >= 128 ? 4 : 8;
     const int tiles = (rows + 15) / 16;
@@ -584,7 +595,7 @@ static int launch_lnlstm_bwd(const float* x, int dx, const float* h, const float
     int qc = QT;
     if ((size_t)QT * per_q + extra(NWMAX) > 160 * 1024) {
         qc = (int)((160 * 1024 - extra(NWMAX)) / per_q);
-        if (qc < 1) return fail(TSPGNN_EUNSUPPORTED, "lnlstm_bwd: d=%d does not fit LDS", D);
+        if (qc < 1 || uv != nullptr) return fail(TSPGNN_EUNSUPPORTED, "lnlstm_bwd: d=%d does not fit LDS", D);
     } else if (tiles <= n_cus() * 4) {
         nw = 4;
     }
@@ -596,7 +607,8 @@ static int launch_lnlstm_bwd(const float* x, int dx, const float* h, const float
     const int max_grid = (tiles + nw - 1) / nw;
     if (grid > max_grid) grid = max_grid;
     lnlstm_bwd_kernel<D, NWMAX><<<grid, nw * 64, lds_bytes, st>>>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in,
-                                                                  workspace, rows, tiles, qc);
+                                                                  workspace, rows, tiles, qc,
+                                                                  reinterpret_cast<const int2*>(uv), Zx);
     int rc = launched("tspgnn_lnlstm_bwd_f32");
     if (rc) return rc;
     reduce_partials(workspace, grid, 10 * D, ln_grad, 10 * D, 1.0f, 1, st);
@@ -664,11 +676,32 @@ extern "C" int tspgnn_lnlstm_bwd_f32(const float* x, int dx, const float* h, con
                    "lnlstm_bwd: null pointer");
     hipStream_t st = as_stream(stream);
     switch (d) {
-        case 32: return launch_lnlstm_bwd<32>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, st);
-        case 64: return launch_lnlstm_bwd<64>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, st);
+        case 32:
+            return launch_lnlstm_bwd<32>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, nullptr,
+                                         nullptr, st);
+        case 64:
+            return launch_lnlstm_bwd<64>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, nullptr,
+                                         nullptr, st);
         default:
-            return launch_lnlstm_bwd<128>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, st);
+            return launch_lnlstm_bwd<128>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows,
+                                          nullptr, nullptr, st);
     }
+}
+
+extern "C" int tspgnn_lnlstm_gather_bwd_f32(const int32_t* uv, const float* Zx, const float* h, const float* c,
+                                            const float* Kh, const float* ln, const float* dh_out, const float* dc_out,
+                                            float* dz, float* dc_in, float* ln_grad, float* workspace, int rows, int d,
+                                            void* stream) {
+    TSPGNN_REQUIRE(rows >= 0, "lnlstm_gather_bwd: rows=%d", rows);
+    TSPGNN_REQUIRE(d == 32 || d == 64, "lnlstm_gather_bwd: d=%d must be 32 or 64", d);
+    if (rows == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(uv && Zx && h && c && Kh && ln && dz && dc_in && ln_grad && workspace,
+                   "lnlstm_gather_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (d == 32)
+        return launch_lnlstm_bwd<32>(nullptr, 0, h, c, Kh, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, uv, Zx,
+                                     st);
+    return launch_lnlstm_bwd<64>(nullptr, 0, h, c, Kh, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, uv, Zx, st);
 }
 
 extern "C" int tspgnn_mlp_bwd_f32(const float* dY, const float* wt, const float* acts, long long acts_stride,

@@ -29,6 +29,10 @@ SIGNATURES = {
     "tspgnn_mlp_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_uint, c_void_p],
     "tspgnn_lnlstm_fwd_f32": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                               c_int, c_void_p],
+    "tspgnn_lnlstm_gather_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_void_p],
+    "tspgnn_lnlstm_gather_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_einit_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_tile_rows_f32": [c_void_p, c_float, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_rowdot_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],

@@ -174,6 +174,76 @@ class LayerNormBasicLSTMCell(object):
     def ln_grad(self):
         return self.store.grad_span(self.base + "/input/gamma", self.base + "/state/beta")
 
+    # ------------------------------------------------------------------ folded adjacency product
+    # (EV y) Kx = EV (y Kx): when the cell's only input is a gather over a two-ones-per-row matrix, the
+    # x-half of the GEMM is applied on the (fewer) source rows and the cell kernel adds the two gathered
+    # rows of Zx = y Kx to h Kh (tspgnn_lnlstm_gather_fwd_f32).
+    def can_fold(self):
+        return self.d == 64 and self.dx == 64
+
+    def _packed_slice(self, key, rows_lo, rows_hi, transposed):
+        def build(out):
+            K = self.kernel()[rows_lo:rows_hi]
+            if out is None:
+                out = torch.empty_like(K)
+            kr, nc = (4 * self.d, rows_hi - rows_lo) if transposed else (rows_hi - rows_lo, 4 * self.d)
+            _lib.call("tspgnn_pack_weights_f32", _lib.ptr(K), _lib.ptr(out), kr, nc, 1 if transposed else 0,
+                      _lib.current_stream())
+            return out
+        return self.store.packed((key, self.base), build)
+
+    def kx_packed(self):
+        return self._packed_slice("lstm.kx", 0, self.dx, False)
+
+    def kh_packed(self):
+        return self._packed_slice("lstm.kh", self.dx, self.dx + self.d, False)
+
+    def kx_t_packed(self):
+        return self._packed_slice("lstm.kxT", 0, self.dx, True)
+
+    def kh_t_packed(self):
+        return self._packed_slice("lstm.khT", self.dx, self.dx + self.d, True)
+
+    def premultiply(self, y, out=None):
+        """Zx = y Kx  ([n_src, 4d])."""
+        if out is None:
+            out = torch.empty((y.shape[0], 4 * self.d), dtype=torch.float32, device=y.device)
+        _lib.call("tspgnn_linear_f32", _lib.ptr(y), self.dx, _lib.ptr(self.kx_packed()), None, 0, _lib.ptr(out),
+                  4 * self.d, 0, y.shape[0], _lib.current_stream())
+        return out
+
+    def gather_call(self, adj, zx, state, out=None):
+        c, h = state.c, state.h
+        rows = h.shape[0]
+        h_out, c_out = out if out is not None else (torch.empty_like(h), torch.empty_like(c))
+        _lib.call("tspgnn_lnlstm_gather_fwd_f32", _lib.ptr(adj.uv), _lib.ptr(zx), _lib.ptr(h), _lib.ptr(c),
+                  _lib.ptr(self.kh_packed()), _lib.ptr(self.ln()), _lib.ptr(h_out), _lib.ptr(c_out), rows, zx.shape[0],
+                  self.d, _lib.current_stream())
+        return h_out, LSTMStateTuple(c=c_out, h=h_out)
+
+    def gather_backward(self, adj, zx, h, c, dh_out, dc_out, dz, dc_in, dh_in, dzx, dy, ws):
+        """Backward of gather_call + premultiply: dz, dc_in, dh_in = dz Kh^T, dzx = EV^T dz, dy = dzx Kx^T."""
+        rows, st = h.shape[0], _lib.current_stream()
+        _lib.call("tspgnn_lnlstm_gather_bwd_f32", _lib.ptr(adj.uv), _lib.ptr(zx), _lib.ptr(h), _lib.ptr(c),
+                  _lib.ptr(self.kh_packed()), _lib.ptr(self.ln()), _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz),
+                  _lib.ptr(dc_in), _lib.ptr(self.ln_grad()), _lib.ptr(ws), rows, self.d, st)
+        _lib.call("tspgnn_linear_f32", _lib.ptr(dz), 4 * self.d, _lib.ptr(self.kh_t_packed()), None, 0, _lib.ptr(dh_in),
+                  self.d, 0, rows, st)
+        adj.matmul(dz, transpose=True, out=dzx)
+        _lib.call("tspgnn_linear_f32", _lib.ptr(dzx), 4 * self.d, _lib.ptr(self.kx_t_packed()), None, 0, _lib.ptr(dy),
+                  self.dx, 0, dzx.shape[0], st)
+
+    def backward_weights_folded(self, y_all, dzx_all, rows_src, h_all, dz_all, rows):
+        """dKx += y^T dZx over T*n_src rows (instead of T*M), dKh += h^T dz over T*M rows."""
+        gK = self.store.grad_view(self.base + "/kernel")
+        st = _lib.current_stream()
+        ws = _lib.workspace("tspgnn_wgrad_workspace_floats", rows_src, self.dx, 4 * self.d, device=dz_all.device)
+        _lib.call("tspgnn_wgrad_f32", _lib.ptr(y_all), _lib.ptr(dzx_all), rows_src, self.dx, 4 * self.d,
+                  _lib.ptr(gK[:self.dx]), None, _lib.ptr(ws), st)
+        ws = _lib.workspace("tspgnn_wgrad_workspace_floats", rows, self.d, 4 * self.d, device=dz_all.device)
+        _lib.call("tspgnn_wgrad_f32", _lib.ptr(h_all), _lib.ptr(dz_all), rows, self.d, 4 * self.d,
+                  _lib.ptr(gK[self.dx:]), None, _lib.ptr(ws), st)
+
     def backward(self, x, h, c, dh_out, dc_out, dz, dc_in, dx_out, dh_in, ws):
         """One step: (dh_out, dc_out) -> dz (kept for the weight gradient), dc_in, dx_out, dh_in; the
         LayerNorm parameter gradients are accumulated into the store's gradient buffer."""
@@ -219,6 +289,7 @@ class GraphNN(object):
             raise NotImplementedError("GraphNN: the HIP path computes in fp32")
         self.float_dtype = float_dtype
         self.store = store if store is not None else V.get_default_store()
+        self.fold_adjacency = True   # (EV y) Kx = EV (y Kx) fast path; False = op-for-op reference order
         self.check_model()
         self._init_parameters()
 
@@ -309,6 +380,18 @@ class GraphNN(object):
                 raise ValueError("Matrix {m} doesn't have the same number of nodes as the initial embeddings of "
                                  "its variable {v}".format(v=v2, m=mat))
 
+    def _folded(self, v, mats):
+        """The loop entry of v if its cell input is a single gather over a two-ones-per-row matrix
+        (then the adjacency product is folded through the cell's GEMM), else None."""
+        if not self.fold_adjacency or len(self.loop[v]) != 1:
+            return None
+        u = self.loop[v][0]
+        if "var" not in u or "fun" in u or "mat" not in u or u.get("transpose?", False):
+            return None
+        if mats[u["mat"]].uv is None or not self._RNN_cells[v].can_fold():
+            return None
+        return u
+
     # ---------------------------------------------------------------- forward
     def __call__(self, adjacency_matrices, initial_embeddings, time_steps, LSTM_initial_states={}):
         """-> {var: LSTMStateTuple(c, h)} after ``time_steps`` synchronous steps
@@ -336,9 +419,18 @@ class GraphNN(object):
             c0 = torch.zeros_like(h0) if v not in LSTM_initial_states \
                 else LSTM_initial_states[v].to(torch.float32).contiguous()
             states[v] = LSTMStateTuple(c=c0, h=h0)
+        folded = {v: self._folded(v, mats) for v in self.var}
         for _ in range(int(time_steps)):
             new_states = {}
             for v in self.var:
+                if folded[v] is not None:
+                    u = folded[v]
+                    y = states[u["var"]].h
+                    if "msg" in u:
+                        y = self._msg_MLPs[u["msg"]](y)
+                    cell = self._RNN_cells[v]
+                    _, new_states[v] = cell.gather_call(mats[u["mat"]], cell.premultiply(y), states[v])
+                    continue
                 inputs = []
                 for update in self.loop[v]:
                     if "var" in update:

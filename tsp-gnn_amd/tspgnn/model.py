@@ -228,6 +228,33 @@ class Session(object):
                   b.B, st)
         return {"last_states": last, "E_vote": vote, "logits": logits, "predictions": pred, "stats": stats}
 
+    def capture_forward(self, batch):
+        """Captures one forward pass over a resident batch into a HIP graph (hipStreamBeginCapture via
+        torch.cuda.CUDAGraph: every libtspgnn launch goes to torch's current stream, so the capture sees
+        all of them) and returns ``replay() -> outputs``.  The T-step loop is ~200 launches of 5-90 us
+        kernels; replaying the graph removes the per-launch host cost.  The captured graph reads the
+        packed weights that were current at capture time: re-capture after the variables change."""
+        b = batch if isinstance(batch, DeviceBatch) else self.prepare(batch)
+        self.forward_device(b)          # warm-up: builds packed-weight caches outside the capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.forward_device(b)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(graph):
+            out = self.forward_device(b)
+        version = self.store.version
+
+        def replay():
+            if self.store.version != version:
+                raise RuntimeError("variables changed since capture_forward(): capture again")
+            graph.replay()
+            return out
+        replay.graph = graph
+        return replay
+
     # ------------------------------------------------------------------ run
     def run(self, fetches, feed_dict=None):
         single = not isinstance(fetches, (list, tuple))
