@@ -468,10 +468,18 @@ class GraphNN(object):
                     mats[u["mat"]] = DeviceAdjacency.wrap(adjacency_matrices[u["mat"]], device)
         tape = type("Tape", (), {})()
         tape.T, tape.mats = T, mats
+        tape.folded = {v: self._folded(v, mats) for v in self.var}
         n = {v: initial_embeddings[v].shape[0] for v in self.var}
         tape.H = {v: torch.empty((T + 1, n[v], d), **f32) for v, d in self.var.items()}
         tape.C = {v: torch.empty((T + 1, n[v], d), **f32) for v, d in self.var.items()}
-        tape.X = {v: torch.empty((T, n[v], self._RNN_cells[v].dx), **f32) for v in self.var}
+        # cell inputs; for a folded cell: the message y per SOURCE row and Zx = y Kx instead of the aggregate
+        tape.X, tape.ZX = {}, {}
+        for v in self.var:
+            u = tape.folded[v]
+            rows_x = n[v] if u is None else n[u["var"]]
+            tape.X[v] = torch.empty((T, rows_x, self._RNN_cells[v].dx), **f32)
+            if u is not None:
+                tape.ZX[v] = torch.empty((T, rows_x, 4 * self.var[v]), **f32)
         tape.acts = {}
         for v in self.var:
             tape.H[v][0].copy_(initial_embeddings[v])
@@ -483,6 +491,20 @@ class GraphNN(object):
                     tape.acts[(v, i)] = torch.empty((max(mlp.n_square - 1, 1), T, n[src], self.var[src]), **f32)
         for t in range(T):
             for v in self.var:
+                if tape.folded[v] is not None:
+                    u, cell = tape.folded[v], self._RNN_cells[v]
+                    src = u["var"]
+                    y = tape.H[src][t]
+                    if "msg" in u:
+                        acts = tape.acts[(v, 0)]
+                        y = self._msg_MLPs[u["msg"]].forward_saving(y, tape.X[v][t], acts[:, t], acts.stride(0))
+                    else:
+                        tape.X[v][t].copy_(y)
+                        y = tape.X[v][t]
+                    cell.premultiply(y, out=tape.ZX[v][t])
+                    cell.gather_call(mats[u["mat"]], tape.ZX[v][t], LSTMStateTuple(c=tape.C[v][t], h=tape.H[v][t]),
+                                     out=(tape.H[v][t + 1], tape.C[v][t + 1]))
+                    continue
                 single = len(self.loop[v]) == 1
                 inputs = []
                 for i, u in enumerate(self.loop[v]):
@@ -523,15 +545,22 @@ class GraphNN(object):
             mlp = self._msg_MLPs[u["msg"]]
             DPRE[(v, i)] = torch.empty((mlp.n_square, T, n[u["var"]], self.var[u["var"]]), **f32)
         ws = {v: _lib.workspace("tspgnn_lnlstm_bwd_workspace_floats", d, device=device) for v, d in self.var.items()}
+        folded = tape.folded
+        DZX = {v: torch.empty_like(tape.ZX[v]) for v in self.var if folded[v] is not None}
         dH = {v: (dstates.get(v, (None, None))[0]) for v in self.var}
         dC = {v: (dstates.get(v, (None, None))[1]) for v in self.var}
         for t in range(T - 1, -1, -1):
             ndH = {v: torch.empty((n[v], d), **f32) for v, d in self.var.items()}
             ndC = {v: torch.empty((n[v], d), **f32) for v, d in self.var.items()}
-            dX = {v: torch.empty((n[v], self._RNN_cells[v].dx), **f32) for v in self.var}
+            dX = {v: torch.empty((tape.X[v].shape[1], self._RNN_cells[v].dx), **f32) for v in self.var}
             for v in self.var:   # all cells first: they WRITE dh; the message paths below ACCUMULATE into it
-                self._RNN_cells[v].backward(tape.X[v][t], tape.H[v][t], tape.C[v][t], dH[v], dC[v], DZ[v][t], ndC[v],
-                                            dX[v], ndH[v], ws[v])
+                cell = self._RNN_cells[v]
+                if folded[v] is not None:   # dX[v] is already the gradient w.r.t. the message y (source rows)
+                    cell.gather_backward(mats[folded[v]["mat"]], tape.ZX[v][t], tape.H[v][t], tape.C[v][t], dH[v], dC[v],
+                                         DZ[v][t], ndC[v], ndH[v], DZX[v][t], dX[v], ws[v])
+                else:
+                    cell.backward(tape.X[v][t], tape.H[v][t], tape.C[v][t], dH[v], dC[v], DZ[v][t], ndC[v], dX[v],
+                                  ndH[v], ws[v])
             for v in self.var:
                 off = 0
                 for i, u in enumerate(self.loop[v]):
@@ -539,7 +568,7 @@ class GraphNN(object):
                     dy = dX[v] if len(self.loop[v]) == 1 else dX[v][:, off:off + w].contiguous()
                     off += w
                     src = u["var"]
-                    if "mat" in u:   # adjoint of mat (x) y is mat^T (x) dy and vice versa
+                    if "mat" in u and folded[v] is None:   # adjoint of mat (x) y is mat^T (x) dy and vice versa
                         dy = mats[u["mat"]].matmul(dy, transpose=not u.get("transpose?", False))
                     if "msg" in u:
                         mlp = self._msg_MLPs[u["msg"]]
@@ -552,8 +581,13 @@ class GraphNN(object):
         # weight gradients: one reduction per variable over all T steps
         for v, d in self.var.items():
             cell = self._RNN_cells[v]
-            cell.backward_weights(tape.X[v].view(-1, cell.dx), tape.H[v][:T].reshape(-1, d), DZ[v].view(-1, 4 * d),
-                                  T * n[v])
+            if folded[v] is not None:
+                rows_src = T * tape.X[v].shape[1]
+                cell.backward_weights_folded(tape.X[v].view(-1, cell.dx), DZX[v].view(-1, 4 * d), rows_src,
+                                             tape.H[v][:T].reshape(-1, d), DZ[v].view(-1, 4 * d), T * n[v])
+            else:
+                cell.backward_weights(tape.X[v].view(-1, cell.dx), tape.H[v][:T].reshape(-1, d), DZ[v].view(-1, 4 * d),
+                                      T * n[v])
         for (v, i), dpre in DPRE.items():
             u = self.loop[v][i]
             mlp = self._msg_MLPs[u["msg"]]
