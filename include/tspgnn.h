@@ -111,6 +111,28 @@ int tspgnn_lnlstm_gather_fwd_f32(const int32_t* uv, const float* Zx, const float
                                  const float* Kh, const float* ln, float* h_out, float* c_out,
                                  int rows, int n_src, int d, void* stream);
 
+/*
+ * Several independent tasks in ONE launch (<= 4): the workgroups are divided among the tasks in
+ * proportion to their work and each stages its own task's weights.  One message-passing step runs the
+ * edge-side and vertex-side MLPs as one launch and the two cells as another, so the small vertex-side
+ * problems do not pay their own launch, weight staging and tail (graphnn.py:144-171 iterates the
+ * variables; the updates of one step are mutually independent because they all read the OLD states).
+ * The task arrays live in HOST memory; all pointers inside are device pointers.
+ */
+typedef struct tspgnn_mlp_task {
+    const float* X; const float* wb; float* Y; float* acts; long long acts_stride;
+    int rows; int n_layers; unsigned relu_mask;
+} tspgnn_mlp_task;   /* fields as the arguments of tspgnn_mlp_fwd_f32 */
+
+typedef struct tspgnn_lstm_task {
+    const float* x; int dx; const float* h; const float* c; const float* K; const float* ln;
+    float* h_out; float* c_out; int rows;
+    const int32_t* uv; const float* Zx;   /* gather-init mode when uv != NULL: dx == 0, K = Kh */
+} tspgnn_lstm_task;  /* fields as the arguments of tspgnn_lnlstm_fwd_f32 / tspgnn_lnlstm_gather_fwd_f32 */
+
+int tspgnn_mlp_fwd_multi_f32(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream);
+int tspgnn_lnlstm_fwd_multi_f32(const tspgnn_lstm_task* tasks, int n_tasks, int d, void* stream);
+
 /* ------------------------------------------------------------------ pre / post loop */
 
 /*

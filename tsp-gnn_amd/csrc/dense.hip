@@ -53,16 +53,38 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // Persistent workgroups: all layer weights (permuted) + biases live in LDS for the lifetime of
 // the block; each wavefront pulls 16-row tiles from the block's contiguous tile range through
 // an LDS ticket counter (keeps the four SIMDs of a CU evenly loaded at the tail).
+// One launch may carry several independent tasks (e.g. the edge-side and the vertex-side message MLP
+// of one time step): the workgroups are split among the tasks in proportion to their tiles, and each
+// workgroup stages the weights of its own task.  The small vertex-side problem then rides along with
+// the large edge-side one instead of paying its own launch, staging and tail.
+constexpr int kMaxTasks = 4;
+
+struct MlpTaskTable {
+    tspgnn_mlp_task task[kMaxTasks];
+    int blk_end[kMaxTasks];  // exclusive prefix: task k owns workgroups [blk_end[k-1], blk_end[k])
+    int n;
+};
+
 template <int D, int MAXL>
-__global__ __launch_bounds__(512) void mlp_fwd_kernel(const float* __restrict__ X, const float* __restrict__ wb,
-                                                      float* __restrict__ Y, float* __restrict__ acts,
-                                                      long long acts_stride, int rows, int n_layers,
-                                                      unsigned relu_mask, int tiles_total) {
+__global__ __launch_bounds__(512) void mlp_fwd_kernel(const MlpTaskTable tt) {
     constexpr int NT = D / 16;
     __shared__ __attribute__((aligned(16))) float lds[MAXL * (D * D + D) + 4];
     float* lds_w = lds;
     float* lds_b = lds + MAXL * D * D;
     int* ticket = reinterpret_cast<int*>(lds + MAXL * (D * D + D));
+
+    int k = 0;
+    while (k + 1 < tt.n && (int)blockIdx.x >= tt.blk_end[k]) ++k;
+    const int blk0 = k ? tt.blk_end[k - 1] : 0;
+    const int my_blk = blockIdx.x - blk0, my_grid = tt.blk_end[k] - blk0;
+    const float* __restrict__ X = tt.task[k].X;
+    const float* __restrict__ wb = tt.task[k].wb;
+    float* __restrict__ Y = tt.task[k].Y;
+    float* __restrict__ acts = tt.task[k].acts;
+    const long long acts_stride = tt.task[k].acts_stride;
+    const int rows = tt.task[k].rows, n_layers = tt.task[k].n_layers;
+    const unsigned relu_mask = tt.task[k].relu_mask;
+    const int tiles_total = (rows + 15) / 16;
 
     const int tid = threadIdx.x;
     for (int l = 0; l < n_layers; ++l) {
@@ -70,8 +92,8 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(const float* __restrict__ 
         copy_to_lds(lds_w + l * D * D, Wl, D * D, tid, blockDim.x);
         for (int i = tid; i < D; i += blockDim.x) lds_b[l * D + i] = Wl[D * D + i];
     }
-    const int t_beg = (int)((long long)tiles_total * blockIdx.x / gridDim.x);
-    const int t_end = (int)((long long)tiles_total * (blockIdx.x + 1) / gridDim.x);
+    const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
+    const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
     if (tid == 0) *ticket = t_beg;
     __syncthreads();
 
@@ -173,16 +195,34 @@ __device__ __forceinline__ void lstm_epilogue(f32x4 (&acc)[D / 4], f32x4 (&cf)[D
 // linear, (EV Y) K_x = EV (Y K_x): the x-half of the cell's GEMM moves from the M edge rows to the
 // N = M/19.5 vertex rows, halving this kernel's MFMA work and LDS footprint and removing the
 // [M,d] aggregate from HBM altogether.
+struct LstmTaskTable {
+    tspgnn_lstm_task task[kMaxTasks];
+    int blk_end[kMaxTasks];
+    int n;
+};
+
 template <int D, int NW>
-__global__ __launch_bounds__(NW * 64) void lnlstm_fwd_kernel(const float* __restrict__ x, int dx,
-                                                             const float* __restrict__ h, const float* __restrict__ c,
-                                                             const float* __restrict__ K, const float* __restrict__ ln,
-                                                             float* __restrict__ h_out, float* __restrict__ c_out,
-                                                             int rows, int tiles_total, const int2* __restrict__ uv,
-                                                             const float* __restrict__ Zx) {
+__global__ __launch_bounds__(NW * 64) void lnlstm_fwd_kernel(const LstmTaskTable tt) {
     constexpr int NT4 = D / 4;   // output tiles of z (4D columns)
     constexpr int TPG = D / 16;  // tiles per gate
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    int k = 0;
+    while (k + 1 < tt.n && (int)blockIdx.x >= tt.blk_end[k]) ++k;
+    const int blk0 = k ? tt.blk_end[k - 1] : 0;
+    const int my_blk = blockIdx.x - blk0, my_grid = tt.blk_end[k] - blk0;
+    const float* __restrict__ x = tt.task[k].x;
+    const int dx = tt.task[k].dx;
+    const float* __restrict__ h = tt.task[k].h;
+    const float* __restrict__ c = tt.task[k].c;
+    const float* __restrict__ K = tt.task[k].K;
+    const float* __restrict__ ln = tt.task[k].ln;
+    float* __restrict__ h_out = tt.task[k].h_out;
+    float* __restrict__ c_out = tt.task[k].c_out;
+    const int rows = tt.task[k].rows;
+    const int2* __restrict__ uv = reinterpret_cast<const int2*>(tt.task[k].uv);
+    const float* __restrict__ Zx = tt.task[k].Zx;
+    const int tiles_total = (rows + 15) / 16;
+
     const int krows = dx + D;
     float* lds_k = lds;
     float* lds_ln = lds + (size_t)krows * 4 * D;
@@ -191,8 +231,8 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_kernel(const float* __rest
     const int tid = threadIdx.x;
     copy_to_lds(lds_k, K, krows * 4 * D, tid, blockDim.x);
     for (int i = tid; i < 10 * D; i += blockDim.x) lds_ln[i] = ln[i];
-    const int t_beg = (int)((long long)tiles_total * blockIdx.x / gridDim.x);
-    const int t_end = (int)((long long)tiles_total * (blockIdx.x + 1) / gridDim.x);
+    const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
+    const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
     if (tid == 0) *ticket = t_beg;
     __syncthreads();
 
@@ -271,44 +311,50 @@ __global__ __launch_bounds__(512) void lnlstm_fwd_chunked_kernel(const float* __
     }
 }
 
+// Workgroups per task, proportional to cost[k] (at least one each); grid = sum.
+static int split_blocks(const long long* cost, int n, int grid, int* blk_end) {
+    long long total = 0;
+    for (int k = 0; k < n; ++k) total += cost[k] > 0 ? cost[k] : 1;
+    if (grid < n) grid = n;
+    int used = 0;
+    for (int k = 0; k < n; ++k) {
+        const long long ck = cost[k] > 0 ? cost[k] : 1;
+        int bk = (int)((ck * grid + total / 2) / total);
+        if (bk < 1) bk = 1;
+        used += bk;
+        blk_end[k] = used;
+    }
+    return used;
+}
+
 template <int D, int MAXL>
-static int launch_mlp(const float* X, const float* wb, float* Y, float* acts, long long acts_stride, int rows,
-                      int n_layers, unsigned relu_mask, hipStream_t st) {
-    const int tiles = (rows + 15) / 16;
+static int launch_mlp(const tspgnn_mlp_task* tasks, int n, hipStream_t st) {
+    MlpTaskTable tt;
+    long long cost[kMaxTasks];
+    long long tiles_all = 0;
+    for (int k = 0; k < n; ++k) {
+        tt.task[k] = tasks[k];
+        if (tt.task[k].acts && tt.task[k].acts_stride == 0) tt.task[k].acts_stride = (long long)tasks[k].rows * D;
+        cost[k] = ((long long)tasks[k].rows + 15) / 16 * tasks[k].n_layers;
+        tiles_all += ((long long)tasks[k].rows + 15) / 16;
+    }
+    tt.n = n;
     // LDS per block decides residency: D=64 -> 65 KiB -> 2 blocks (16 waves) per CU.
     const int lds_bytes = MAXL * (D * D + D) * 4 + 16;
     const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
     int grid = n_cus() * per_cu;
-    const int nw = tiles <= grid * 4 ? 4 : 8;  // few tiles: one wavefront per SIMD, more workgroups
-    const int max_grid = (tiles + nw - 1) / nw;  // at least one tile per wave
-    if (grid > max_grid) grid = max_grid;
-    mlp_fwd_kernel<D, MAXL><<<grid, nw * 64, 0, st>>>(X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask, tiles);
+    const int nw = tiles_all <= (long long)grid * 4 ? 4 : 8;  // few tiles: one wavefront per SIMD, more workgroups
+    const long long max_grid = (tiles_all + nw - 1) / nw;     // at least one tile per wave
+    if (grid > max_grid) grid = (int)max_grid;
+    grid = split_blocks(cost, n, grid, tt.blk_end);
+    mlp_fwd_kernel<D, MAXL><<<grid, nw * 64, 0, st>>>(tt);
     return launched("tspgnn_mlp_fwd_f32");
 }
 
 template <int D>
-static int launch_lnlstm(const float* x, int dx, const float* h, const float* c, const float* K, const float* ln,
-                         float* h_out, float* c_out, int rows, const int32_t* uv, const float* Zx, hipStream_t st) {
-    const int tiles = (rows + 15) / 16;
+static int launch_lnlstm_chunked(const tspgnn_lstm_task& t, hipStream_t st) {
+    const int tiles = (t.rows + 15) / 16;
     const size_t extra = (10 * D + 4) * sizeof(float);
-    const size_t resident = (size_t)(dx + D) * 4 * D * sizeof(float) + extra;
-    const size_t kLdsMax = 160 * 1024;
-    if (resident <= kLdsMax) {
-        // Few tiles (the vertex side): one wavefront per SIMD and more, smaller workgroups, so every
-        // tile gets a matrix pipe to itself; many tiles (the edge side): one workgroup per CU, two
-        // wavefronts per SIMD.
-        int grid = n_cus();
-        const int nw = tiles <= grid * 4 ? 4 : 8;
-        const int max_grid = (tiles + nw - 1) / nw;
-        if (grid > max_grid) grid = max_grid;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlstm_fwd_kernel<D, 8>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident);
-        if (e != hipSuccess) return fail((int)e, "lnlstm_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        lnlstm_fwd_kernel<D, 8><<<grid, nw * 64, resident, st>>>(x, dx, h, c, K, ln, h_out, c_out, rows, tiles,
-                                                                  reinterpret_cast<const int2*>(uv), Zx);
-        return launched("tspgnn_lnlstm_fwd_f32");
-    }
-    if (uv != nullptr) return fail(TSPGNN_EUNSUPPORTED, "lnlstm_gather_fwd: K_h[%d,%d] does not fit LDS", D, 4 * D);
     // chunk = as many 16-row blocks of K as fit 128 KiB
     const int qc = (int)((128 * 1024) / (16 * 4 * D * sizeof(float)));
     const size_t chunked = (size_t)qc * 16 * 4 * D * sizeof(float) + extra;
@@ -318,8 +364,71 @@ static int launch_lnlstm(const float* x, int dx, const float* h, const float* c,
     int grid = n_cus();
     const int rounds = (tiles + 7) / 8;
     if (grid > rounds) grid = rounds;
-    lnlstm_fwd_chunked_kernel<D><<<grid, 512, chunked, st>>>(x, dx, h, c, K, ln, h_out, c_out, rows, tiles, qc);
+    lnlstm_fwd_chunked_kernel<D><<<grid, 512, chunked, st>>>(t.x, t.dx, t.h, t.c, t.K, t.ln, t.h_out, t.c_out, t.rows,
+                                                             tiles, qc);
     return launched("tspgnn_lnlstm_fwd_f32");
+}
+
+template <int D>
+static int launch_lnlstm(const tspgnn_lstm_task* tasks, int n, hipStream_t st) {
+    const size_t extra = (10 * D + 4) * sizeof(float);
+    const size_t kLdsMax = 160 * 1024;
+    size_t resident = 0;
+    bool all_fit = true;
+    for (int k = 0; k < n; ++k) {
+        const size_t r = (size_t)(tasks[k].dx + D) * 4 * D * sizeof(float) + extra;
+        if (r > kLdsMax) all_fit = false;
+        if (r > resident) resident = r;
+    }
+    if (!all_fit) {  // a K that does not fit LDS: one chunked launch per task
+        for (int k = 0; k < n; ++k) {
+            if (tasks[k].uv) return fail(TSPGNN_EUNSUPPORTED, "lnlstm_gather_fwd: K_h[%d,%d] does not fit LDS", D, 4 * D);
+            const int rc = launch_lnlstm_chunked<D>(tasks[k], st);
+            if (rc) return rc;
+        }
+        return TSPGNN_OK;
+    }
+    LstmTaskTable tt;
+    long long cost[kMaxTasks];
+    long long tiles_all = 0;
+    for (int k = 0; k < n; ++k) {
+        tt.task[k] = tasks[k];
+        const long long tiles = ((long long)tasks[k].rows + 15) / 16;
+        cost[k] = tiles * ((tasks[k].dx + D) / 16 + 3);  // k-blocks + ~3 blocks' worth of epilogue
+        tiles_all += tiles;
+    }
+    tt.n = n;
+    // Few tiles (a lone vertex-side task): one wavefront per SIMD and more, smaller workgroups, so every
+    // tile gets a matrix pipe to itself; many tiles: one workgroup per CU, two wavefronts per SIMD.
+    int grid = n_cus();
+    const int nw = tiles_all <= (long long)grid * 4 ? 4 : 8;
+    const long long max_grid = (tiles_all + nw - 1) / nw;
+    if (grid > max_grid) grid = (int)max_grid;
+    grid = split_blocks(cost, n, grid, tt.blk_end);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlstm_fwd_kernel<D, 8>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident);
+    if (e != hipSuccess) return fail((int)e, "lnlstm_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    lnlstm_fwd_kernel<D, 8><<<grid, nw * 64, resident, st>>>(tt);
+    return launched("tspgnn_lnlstm_fwd_f32");
+}
+
+static int check_mlp_task(const tspgnn_mlp_task& t, int d) {
+    TSPGNN_REQUIRE(t.rows >= 0, "mlp_fwd: rows=%d", t.rows);
+    TSPGNN_REQUIRE(t.n_layers >= 1 && t.n_layers <= 4, "mlp_fwd: n_layers=%d must be in 1..4", t.n_layers);
+    TSPGNN_REQUIRE(d != 128 || t.n_layers <= 2, "mlp_fwd: d=128 holds at most 2 layers in LDS (got %d)", t.n_layers);
+    TSPGNN_REQUIRE(t.rows == 0 || (t.X && t.wb && t.Y), "mlp_fwd: null pointer");
+    return TSPGNN_OK;
+}
+
+static int check_lstm_task(const tspgnn_lstm_task& t, int d) {
+    TSPGNN_REQUIRE(t.rows >= 0, "lnlstm_fwd: rows=%d", t.rows);
+    TSPGNN_REQUIRE(t.dx >= 0 && t.dx % 16 == 0, "lnlstm_fwd: dx=%d must be a non-negative multiple of 16", t.dx);
+    TSPGNN_REQUIRE(t.rows == 0 || (t.h && t.c && t.K && t.ln && t.h_out && t.c_out && (t.dx == 0 || t.x)),
+                   "lnlstm_fwd: null pointer");
+    TSPGNN_REQUIRE(t.h_out != t.h && t.c_out != t.c, "lnlstm_fwd: outputs may not alias inputs");
+    TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx && (d == 32 || d == 64)),
+                   "lnlstm_fwd: gather-init mode needs dx == 0, Zx and d in {32,64}");
+    return TSPGNN_OK;
 }
 
 }  // namespace tspgnn
@@ -339,50 +448,63 @@ extern "C" int tspgnn_pack_weights_f32(const float* W, float* P, int krows, int 
     return launched("tspgnn_pack_weights_f32");
 }
 
-extern "C" int tspgnn_mlp_fwd_f32(const float* X, const float* wb, float* Y, float* acts, long long acts_stride,
-                                  int rows, int d, int n_layers, unsigned relu_mask, void* stream) {
-    TSPGNN_REQUIRE(rows >= 0, "mlp_fwd: rows=%d", rows);
-    TSPGNN_REQUIRE(n_layers >= 1 && n_layers <= 4, "mlp_fwd: n_layers=%d must be in 1..4", n_layers);
+extern "C" int tspgnn_mlp_fwd_multi_f32(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream) {
+    TSPGNN_REQUIRE(tasks && n_tasks >= 1 && n_tasks <= kMaxTasks, "mlp_fwd_multi: 1..%d tasks", kMaxTasks);
     TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "mlp_fwd: d=%d must be 32, 64 or 128", d);
-    if (rows == 0) return TSPGNN_OK;
-    TSPGNN_REQUIRE(X && wb && Y, "mlp_fwd: null pointer");
-    if (acts && acts_stride == 0) acts_stride = (long long)rows * d;
+    tspgnn_mlp_task live[kMaxTasks];
+    int n = 0;
+    for (int k = 0; k < n_tasks; ++k) {
+        const int rc = check_mlp_task(tasks[k], d);
+        if (rc) return rc;
+        if (tasks[k].rows > 0) live[n++] = tasks[k];
+    }
+    if (n == 0) return TSPGNN_OK;
     hipStream_t st = as_stream(stream);
     switch (d) {
-        case 32: return launch_mlp<32, 4>(X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask, st);
-        case 64: return launch_mlp<64, 4>(X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask, st);
-        default:
-            if (n_layers > 2)
-                return fail(TSPGNN_EUNSUPPORTED, "mlp_fwd: d=128 holds at most 2 layers in LDS (got %d)", n_layers);
-            return launch_mlp<128, 2>(X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask, st);
+        case 32: return launch_mlp<32, 4>(live, n, st);
+        case 64: return launch_mlp<64, 4>(live, n, st);
+        default: return launch_mlp<128, 2>(live, n, st);
+    }
+}
+
+extern "C" int tspgnn_mlp_fwd_f32(const float* X, const float* wb, float* Y, float* acts, long long acts_stride,
+                                  int rows, int d, int n_layers, unsigned relu_mask, void* stream) {
+    if (d == 128 && n_layers > 2 && n_layers <= 4)
+        return fail(TSPGNN_EUNSUPPORTED, "mlp_fwd: d=128 holds at most 2 layers in LDS (got %d)", n_layers);
+    const tspgnn_mlp_task t = {X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask};
+    return tspgnn_mlp_fwd_multi_f32(&t, 1, d, stream);
+}
+
+extern "C" int tspgnn_lnlstm_fwd_multi_f32(const tspgnn_lstm_task* tasks, int n_tasks, int d, void* stream) {
+    TSPGNN_REQUIRE(tasks && n_tasks >= 1 && n_tasks <= kMaxTasks, "lnlstm_fwd_multi: 1..%d tasks", kMaxTasks);
+    TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "lnlstm_fwd: d=%d must be 32, 64 or 128", d);
+    tspgnn_lstm_task live[kMaxTasks];
+    int n = 0;
+    for (int k = 0; k < n_tasks; ++k) {
+        const int rc = check_lstm_task(tasks[k], d);
+        if (rc) return rc;
+        if (tasks[k].rows > 0) live[n++] = tasks[k];
+    }
+    if (n == 0) return TSPGNN_OK;
+    hipStream_t st = as_stream(stream);
+    switch (d) {
+        case 32: return launch_lnlstm<32>(live, n, st);
+        case 64: return launch_lnlstm<64>(live, n, st);
+        default: return launch_lnlstm<128>(live, n, st);
     }
 }
 
 extern "C" int tspgnn_lnlstm_fwd_f32(const float* x, int dx, const float* h, const float* c, const float* K,
                                      const float* ln, float* h_out, float* c_out, int rows, int d, void* stream) {
-    TSPGNN_REQUIRE(rows >= 0, "lnlstm_fwd: rows=%d", rows);
-    TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "lnlstm_fwd: d=%d must be 32, 64 or 128", d);
-    TSPGNN_REQUIRE(dx >= 0 && dx % 16 == 0, "lnlstm_fwd: dx=%d must be a non-negative multiple of 16", dx);
-    if (rows == 0) return TSPGNN_OK;
-    TSPGNN_REQUIRE(h && c && K && ln && h_out && c_out && (dx == 0 || x), "lnlstm_fwd: null pointer");
-    TSPGNN_REQUIRE(h_out != h && c_out != c, "lnlstm_fwd: outputs may not alias inputs");
-    hipStream_t st = as_stream(stream);
-    switch (d) {
-        case 32: return launch_lnlstm<32>(x, dx, h, c, K, ln, h_out, c_out, rows, nullptr, nullptr, st);
-        case 64: return launch_lnlstm<64>(x, dx, h, c, K, ln, h_out, c_out, rows, nullptr, nullptr, st);
-        default: return launch_lnlstm<128>(x, dx, h, c, K, ln, h_out, c_out, rows, nullptr, nullptr, st);
-    }
+    const tspgnn_lstm_task t = {x, dx, h, c, K, ln, h_out, c_out, rows, nullptr, nullptr};
+    return tspgnn_lnlstm_fwd_multi_f32(&t, 1, d, stream);
 }
 
 extern "C" int tspgnn_lnlstm_gather_fwd_f32(const int32_t* uv, const float* Zx, const float* h, const float* c,
                                             const float* Kh, const float* ln, float* h_out, float* c_out, int rows,
                                             int n_src, int d, void* stream) {
-    TSPGNN_REQUIRE(rows >= 0 && n_src >= 0, "lnlstm_gather_fwd: rows=%d n_src=%d", rows, n_src);
-    TSPGNN_REQUIRE(d == 32 || d == 64, "lnlstm_gather_fwd: d=%d must be 32 or 64", d);
-    if (rows == 0) return TSPGNN_OK;
-    TSPGNN_REQUIRE(uv && Zx && h && c && Kh && ln && h_out && c_out, "lnlstm_gather_fwd: null pointer");
-    TSPGNN_REQUIRE(h_out != h && c_out != c, "lnlstm_gather_fwd: outputs may not alias inputs");
-    hipStream_t st = as_stream(stream);
-    if (d == 32) return launch_lnlstm<32>(nullptr, 0, h, c, Kh, ln, h_out, c_out, rows, uv, Zx, st);
-    return launch_lnlstm<64>(nullptr, 0, h, c, Kh, ln, h_out, c_out, rows, uv, Zx, st);
+    TSPGNN_REQUIRE(n_src >= 0, "lnlstm_gather_fwd: n_src=%d", n_src);
+    TSPGNN_REQUIRE(rows == 0 || (uv && Zx), "lnlstm_gather_fwd: null pointer");
+    const tspgnn_lstm_task t = {nullptr, 0, h, c, Kh, ln, h_out, c_out, rows, uv, Zx};
+    return tspgnn_lnlstm_fwd_multi_f32(&t, 1, d, stream);
 }

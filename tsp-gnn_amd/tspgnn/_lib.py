@@ -29,6 +29,8 @@ SIGNATURES = {
     "tspgnn_mlp_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_uint, c_void_p],
     "tspgnn_lnlstm_fwd_f32": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                               c_int, c_void_p],
+    "tspgnn_mlp_fwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_lnlstm_fwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_gather_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_gather_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -60,6 +62,18 @@ SIZE_QUERIES = {
     "tspgnn_einit_bwd_workspace_floats": [c_int, c_int],
     "tspgnn_adam_workspace_floats": [],
 }
+
+
+class MlpTask(ctypes.Structure):
+    """tspgnn_mlp_task (include/tspgnn.h)."""
+    _fields_ = [("X", c_void_p), ("wb", c_void_p), ("Y", c_void_p), ("acts", c_void_p), ("acts_stride", c_longlong),
+                ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint)]
+
+
+class LstmTask(ctypes.Structure):
+    """tspgnn_lstm_task (include/tspgnn.h)."""
+    _fields_ = [("x", c_void_p), ("dx", c_int), ("h", c_void_p), ("c", c_void_p), ("K", c_void_p), ("ln", c_void_p),
+                ("h_out", c_void_p), ("c_out", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p)]
 
 
 class TspgnnError(RuntimeError):
@@ -129,3 +143,9 @@ def workspace(query, *args, device=None):
     """A scratch tensor sized by one of the tspgnn_*_workspace_floats queries."""
     n = int(getattr(lib, query)(*args))
     return torch.empty(max(n, 1), dtype=torch.float32, device=device)
+
+
+def call_multi(name, tasks, d):
+    """Launch a list of MlpTask / LstmTask structures with one tspgnn_*_multi_f32 call."""
+    arr = (type(tasks[0]) * len(tasks))(*tasks)
+    call(name, ctypes.cast(arr, c_void_p), len(tasks), d, current_stream())

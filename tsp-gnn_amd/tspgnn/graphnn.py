@@ -204,6 +204,15 @@ class LayerNormBasicLSTMCell(object):
     def kh_t_packed(self):
         return self._packed_slice("lstm.khT", self.dx, self.dx + self.d, True)
 
+    def task(self, x, state, out):
+        return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(self.kernel_packed()),
+                             _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None)
+
+    def gather_task(self, adj, zx, state, out):
+        return _lib.LstmTask(None, 0, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(self.kh_packed()),
+                             _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0],
+                             _lib.ptr(adj.uv), _lib.ptr(zx))
+
     def premultiply(self, y, out=None):
         """Zx = y Kx  ([n_src, 4d])."""
         if out is None:
@@ -421,33 +430,74 @@ class GraphNN(object):
             states[v] = LSTMStateTuple(c=c0, h=h0)
         folded = {v: self._folded(v, mats) for v in self.var}
         for _ in range(int(time_steps)):
-            new_states = {}
-            for v in self.var:
-                if folded[v] is not None:
-                    u = folded[v]
-                    y = states[u["var"]].h
-                    if "msg" in u:
-                        y = self._msg_MLPs[u["msg"]](y)
-                    cell = self._RNN_cells[v]
-                    _, new_states[v] = cell.gather_call(mats[u["mat"]], cell.premultiply(y), states[v])
-                    continue
-                inputs = []
-                for update in self.loop[v]:
-                    if "var" in update:
-                        y = states[update["var"]].h
-                        if "fun" in update:
-                            y = update["fun"](y)
-                        if "msg" in update:
-                            y = self._msg_MLPs[update["msg"]](y)
-                        if "mat" in update:
-                            y = mats[update["mat"]].matmul(y, transpose=update.get("transpose?", False))
-                        inputs.append(y)
-                    else:
-                        inputs.append(dense_mats[update["mat"]])
-                x = inputs[0] if len(inputs) == 1 else torch.cat(inputs, dim=1)
-                _, new_states[v] = self._RNN_cells[v](x, states[v])
-            states = new_states
+            states = self._step(states, mats, dense_mats, folded)
         return states
+
+    def _step(self, states, mats, dense_mats, folded):
+        """One synchronous step (graphnn.py:142-173) in three phases, so that independent work of the
+        same kind shares a launch: (A) every message MLP, (B) the adjacency products / vertex-side
+        pre-multiplications, (C) every cell."""
+        f32 = dict(dtype=torch.float32, device=self.store.theta.device)
+        # ---- A: message MLPs of all loop entries
+        msg_out, tasks, keep = {}, {}, []
+        for v in self.var:
+            for i, u in enumerate(self.loop[v]):
+                if "var" not in u:
+                    continue
+                y = states[u["var"]].h
+                if "fun" in u:
+                    y = u["fun"](y)
+                if "msg" in u:
+                    mlp = self._msg_MLPs[u["msg"]]
+                    out = torch.empty((y.shape[0], mlp.sizes[-1]), **f32)
+                    yc = y if (y.dtype == torch.float32 and y.is_contiguous()) else y.to(torch.float32).contiguous()
+                    t = mlp.task(yc, out)
+                    if t is None:
+                        out = mlp(y)
+                    else:
+                        tasks.setdefault(mlp.sizes[-1], []).append(t)
+                        keep.append(yc)
+                    y = out
+                msg_out[(v, i)] = y
+        for d, ts in tasks.items():
+            for k in range(0, len(ts), 4):
+                _lib.call_multi("tspgnn_mlp_fwd_multi_f32", ts[k:k + 4], d)
+        # ---- B: adjacency products (or, for a folded cell, Zx = y Kx on the source rows)
+        cell_in = {}
+        for v in self.var:
+            if folded[v] is not None:
+                cell_in[v] = self._RNN_cells[v].premultiply(msg_out[(v, 0)])
+                continue
+            inputs = []
+            for i, u in enumerate(self.loop[v]):
+                if "var" in u:
+                    y = msg_out[(v, i)]
+                    if "mat" in u:
+                        y = mats[u["mat"]].matmul(y, transpose=u.get("transpose?", False))
+                    inputs.append(y)
+                else:
+                    inputs.append(dense_mats[u["mat"]])
+            cell_in[v] = inputs[0] if len(inputs) == 1 else torch.cat(inputs, dim=1)
+        # ---- C: all cells
+        new_states, tasks = {}, {}
+        for v, d in self.var.items():
+            cell, st = self._RNN_cells[v], states[v]
+            out = (torch.empty_like(st.h), torch.empty_like(st.c))
+            new_states[v] = LSTMStateTuple(c=out[1], h=out[0])
+            if folded[v] is not None:
+                t = cell.gather_task(mats[folded[v]["mat"]], cell_in[v], st, out)
+            else:
+                x = cell_in[v]
+                if x.shape[0] != st.h.shape[0] or x.shape[1] != cell.dx:
+                    raise ValueError("cell input must be [%d,%d], got %s" % (st.h.shape[0], cell.dx, tuple(x.shape)))
+                x = x if x.is_contiguous() else x.contiguous()
+                keep.append(x)
+                t = cell.task(x, st, out)
+            tasks.setdefault(d, []).append(t)
+        for d, ts in tasks.items():
+            for k in range(0, len(ts), 4):
+                _lib.call_multi("tspgnn_lnlstm_fwd_multi_f32", ts[k:k + 4], d)
+        return new_states
 
     # ---------------------------------------------------------------- training: forward with a tape
     def forward_train(self, adjacency_matrices, initial_embeddings, time_steps):

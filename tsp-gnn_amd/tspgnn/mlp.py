@@ -127,6 +127,14 @@ class Mlp(object):
                 mask |= 1 << j
         return mask
 
+    def task(self, x, out, acts=None, acts_stride=0):
+        """An _lib.MlpTask for a single-kernel square chain (None if this Mlp needs several kernels)."""
+        kind, d, n_sq, head = self._plan
+        if kind != "square" or head or len(self._chunks()) != 1:
+            return None
+        return _lib.MlpTask(_lib.ptr(x), _lib.ptr(self.wb_packed(0, n_sq - 1, d)), _lib.ptr(out), _lib.ptr(acts),
+                            acts_stride, x.shape[0], n_sq, self.relu_mask(0, n_sq))
+
     def _chunks(self):
         kind, d, n_sq, head = self._plan
         step = 2 if d == 128 else 4   # layers whose weights fit LDS together
