@@ -147,5 +147,6 @@ def workspace(query, *args, device=None):
 
 def call_multi(name, tasks, d):
     """Launch a list of MlpTask / LstmTask structures with one tspgnn_*_multi_f32 call."""
-    arr = (type(tasks[0]) * len(tasks))(*tasks)
-    call(name, ctypes.cast(arr, c_void_p), len(tasks), d, current_stream())
+    if isinstance(tasks, list):
+        tasks = (type(tasks[0]) * len(tasks))(*tasks)
+    call(name, ctypes.cast(tasks, c_void_p), len(tasks), d, current_stream())

@@ -429,9 +429,86 @@ class GraphNN(object):
                 else LSTM_initial_states[v].to(torch.float32).contiguous()
             states[v] = LSTMStateTuple(c=c0, h=h0)
         folded = {v: self._folded(v, mats) for v in self.var}
-        for _ in range(int(time_steps)):
+        T = int(time_steps)
+        plan = self._plan(states, mats, folded) if T > 0 else None
+        if plan is not None:
+            for t in range(T):
+                plan[t & 1]()
+            return plan[2][T & 1]
+        for _ in range(T):
             states = self._step(states, mats, dense_mats, folded)
         return states
+
+    def _plan(self, states, mats, folded):
+        """Pre-builds the launches of an even and an odd step over two ping-pong state buffers, so that
+        the T-step loop is a handful of ctypes calls per step (the host stays ahead of the GPU even
+        without HIP-graph replay).  Returns (run_even, run_odd, (states_if_T_even, states_if_T_odd)), or
+        None when the wiring needs the general path (Python 'fun' entries, dense matrices, MLPs that do
+        not fit one kernel)."""
+        f32 = dict(dtype=torch.float32, device=self.store.theta.device)
+        for v in self.var:
+            for u in self.loop[v]:
+                if "var" not in u or "fun" in u:
+                    return None
+                if "msg" in u and len(self._msg_MLPs[u["msg"]]._chunks()) != 1:
+                    return None
+        # buf[p] holds the states a step of parity p READS; it writes buf[1-p]
+        buf = [{v: LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) for v, st in states.items()},
+               {v: LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h)) for v, st in states.items()}]
+        runs, keep = [], []
+        for p in (0, 1):
+            src_states, dst_states = buf[p], buf[1 - p]
+            mlp_tasks, lstm_tasks, mid, msg_out = {}, {}, [], {}
+            for v in self.var:
+                for i, u in enumerate(self.loop[v]):
+                    y = src_states[u["var"]].h
+                    if "msg" in u:
+                        mlp = self._msg_MLPs[u["msg"]]
+                        out = torch.empty((y.shape[0], mlp.sizes[-1]), **f32)
+                        mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.task(y, out))
+                        y = out
+                    msg_out[(v, i)] = y
+            for v, d in self.var.items():
+                cell, st = self._RNN_cells[v], src_states[v]
+                out = (dst_states[v].h, dst_states[v].c)
+                if folded[v] is not None:
+                    zx = torch.empty((msg_out[(v, 0)].shape[0], 4 * d), **f32)
+                    mid.append((cell.premultiply, (msg_out[(v, 0)], zx)))
+                    lstm_tasks.setdefault(d, []).append(cell.gather_task(mats[folded[v]["mat"]], zx, st, out))
+                    keep.append(zx)
+                    continue
+                inputs = []
+                for i, u in enumerate(self.loop[v]):
+                    y = msg_out[(v, i)]
+                    if "mat" in u:
+                        adj, tr = mats[u["mat"]], u.get("transpose?", False)
+                        o = torch.empty((adj.shape[1] if tr else adj.shape[0], y.shape[1]), **f32)
+                        mid.append((adj.matmul, (y, tr, o)))
+                        y = o
+                    inputs.append(y)
+                if len(inputs) == 1:
+                    x = inputs[0]
+                else:
+                    x = torch.empty((st.h.shape[0], cell.dx), **f32)
+                    mid.append((lambda ins, o: torch.cat(ins, dim=1, out=o), (inputs, x)))
+                if x.shape[0] != st.h.shape[0] or x.shape[1] != cell.dx:
+                    raise ValueError("cell input must be [%d,%d], got %s" % (st.h.shape[0], cell.dx, tuple(x.shape)))
+                lstm_tasks.setdefault(d, []).append(cell.task(x, st, out))
+                keep.append(x)
+            keep.append(msg_out)
+
+            def run(mlp_tasks=mlp_tasks, mid=mid, lstm_tasks=lstm_tasks):
+                for d, ts in mlp_tasks.items():
+                    for k in range(0, len(ts), 4):
+                        _lib.call_multi("tspgnn_mlp_fwd_multi_f32", ts[k:k + 4], d)
+                for fn, args in mid:
+                    fn(*args)
+                for d, ts in lstm_tasks.items():
+                    for k in range(0, len(ts), 4):
+                        _lib.call_multi("tspgnn_lnlstm_fwd_multi_f32", ts[k:k + 4], d)
+            runs.append(run)
+        self._plan_keep = keep   # buffers referenced by raw pointers inside the task structures
+        return runs[0], runs[1], (buf[0], buf[1])
 
     def _step(self, states, mats, dense_mats, folded):
         """One synchronous step (graphnn.py:142-173) in three phases, so that independent work of the
