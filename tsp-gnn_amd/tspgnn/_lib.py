@@ -145,6 +145,11 @@ def workspace(query, *args, device=None):
     return torch.empty(max(n, 1), dtype=torch.float32, device=device)
 
 
+def task_array(tasks):
+    """ctypes array of MlpTask / LstmTask (build once, launch many times)."""
+    return (type(tasks[0]) * len(tasks))(*tasks)
+
+
 def call_multi(name, tasks, d):
     """Launch a list of MlpTask / LstmTask structures with one tspgnn_*_multi_f32 call."""
     if isinstance(tasks, list):

@@ -497,15 +497,16 @@ class GraphNN(object):
                 keep.append(x)
             keep.append(msg_out)
 
-            def run(mlp_tasks=mlp_tasks, mid=mid, lstm_tasks=lstm_tasks):
-                for d, ts in mlp_tasks.items():
-                    for k in range(0, len(ts), 4):
-                        _lib.call_multi("tspgnn_mlp_fwd_multi_f32", ts[k:k + 4], d)
+            mlp_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in mlp_tasks.items() for k in range(0, len(ts), 4)]
+            lstm_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in lstm_tasks.items() for k in range(0, len(ts), 4)]
+
+            def run(mlp_calls=mlp_calls, mid=mid, lstm_calls=lstm_calls):
+                for arr, d in mlp_calls:
+                    _lib.call_multi("tspgnn_mlp_fwd_multi_f32", arr, d)
                 for fn, args in mid:
                     fn(*args)
-                for d, ts in lstm_tasks.items():
-                    for k in range(0, len(ts), 4):
-                        _lib.call_multi("tspgnn_lnlstm_fwd_multi_f32", ts[k:k + 4], d)
+                for arr, d in lstm_calls:
+                    _lib.call_multi("tspgnn_lnlstm_fwd_multi_f32", arr, d)
             runs.append(run)
         self._plan_keep = keep   # buffers referenced by raw pointers inside the task structures
         return runs[0], runs[1], (buf[0], buf[1])
