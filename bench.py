@@ -44,9 +44,14 @@ def spmm_bytes(N, M, d, eb=4, ib=4):
     return gather, rowsum
 
 
-def dense_flops_per_step(N, M, d):
-    """MFMA work per message-passing step: two 4-layer d x d MLPs and two [2d,4d] LSTM GEMMs."""
-    return (M + N) * (4 * 2 * d * d + 2 * 2 * d * 4 * d)
+def dense_flops_per_step(N, M, d, folded=True):
+    """MFMA work per message-passing step.  Reference op count: two 4-layer d x d MLPs and two [2d,4d]
+    LSTM GEMMs on M+N rows.  Executed (folded=True): the x-half of the edge cell's GEMM runs on the N
+    vertex rows ((EV y)Kx = EV(y Kx)) instead of the M edge rows."""
+    mlp = (M + N) * 4 * 2 * d * d
+    if not folded:
+        return mlp + (M + N) * 2 * 2 * d * 4 * d
+    return mlp + M * 2 * d * 4 * d + N * 2 * 2 * d * 4 * d + N * 2 * d * 4 * d
 
 
 def main():
@@ -185,10 +190,17 @@ def main():
 
         t_gather, t_rowsum, t_pair = time_loop([gather]), time_loop([rowsum]), time_loop([gather, rowsum])
         pair_gbs = (gather_b + rowsum_b) / (t_pair * 1e-6) / 1e9
+        traffic = None   # HBM-side bytes per launch pair from the committed PMC pass (rocprofv3 --pmc cannot run in here)
+        tpath = os.path.join(ROOT, "profiles", "r01_spmm_pmc_traffic.json")
+        if args.workload == "c2" and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("pair_traffic_bytes")
         roofline = {
             "kernel": "tspgnn_gather2_sum_f32 + tspgnn_csr_rowsum_f32 (the vertex<->edge SpMM pair)",
             "bound": "hbm", "achieved": round(pair_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(pair_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(pair_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": "profiles/r01_spmm_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+                              if traffic else None,
             "algorithmic_bytes_per_launch": {"gather2_sum": gather_b, "csr_rowsum": rowsum_b},
             "avg_us": {"gather2_sum": round(t_gather, 2), "csr_rowsum": round(t_rowsum, 2), "pair": round(t_pair, 2)},
             "per_kernel_GBs": {"gather2_sum": round(gather_b / t_gather / 1e3, 1),
@@ -196,14 +208,20 @@ def main():
             "spmm_steps_per_s": round(1e6 / t_pair, 1),
             "incidences_per_s": round(4 * M * 1e6 / t_pair, 1),
         }
-        dense_us = sum(v["total_us"] for k, v in kernels_us.items() if k in ("tspgnn_mlp_fwd_f32", "tspgnn_lnlstm_fwd_f32"))
+        dense_names = ("tspgnn_mlp_fwd_f32", "tspgnn_mlp_fwd_multi_f32", "tspgnn_lnlstm_fwd_f32",
+                       "tspgnn_lnlstm_fwd_multi_f32", "tspgnn_lnlstm_gather_fwd_f32", "tspgnn_linear_f32")
+        dense_us = sum(v["total_us"] for k, v in kernels_us.items() if k in dense_names)
         # E_vote's 3 hidden layers also run through mlp_fwd: count their flops too
-        dense_flops = T * dense_flops_per_step(N, M, d) + M * 3 * 2 * d * d
+        dense_flops = T * dense_flops_per_step(N, M, d, folded=True) + M * 3 * 2 * d * d
         roofline_dense = {
-            "kernel": "tspgnn_mlp_fwd_f32 + tspgnn_lnlstm_fwd_f32 (fp32 MFMA 16x16x4)",
+            "kernel": "mlp_fwd_multi + lnlstm_fwd_multi + linear (fp32 MFMA v_mfma_f32_16x16x4_f32)",
             "bound": "mfma", "achieved": round(dense_flops / (dense_us * 1e-6) / 1e12, 2) if dense_us else None,
             "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
             "frac": round(dense_flops / (dense_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4) if dense_us else None,
+            "executed_gflop_per_mp_step": round(dense_flops_per_step(N, M, d, True) / 1e9, 3),
+            "reference_gflop_per_mp_step": round(dense_flops_per_step(N, M, d, False) / 1e9, 3),
+            "note": "executed flops (the adjacency product is folded through the edge cell's GEMM); the reference "
+                    "graph does 10.3 GFLOP of dense work per step at C2",
         }
 
         cpu_baseline = None

@@ -20,12 +20,14 @@ __global__ __launch_bounds__(256) void gather2_sum_kernel(const int2* __restrict
         const int2 ends = uv[e];
         const float4 a = X[(long long)ends.x * d4 + c];
         const float4 b = X[(long long)ends.y * d4 + c];
-        float4 r;
-        r.x = a.x + b.x;
-        r.y = a.y + b.y;
-        r.z = a.z + b.z;
-        r.w = a.w + b.w;
-        Y[i] = r;
+        f32x4 r;
+        r[0] = a.x + b.x;
+        r[1] = a.y + b.y;
+        r[2] = a.z + b.z;
+        r[3] = a.w + b.w;
+        // streamed once, consumed by a later kernel: non-temporal store keeps X (re-read by every
+        // workgroup) resident in L2
+        __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(Y) + i);
     }
 }
 
@@ -42,7 +44,12 @@ __global__ __launch_bounds__(256) void csr_rowsum_kernel(const int* __restrict__
                                                          const float4* __restrict__ X,
                                                          float4* __restrict__ Y, int N) {
     constexpr int RPW = kWave / LPR;
-    const int v = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  Give each
+    // XCD one contiguous eighth of the vertices, so the ~n vertices of one graph -- which together read
+    // every edge row of that graph TWICE (once per endpoint) -- share one L2 and the second read hits.
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const unsigned vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;  // bijective for any nb
+    const int v = (int)(((long long)vb * blockDim.x + threadIdx.x) >> 6);
     if (v >= N) return;  // wave-uniform
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
