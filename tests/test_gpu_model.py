@@ -244,3 +244,68 @@ def test_captured_graph_replay_matches_eager(cuda_device):
     model.store.load(params)                      # bumps the variable version
     with pytest.raises(RuntimeError, match="capture again"):
         replay()
+
+
+def test_binary_search_caller(cuda_device):
+    """experiments/binary_search.py get_cost on the HIP predictions: same probes and decisions as the loop
+    driven by the float64 oracle (untrained weights, so only the mechanics are checked), and the k-ary
+    variant brackets the same threshold crossing."""
+    rng = np.random.RandomState(5)
+    inst = tspgnn.random_instance(9, rng)
+    d, T = 32, 3
+    params = P.init_params(d, seed=12, perturb=True)
+    model = tspgnn.build_network(d)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    wpred, pred, route_cost, iters = tspgnn.get_cost(sess, model, inst, T)
+    # the same loop on the oracle
+    Ma, Mw, route = inst
+    from tspgnn.binary_search import cost_bounds
+    wmin, wmax = cost_bounds(Mw, 9)
+    EV, W, _, r, nv, ne = tspgnn.InstanceLoader.create_batch([inst], target_cost=0.0)
+    tp = TO.to_torch(params, torch.float64)
+    w, it = (wmin + wmax) / 2, 0
+    while wmin < w * 0.99 or w * 1.01 < wmax:
+        b = {"ev_uv": EV.uv, "W": W, "C": np.ones_like(W) * w, "route_exists": r, "n_vertices": nv, "n_edges": ne}
+        p = TO.forward(tp, b, T)["predictions"].item()
+        if p < 0.5:
+            wmin = w
+        else:
+            wmax = w
+        w, it = (wmin + wmax) / 2, it + 1
+    assert it == iters and abs(w - wpred) < 1e-12 and 0 < iters < 40
+    assert abs(route_cost - sum(Mw[min(i, j), max(i, j)] for i, j in zip(route, route[1:] + route[:1])) / 9) < 1e-12
+    w8, _, _, it8 = tspgnn.get_cost(sess, model, inst, T, parallel=8)
+    assert it8 <= (iters + 2) // 3 + 1
+
+
+def test_c4_ragged_full_size(cuda_device):
+    """BASELINE configs[3]: mixed n in {20..80}, batch 512, one GPU, CSR-packed block-diagonal adjacency
+    (seed 0 -> N=25 362, M=695 849 per SURVEY.md §8d M2).  Full-size properties: sizes, finite outputs,
+    per-problem prediction of three problems equal to running each alone (ragged segments)."""
+    rng = np.random.RandomState(0)
+    sizes = rng.randint(20, 81, size=512)
+    t = tspgnn.synthetic_batch(sizes, seed=1234)
+    EV, W, C, r, nv, ne = t
+    assert EV.shape == (int((sizes * (sizes - 1) // 2).sum()), int(sizes.sum()))
+    params = P.init_params(64, seed=0)
+    out = run_hip(64, params, t, 8, fetch=("predictions", "loss"))
+    assert np.all(np.isfinite(out["predictions"])) and np.isfinite(out["loss"])
+    eo = np.concatenate([[0], np.cumsum(ne)]); vo = np.concatenate([[0], np.cumsum(nv)])
+    for i in (0, 255, 511):
+        ev = tspgnn.SparseEV(EV.uv[eo[i]:eo[i + 1]] - vo[i], int(nv[i]))
+        one = run_hip(64, params, (ev, W[eo[i]:eo[i + 1]], C[eo[i]:eo[i + 1]], r[i:i + 1], nv[i:i + 1], ne[i:i + 1]), 8,
+                      fetch=("predictions",))
+        assert abs(float(one["predictions"][0]) - float(out["predictions"][i])) < 2e-6
+
+
+def test_c5_shape_d128_n200(cuda_device):
+    """BASELINE configs[4] shape at a reduced batch: n=200 (vertex degree 199 > one wavefront of edge ids),
+    d=128 (LSTM kernel matrix streamed through LDS in chunks), fp32; parity against the oracle at T=2."""
+    t = tspgnn.synthetic_batch([200, 200], seed=3)
+    params = P.init_params(128, seed=6, perturb=True)
+    hip = run_hip(128, params, t, 2, fetch=("predictions", "last_states"))
+    ref = TO.forward(TO.to_torch(params, torch.float64), batch_from_tuple(t), 2)
+    assert rel_err(hip["predictions"], ref["predictions"].numpy()) < REL_TOL
+    assert rel_err(hip["last_states"]["V"].h, ref["last_states"]["V"][0].numpy()) < REL_TOL

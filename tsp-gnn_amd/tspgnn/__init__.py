@@ -8,6 +8,7 @@ from . import _lib  # noqa: F401  (raises ImportError if libtspgnn.so is missing
 from ._lib import TspgnnError
 from .graphnn import GraphNN, LSTMStateTuple, DeviceAdjacency, LayerNormBasicLSTMCell
 from .instance_loader import InstanceLoader, SparseEV, read_graph, write_graph, synthetic_batch, random_instance
+from .binary_search import get_cost
 from .mlp import Mlp
 from .model import build_network, Session, global_variables_initializer
 from .variables import VariableStore, get_default_store, reset_default_store
@@ -15,5 +16,5 @@ from .variables import VariableStore, get_default_store, reset_default_store
 __all__ = [
     "TspgnnError", "GraphNN", "LSTMStateTuple", "DeviceAdjacency", "LayerNormBasicLSTMCell", "InstanceLoader",
     "SparseEV", "read_graph", "write_graph", "synthetic_batch", "random_instance", "Mlp", "build_network",
-    "Session", "global_variables_initializer", "VariableStore", "get_default_store", "reset_default_store",
+    "Session", "global_variables_initializer", "get_cost", "VariableStore", "get_default_store", "reset_default_store",
 ]
