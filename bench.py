@@ -225,7 +225,7 @@ def main():
         }
 
         cpu_baseline = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             cpu_baseline = run_cpu_baseline(d, batch, T, args.cpu_seconds, M)
 
         result = {
