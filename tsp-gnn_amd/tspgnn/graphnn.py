@@ -618,43 +618,62 @@ class GraphNN(object):
                     src = u["var"]
                     tape.acts[(v, i)] = torch.empty((max(mlp.n_square - 1, 1), T, n[src], self.var[src]), **f32)
         for t in range(T):
+            # ---- A: every message MLP of the step in one launch (per width), outputs straight into the tape
+            msg_out, mlp_tasks = {}, {}
             for v in self.var:
-                if tape.folded[v] is not None:
-                    u, cell = tape.folded[v], self._RNN_cells[v]
+                single = len(self.loop[v]) == 1
+                for i, u in enumerate(self.loop[v]):
                     src = u["var"]
                     y = tape.H[src][t]
                     if "msg" in u:
-                        acts = tape.acts[(v, 0)]
-                        y = self._msg_MLPs[u["msg"]].forward_saving(y, tape.X[v][t], acts[:, t], acts.stride(0))
-                    else:
-                        tape.X[v][t].copy_(y)
-                        y = tape.X[v][t]
-                    cell.premultiply(y, out=tape.ZX[v][t])
-                    cell.gather_call(mats[u["mat"]], tape.ZX[v][t], LSTMStateTuple(c=tape.C[v][t], h=tape.H[v][t]),
-                                     out=(tape.H[v][t + 1], tape.C[v][t + 1]))
+                        mlp = self._msg_MLPs[u["msg"]]
+                        acts = tape.acts[(v, i)]
+                        to_tape = tape.folded[v] is not None or (single and "mat" not in u)
+                        out = tape.X[v][t] if to_tape else torch.empty((n[src], mlp.sizes[-1]), **f32)
+                        task = mlp.task(y, out, acts[:, t], acts.stride(0))
+                        if task is None:
+                            mlp.forward_saving(y, out, acts[:, t], acts.stride(0))
+                        else:
+                            mlp_tasks.setdefault(mlp.sizes[-1], []).append(task)
+                        y = out
+                    msg_out[(v, i)] = y
+            for d, ts in mlp_tasks.items():
+                for k in range(0, len(ts), 4):
+                    _lib.call_multi("tspgnn_mlp_fwd_multi_f32", ts[k:k + 4], d)
+            # ---- B: adjacency products / vertex-side pre-multiplication
+            for v in self.var:
+                if tape.folded[v] is not None:
+                    u = tape.folded[v]
+                    if "msg" not in u:
+                        tape.X[v][t].copy_(msg_out[(v, 0)])
+                    self._RNN_cells[v].premultiply(tape.X[v][t], out=tape.ZX[v][t])
                     continue
                 single = len(self.loop[v]) == 1
                 inputs = []
                 for i, u in enumerate(self.loop[v]):
-                    src = u["var"]
-                    y = tape.H[src][t]
-                    direct = tape.X[v][t] if single else None     # last op of the entry writes the cell input
-                    if "msg" in u:
-                        mlp = self._msg_MLPs[u["msg"]]
-                        acts = tape.acts[(v, i)]
-                        out = direct if (direct is not None and "mat" not in u) else \
-                            torch.empty((n[src], mlp.sizes[-1]), **f32)
-                        y = mlp.forward_saving(y, out, acts[:, t], acts.stride(0))  # acts[:, t][l] = layer l at step t
+                    y = msg_out[(v, i)]
                     if "mat" in u:
-                        y = mats[u["mat"]].matmul(y, transpose=u.get("transpose?", False), out=direct)
-                    elif "msg" not in u and direct is not None:
-                        direct.copy_(y)
-                        y = direct
+                        y = mats[u["mat"]].matmul(y, transpose=u.get("transpose?", False),
+                                                  out=tape.X[v][t] if single else None)
+                    elif single and "msg" not in u:
+                        tape.X[v][t].copy_(y)
                     inputs.append(y)
                 if not single:
                     torch.cat(inputs, dim=1, out=tape.X[v][t])
-                self._RNN_cells[v](tape.X[v][t], LSTMStateTuple(c=tape.C[v][t], h=tape.H[v][t]),
-                                   out=(tape.H[v][t + 1], tape.C[v][t + 1]))
+            # ---- C: every cell of the step in one launch (per width)
+            lstm_tasks = {}
+            for v, d in self.var.items():
+                cell = self._RNN_cells[v]
+                st = LSTMStateTuple(c=tape.C[v][t], h=tape.H[v][t])
+                out = (tape.H[v][t + 1], tape.C[v][t + 1])
+                if tape.folded[v] is not None:
+                    task = cell.gather_task(mats[tape.folded[v]["mat"]], tape.ZX[v][t], st, out)
+                else:
+                    task = cell.task(tape.X[v][t], st, out)
+                lstm_tasks.setdefault(d, []).append(task)
+            for d, ts in lstm_tasks.items():
+                for k in range(0, len(ts), 4):
+                    _lib.call_multi("tspgnn_lnlstm_fwd_multi_f32", ts[k:k + 4], d)
         states = {v: LSTMStateTuple(c=tape.C[v][T], h=tape.H[v][T]) for v in self.var}
         return states, tape
 
