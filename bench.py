@@ -188,7 +188,12 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) * 1e3 / iters   # us per iteration
 
-        t_gather, t_rowsum, t_pair = time_loop([gather]), time_loop([rowsum]), time_loop([gather, rowsum])
+        def pair():   # both directions of a step's aggregation in one launch (tspgnn_spmm_pair_f32)
+            _lib.call("tspgnn_spmm_pair_f32", _lib.ptr(adj.uv), _lib.ptr(X), _lib.ptr(Y), _lib.ptr(rowptr), _lib.ptr(eid),
+                      _lib.ptr(Z), _lib.ptr(Vout), M, N, d, st)
+
+        t_gather, t_rowsum, t_pair, t_two = time_loop([gather]), time_loop([rowsum]), time_loop([pair]), \
+            time_loop([gather, rowsum])
         pair_gbs = (gather_b + rowsum_b) / (t_pair * 1e-6) / 1e9
         traffic = None   # HBM-side bytes per launch pair from the committed PMC pass (rocprofv3 --pmc cannot run in here)
         tpath = os.path.join(ROOT, "profiles", "r01_spmm_pmc_traffic.json")
@@ -196,13 +201,14 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get("pair_traffic_bytes")
         roofline = {
-            "kernel": "tspgnn_gather2_sum_f32 + tspgnn_csr_rowsum_f32 (the vertex<->edge SpMM pair)",
+            "kernel": "tspgnn_spmm_pair_f32 (E<-V gather + V<-E CSR row-sum of one step in one launch)",
             "bound": "hbm", "achieved": round(pair_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(pair_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_source": "profiles/r01_spmm_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
                               if traffic else None,
             "algorithmic_bytes_per_launch": {"gather2_sum": gather_b, "csr_rowsum": rowsum_b},
-            "avg_us": {"gather2_sum": round(t_gather, 2), "csr_rowsum": round(t_rowsum, 2), "pair": round(t_pair, 2)},
+            "avg_us": {"gather2_sum": round(t_gather, 2), "csr_rowsum": round(t_rowsum, 2), "pair": round(t_pair, 2),
+                       "two_launches": round(t_two, 2)},
             "per_kernel_GBs": {"gather2_sum": round(gather_b / t_gather / 1e3, 1),
                                "csr_rowsum": round(rowsum_b / t_rowsum / 1e3, 1)},
             "spmm_steps_per_s": round(1e6 / t_pair, 1),

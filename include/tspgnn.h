@@ -60,6 +60,15 @@ int tspgnn_csr_rowsum_f32(const int32_t* rowptr, const int32_t* eid, const float
                           int N, int M, int d, void* stream);
 
 /*
+ * Both aggregations of one message-passing step in one launch (they are independent: every update
+ * reads the OLD states, graphnn.py:143):  Ye = EV Xv  (gather, as tspgnn_gather2_sum_f32)  and
+ * Yv = EV^T Xe  (row-sum, as tspgnn_csr_rowsum_f32).  Xv:[N,d] Ye:[M,d] Xe:[M,d] Yv:[N,d]; d in
+ * {32,64,128,256}.  Shares the chip between the two streams instead of two launch latencies.
+ */
+int tspgnn_spmm_pair_f32(const int32_t* uv, const float* Xv, float* Ye, const int32_t* rowptr,
+                         const int32_t* eid, const float* Xe, float* Yv, int M, int N, int d, void* stream);
+
+/*
  * Y[r,:] = sum_k val[k] * X[col[k],:], k in [rowptr[r],rowptr[r+1])     r in [0,R)
  * General valued CSR product for GraphNN matrices that are not 0/1 patterns
  * (graphnn.py:156-160 with an arbitrary `mat`).  X:[C,d]  Y:[R,d].

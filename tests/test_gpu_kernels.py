@@ -90,6 +90,25 @@ def test_gather2_and_rowsum(cuda_device, name, d):
     assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
 
 
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+def test_spmm_pair_equals_the_two_kernels(cuda_device, d):
+    g = load_pack("ragged_B6", 0)
+    ev = SparseEV(g["ev_uv"], int(g["ev_shape"][1]))
+    M, N = ev.shape
+    rng = np.random.RandomState(d)
+    Xv = dev(rng.randn(N, d), cuda_device); Xe = dev(rng.randn(M, d), cuda_device)
+    rowptr, eid = ev.csr_by_vertex()
+    uv = dev(ev.uv, cuda_device, np.int32); rp = dev(rowptr, cuda_device, np.int32); ei = dev(eid, cuda_device, np.int32)
+    Ye1 = torch.empty((M, d), device=cuda_device); Yv1 = torch.empty((N, d), device=cuda_device)
+    Ye2 = torch.empty_like(Ye1); Yv2 = torch.empty_like(Yv1)
+    _lib.call("tspgnn_gather2_sum_f32", _lib.ptr(uv), _lib.ptr(Xv), _lib.ptr(Ye1), M, N, d, None)
+    _lib.call("tspgnn_csr_rowsum_f32", _lib.ptr(rp), _lib.ptr(ei), _lib.ptr(Xe), _lib.ptr(Yv1), N, M, d, None)
+    _lib.call("tspgnn_spmm_pair_f32", _lib.ptr(uv), _lib.ptr(Xv), _lib.ptr(Ye2), _lib.ptr(rp), _lib.ptr(ei), _lib.ptr(Xe),
+              _lib.ptr(Yv2), M, N, d, None)
+    torch.cuda.synchronize()
+    assert torch.equal(Ye1, Ye2) and torch.equal(Yv1, Yv2)      # same per-row arithmetic: bit exact
+
+
 def test_rowsum_high_degree_and_empty_rows(cuda_device):
     # n=200 complete graph: degree 199 (> one wavefront of edge ids); plus isolated vertices
     n = 200

@@ -9,12 +9,11 @@ namespace tspgnn {
 // ---------------------------------------------------------------- E <- V : gather, 2 nnz / row
 // One float4 per thread; a row of d floats is covered by d/4 adjacent lanes, so a wave64
 // writes 64*16 B = 1 KiB of contiguous Y per store instruction.
-__global__ __launch_bounds__(256) void gather2_sum_kernel(const int2* __restrict__ uv,
-                                                          const float4* __restrict__ X,
-                                                          float4* __restrict__ Y, int M, int d4) {
+__device__ __forceinline__ void gather2_sum_body(const int2* __restrict__ uv, const float4* __restrict__ X,
+                                                 float4* __restrict__ Y, int M, int d4, unsigned blk, unsigned nblk) {
     const long long total = (long long)M * d4;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long stride = (long long)nblk * blockDim.x;
+    for (long long i = (long long)blk * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int e = (int)(i / d4);
         const int c = (int)(i - (long long)e * d4);
         const int2 ends = uv[e];
@@ -31,6 +30,11 @@ __global__ __launch_bounds__(256) void gather2_sum_kernel(const int2* __restrict
     }
 }
 
+__global__ __launch_bounds__(256) void gather2_sum_kernel(const int2* __restrict__ uv, const float4* __restrict__ X,
+                                                          float4* __restrict__ Y, int M, int d4) {
+    gather2_sum_body(uv, X, Y, M, d4, blockIdx.x, gridDim.x);
+}
+
 // ---------------------------------------------------------------- V <- E : CSR row-sum
 // One wavefront per vertex.  LPR = d/4 lanes cover one edge row (float4 each), so the wave
 // reads RPW = 64/LPR edge rows per step; lane-group s accumulates the edges k = s (mod RPW)
@@ -38,16 +42,14 @@ __global__ __launch_bounds__(256) void gather2_sum_kernel(const int2* __restrict
 // order (deterministic result).  Edge ids of the row are fetched with one coalesced load
 // per 64 edges and broadcast by shuffle instead of one dependent scalar load per edge.
 template <int LPR, bool VALUED>
-__global__ __launch_bounds__(256) void csr_rowsum_kernel(const int* __restrict__ rowptr,
-                                                         const int* __restrict__ eid,
-                                                         const float* __restrict__ val,
-                                                         const float4* __restrict__ X,
-                                                         float4* __restrict__ Y, int N) {
+__device__ __forceinline__ void csr_rowsum_body(const int* __restrict__ rowptr, const int* __restrict__ eid,
+                                                const float* __restrict__ val, const float4* __restrict__ X,
+                                                float4* __restrict__ Y, int N, unsigned blk, unsigned nblk) {
     constexpr int RPW = kWave / LPR;
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  Give each
     // XCD one contiguous eighth of the vertices, so the ~n vertices of one graph -- which together read
     // every edge row of that graph TWICE (once per endpoint) -- share one L2 and the second read hits.
-    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const unsigned nb = nblk, q = nb >> 3, r = nb & 7, xcd = blk & 7, slot = blk >> 3;
     const unsigned vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;  // bijective for any nb
     const int v = (int)(((long long)vb * blockDim.x + threadIdx.x) >> 6);
     if (v >= N) return;  // wave-uniform
@@ -91,6 +93,29 @@ __global__ __launch_bounds__(256) void csr_rowsum_kernel(const int* __restrict__
         acc.w += __shfl_xor(acc.w, off);
     }
     if (sub == 0) Y[(long long)v * LPR + c] = acc;
+}
+
+template <int LPR, bool VALUED>
+__global__ __launch_bounds__(256) void csr_rowsum_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
+                                                         const float* __restrict__ val, const float4* __restrict__ X,
+                                                         float4* __restrict__ Y, int N) {
+    csr_rowsum_body<LPR, VALUED>(rowptr, eid, val, X, Y, N, blockIdx.x, gridDim.x);
+}
+
+// Both directions of one message-passing step's aggregation in ONE launch: E <- V gather and V <- E
+// row-sum read disjoint inputs and write disjoint outputs (both updates read the OLD states,
+// graphnn.py:143), so their workgroups can share the chip and the HBM pipe instead of paying two
+// launch latencies for ~5 us of streaming each.  Workgroups [0, nb_rowsum) run the row-sum (a multiple
+// of 8 keeps its XCD-contiguous vertex order), the rest the gather.
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_pair_kernel(const int2* __restrict__ uv, const float4* __restrict__ Xv,
+                                                        float4* __restrict__ Ye, int M, const int* __restrict__ rowptr,
+                                                        const int* __restrict__ eid, const float4* __restrict__ Xe,
+                                                        float4* __restrict__ Yv, int N, unsigned nb_rowsum) {
+    if (blockIdx.x < nb_rowsum)
+        csr_rowsum_body<LPR, false>(rowptr, eid, nullptr, Xe, Yv, N, blockIdx.x, nb_rowsum);
+    else
+        gather2_sum_body(uv, Xv, Ye, M, LPR, blockIdx.x - nb_rowsum, gridDim.x - nb_rowsum);
 }
 
 // Any d that is a multiple of 4 but not 32/64/128/256: one thread per (row, float4 column).
@@ -153,6 +178,35 @@ extern "C" int tspgnn_gather2_sum_f32(const int32_t* uv, const float* X, float* 
         reinterpret_cast<const int2*>(uv), reinterpret_cast<const float4*>(X), reinterpret_cast<float4*>(Y), M,
         d4);
     return launched("tspgnn_gather2_sum_f32");
+}
+
+extern "C" int tspgnn_spmm_pair_f32(const int32_t* uv, const float* Xv, float* Ye, const int32_t* rowptr,
+                                    const int32_t* eid, const float* Xe, float* Yv, int M, int N, int d, void* stream) {
+    TSPGNN_REQUIRE(M >= 0 && N >= 0, "spmm_pair: negative size (M=%d N=%d)", M, N);
+    TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128 || d == 256, "spmm_pair: d=%d must be 32, 64, 128 or 256", d);
+    if (M == 0 || N == 0) {  // degenerate: fall back to the two single-direction entry points
+        int rc = tspgnn_gather2_sum_f32(uv, Xv, Ye, M, N, d, stream);
+        return rc ? rc : tspgnn_csr_rowsum_f32(rowptr, eid, Xe, Yv, N, M, d, stream);
+    }
+    TSPGNN_REQUIRE(uv && Xv && Ye && rowptr && eid && Xe && Yv, "spmm_pair: null pointer");
+    const int d4 = d / 4;
+    unsigned nb_rowsum = (unsigned)(((long long)N * kWave + 255) / 256);
+    long long nb_gather = ((long long)M * d4 + 255) / 256;
+    if (nb_gather > 256 * 16) nb_gather = 256 * 16;
+    const unsigned grid = nb_rowsum + (unsigned)nb_gather;
+    hipStream_t st = as_stream(stream);
+    const int2* uv2 = reinterpret_cast<const int2*>(uv);
+    const float4* Xv4 = reinterpret_cast<const float4*>(Xv);
+    const float4* Xe4 = reinterpret_cast<const float4*>(Xe);
+    float4* Ye4 = reinterpret_cast<float4*>(Ye);
+    float4* Yv4 = reinterpret_cast<float4*>(Yv);
+    switch (d4) {
+        case 8: spmm_pair_kernel<8><<<grid, 256, 0, st>>>(uv2, Xv4, Ye4, M, rowptr, eid, Xe4, Yv4, N, nb_rowsum); break;
+        case 16: spmm_pair_kernel<16><<<grid, 256, 0, st>>>(uv2, Xv4, Ye4, M, rowptr, eid, Xe4, Yv4, N, nb_rowsum); break;
+        case 32: spmm_pair_kernel<32><<<grid, 256, 0, st>>>(uv2, Xv4, Ye4, M, rowptr, eid, Xe4, Yv4, N, nb_rowsum); break;
+        default: spmm_pair_kernel<64><<<grid, 256, 0, st>>>(uv2, Xv4, Ye4, M, rowptr, eid, Xe4, Yv4, N, nb_rowsum); break;
+    }
+    return launched("tspgnn_spmm_pair_f32");
 }
 
 extern "C" int tspgnn_csr_rowsum_f32(const int32_t* rowptr, const int32_t* eid, const float* X, float* Y, int N,

@@ -24,6 +24,8 @@ c_int, c_uint, c_float, c_void_p, c_char_p, c_longlong = (ctypes.c_int, ctypes.c
 SIGNATURES = {
     "tspgnn_gather2_sum_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tspgnn_csr_rowsum_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tspgnn_spmm_pair_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                             c_void_p],
     "tspgnn_csr_spmm_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tspgnn_pack_weights_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tspgnn_mlp_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_uint, c_void_p],
