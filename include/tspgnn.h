@@ -131,6 +131,7 @@ int tspgnn_lnlstm_gather_fwd_f32(const int32_t* uv, const float* Zx, const float
 typedef struct tspgnn_mlp_task {
     const float* X; const float* wb; float* Y; float* acts; long long acts_stride;
     int rows; int n_layers; unsigned relu_mask;
+    const float* proj_w; float* proj_out;  /* optional: proj_out[rows,4d] = Y * P, proj_w = pack_weights(P[d,4d]) */
 } tspgnn_mlp_task;   /* fields as the arguments of tspgnn_mlp_fwd_f32 */
 
 typedef struct tspgnn_lstm_task {
@@ -262,11 +263,14 @@ long long tspgnn_adam_workspace_floats(void);
  * One optimiser step on the flat parameter buffer (model.py:160-167): g += l2_scale*theta (gradient
  * of l2_scale * sum l2_loss(var)); global_norm = ||g||; g *= clip/max(global_norm, clip)
  * (clip_norm <= 0: no clipping); Adam with the bias-corrected step lr_t.  gnorm_out[0] = global_norm.
+ * step_counter == NULL: lr_t is the already bias-corrected rate lr*sqrt(1-b2^t)/(1-b1^t).
+ * step_counter != NULL (device int): the counter is incremented to t and lr_t is the BASE rate, corrected on
+ * the device -- no host value changes between steps, so the whole training step can be replayed as a HIP graph.
  * In data-parallel training g is the all-reduced (averaged) gradient.
  */
 int tspgnn_adam_clip_step_f32(float* theta, float* g, float* m, float* v, int n, float l2_scale,
                               float clip_norm, float lr_t, float beta1, float beta2, float eps,
-                              float* gnorm_out, float* workspace, void* stream);
+                              float* gnorm_out, float* workspace, int* step_counter, void* stream);
 
 #ifdef __cplusplus
 }

@@ -242,7 +242,7 @@ def test_adam_clip_step(cuda_device):
     td, gd, md, vd = (dev(a, cuda_device) for a in (theta, g, m, v))
     gn = empty((1,), cuda_device); wsz = ws("tspgnn_adam_workspace_floats", device=cuda_device)
     _lib.call("tspgnn_adam_clip_step_f32", _lib.ptr(td), _lib.ptr(gd), _lib.ptr(md), _lib.ptr(vd), n, TO.L2NORM_SCALING, TO.CLIP_NORM,
-              float(lr_t), TO.ADAM_B1, TO.ADAM_B2, TO.ADAM_EPS, _lib.ptr(gn), _lib.ptr(wsz), None)
+              float(lr_t), TO.ADAM_B1, TO.ADAM_B2, TO.ADAM_EPS, _lib.ptr(gn), _lib.ptr(wsz), None, None)
     torch.cuda.synchronize()
     g64 = g.astype(np.float64) + TO.L2NORM_SCALING * theta
     clipped, gnorm = TO.clip_by_global_norm({"a": g64})
@@ -250,3 +250,11 @@ def test_adam_clip_step(cuda_device):
     assert abs(gn.item() - gnorm) < 1e-5 * gnorm and gnorm > TO.CLIP_NORM     # the clip is active in this case
     assert rel_err(md.cpu().numpy(), m2["a"]) < 1e-6 and rel_err(vd.cpu().numpy(), v2["a"]) < 1e-6
     assert np.abs(td.cpu().numpy() - p["a"]).max() < 1e-6 * np.abs(p["a"]).max()
+    # device-side step counter: same update when the counter reaches the same step
+    td2, gd2, md2, vd2 = (dev(a, cuda_device) for a in (theta, g, m, v))
+    cnt = torch.full((1,), step - 1, dtype=torch.int32, device=cuda_device); _KEEP.append(cnt)
+    _lib.call("tspgnn_adam_clip_step_f32", _lib.ptr(td2), _lib.ptr(gd2), _lib.ptr(md2), _lib.ptr(vd2), n, TO.L2NORM_SCALING, TO.CLIP_NORM,
+              TO.LEARNING_RATE, TO.ADAM_B1, TO.ADAM_B2, TO.ADAM_EPS, _lib.ptr(gn), _lib.ptr(wsz), _lib.ptr(cnt), None)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == step
+    assert np.abs(td2.cpu().numpy() - p["a"]).max() < 2e-6 * np.abs(p["a"]).max()

@@ -309,3 +309,30 @@ def test_c5_shape_d128_n200(cuda_device):
     ref = TO.forward(TO.to_torch(params, torch.float64), batch_from_tuple(t), 2)
     assert rel_err(hip["predictions"], ref["predictions"].numpy()) < REL_TOL
     assert rel_err(hip["last_states"]["V"].h, ref["last_states"]["V"][0].numpy()) < REL_TOL
+
+
+def test_captured_training_step_matches_eager(cuda_device):
+    """capture_train_step (two HIP graphs around the all-reduce) must walk the same trajectory as eager
+    train_step: identical weights after 3 steps, bit for bit (same kernels, same order)."""
+    t = pack_tuple("ragged_B6", 1)
+    params = P.init_params(64, seed=9, perturb=True)
+    finals = []
+    for captured in (False, True):
+        model = tspgnn.build_network(64)
+        sess = tspgnn.Session(model)
+        sess.run(tspgnn.global_variables_initializer())
+        model.store.load(params)
+        EV, W, C, route_exists, n_vertices, n_edges = t
+        feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: 3,
+                model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+        b = sess.prepare(feed)
+        step = sess.capture_train_step(b) if captured else (lambda: sess.train_step(b))
+        losses = []
+        for _ in range(3):
+            out = step()
+            losses.append(float(out["stats"][0].item()))
+        torch.cuda.synchronize()
+        finals.append((model.store.theta.clone(), losses, int(sess._adam["t"].item())))
+    assert finals[0][2] == finals[1][2] == 3
+    assert finals[0][1] == finals[1][1]
+    assert torch.equal(finals[0][0], finals[1][0])

@@ -66,7 +66,7 @@ struct MlpTaskTable {
 };
 
 template <int D, int MAXL>
-__global__ __launch_bounds__(512) void mlp_fwd_kernel(const MlpTaskTable tt) {
+__global__ __launch_bounds__(512, 4) void mlp_fwd_kernel(const MlpTaskTable tt) {
     constexpr int NT = D / 16;
     __shared__ __attribute__((aligned(16))) float lds[MAXL * (D * D + D) + 4];
     float* lds_w = lds;
@@ -84,6 +84,8 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(const MlpTaskTable tt) {
     const long long acts_stride = tt.task[k].acts_stride;
     const int rows = tt.task[k].rows, n_layers = tt.task[k].n_layers;
     const unsigned relu_mask = tt.task[k].relu_mask;
+    const float* __restrict__ proj_w = tt.task[k].proj_w;
+    float* __restrict__ proj_out = tt.task[k].proj_out;
     const int tiles_total = (rows + 15) / 16;
 
     const int tid = threadIdx.x;
@@ -144,6 +146,37 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(const MlpTaskTable tt) {
         if (valid) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) st4(Y + rbase + t * 16, a[t]);
+        }
+    }
+    // Optional second phase of a (small) task: proj_out = Y * P with P = proj_w packed [D, 4D] -- the
+    // vertex-side pre-multiplication Zx = V_msg_E(V.h) K_x of the folded edge update -- after restaging
+    // this workgroup's LDS with P.  Saves a launch per message-passing step.
+    if constexpr (D <= 64) {
+        if (proj_w != nullptr) {
+            constexpr int NP = D / 4;  // output tiles of the projection (4D columns)
+            __threadfence_block();
+            __syncthreads();           // every wavefront is done with the MLP weights and has stored its Y rows
+            copy_to_lds(lds_w, proj_w, D * 4 * D, tid, blockDim.x);
+            if (tid == 0) *ticket = t_beg;
+            __syncthreads();
+            for (;;) {
+                int tile = 0;
+                if (lane == 0) tile = atomicAdd(ticket, 1);
+                tile = __builtin_amdgcn_readfirstlane(tile);
+                if (tile >= t_end) break;
+                const int row = tile * 16 + rl;
+                const bool valid = row < rows;
+                const size_t rc = (size_t)(valid ? row : rows - 1);
+                f32x4 acc[NP];
+#pragma unroll
+                for (int t = 0; t < NP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* yr = Y + rc * D + g * 4;
+                gemm_kloop<NP>(acc, lds_w, 0, 0, NT, yr, yr, NT, g, rl);
+                if (valid) {
+#pragma unroll
+                    for (int t = 0; t < NP; ++t) st4(proj_out + rc * 4 * D + t * 16 + g * 4, acc[t]);
+                }
+            }
         }
     }
 }
@@ -335,7 +368,7 @@ static int launch_mlp(const tspgnn_mlp_task* tasks, int n, hipStream_t st) {
     for (int k = 0; k < n; ++k) {
         tt.task[k] = tasks[k];
         if (tt.task[k].acts && tt.task[k].acts_stride == 0) tt.task[k].acts_stride = (long long)tasks[k].rows * D;
-        cost[k] = ((long long)tasks[k].rows + 15) / 16 * tasks[k].n_layers;
+        cost[k] = ((long long)tasks[k].rows + 15) / 16 * (tasks[k].n_layers + (tasks[k].proj_w ? 5 : 0));
         tiles_all += ((long long)tasks[k].rows + 15) / 16;
     }
     tt.n = n;
@@ -417,6 +450,7 @@ static int check_mlp_task(const tspgnn_mlp_task& t, int d) {
     TSPGNN_REQUIRE(t.n_layers >= 1 && t.n_layers <= 4, "mlp_fwd: n_layers=%d must be in 1..4", t.n_layers);
     TSPGNN_REQUIRE(d != 128 || t.n_layers <= 2, "mlp_fwd: d=128 holds at most 2 layers in LDS (got %d)", t.n_layers);
     TSPGNN_REQUIRE(t.rows == 0 || (t.X && t.wb && t.Y), "mlp_fwd: null pointer");
+    TSPGNN_REQUIRE(!t.proj_w || (t.proj_out && (d == 32 || d == 64)), "mlp_fwd: projection needs proj_out and d in {32,64}");
     return TSPGNN_OK;
 }
 
@@ -471,7 +505,7 @@ extern "C" int tspgnn_mlp_fwd_f32(const float* X, const float* wb, float* Y, flo
                                   int rows, int d, int n_layers, unsigned relu_mask, void* stream) {
     if (d == 128 && n_layers > 2 && n_layers <= 4)
         return fail(TSPGNN_EUNSUPPORTED, "mlp_fwd: d=128 holds at most 2 layers in LDS (got %d)", n_layers);
-    const tspgnn_mlp_task t = {X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask};
+    const tspgnn_mlp_task t = {X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask, nullptr, nullptr};
     return tspgnn_mlp_fwd_multi_f32(&t, 1, d, stream);
 }
 

@@ -53,7 +53,7 @@ SIGNATURES = {
     "tspgnn_wcolsum_f32": [c_void_p, c_void_p, c_longlong, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "tspgnn_einit_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_adam_clip_step_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
-                                  c_float, c_float, c_void_p, c_void_p, c_void_p],
+                                  c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 
 # size queries: name -> argtypes; these return long long (floats of workspace)
@@ -69,7 +69,7 @@ SIZE_QUERIES = {
 class MlpTask(ctypes.Structure):
     """tspgnn_mlp_task (include/tspgnn.h)."""
     _fields_ = [("X", c_void_p), ("wb", c_void_p), ("Y", c_void_p), ("acts", c_void_p), ("acts_stride", c_longlong),
-                ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint)]
+                ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint), ("proj_w", c_void_p), ("proj_out", c_void_p)]
 
 
 class LstmTask(ctypes.Structure):

@@ -458,22 +458,29 @@ class GraphNN(object):
         runs, keep = [], []
         for p in (0, 1):
             src_states, dst_states = buf[p], buf[1 - p]
-            mlp_tasks, lstm_tasks, mid, msg_out = {}, {}, [], {}
+            mlp_tasks, lstm_tasks, mid, msg_out, zxs = {}, {}, [], {}, {}
             for v in self.var:
                 for i, u in enumerate(self.loop[v]):
                     y = src_states[u["var"]].h
                     if "msg" in u:
                         mlp = self._msg_MLPs[u["msg"]]
                         out = torch.empty((y.shape[0], mlp.sizes[-1]), **f32)
-                        mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.task(y, out))
+                        proj = None
+                        if folded[v] is not None:   # Zx = msg(y) Kx rides in the MLP launch
+                            zxs[v] = torch.empty((y.shape[0], 4 * self.var[v]), **f32)
+                            proj = (self._RNN_cells[v].kx_packed(), zxs[v])
+                        mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.task(y, out, proj=proj))
                         y = out
                     msg_out[(v, i)] = y
             for v, d in self.var.items():
                 cell, st = self._RNN_cells[v], src_states[v]
                 out = (dst_states[v].h, dst_states[v].c)
                 if folded[v] is not None:
-                    zx = torch.empty((msg_out[(v, 0)].shape[0], 4 * d), **f32)
-                    mid.append((cell.premultiply, (msg_out[(v, 0)], zx)))
+                    if v in zxs:
+                        zx = zxs[v]
+                    else:
+                        zx = torch.empty((msg_out[(v, 0)].shape[0], 4 * d), **f32)
+                        mid.append((cell.premultiply, (msg_out[(v, 0)], zx)))
                     lstm_tasks.setdefault(d, []).append(cell.gather_task(mats[folded[v]["mat"]], zx, st, out))
                     keep.append(zx)
                     continue
@@ -630,9 +637,12 @@ class GraphNN(object):
                         acts = tape.acts[(v, i)]
                         to_tape = tape.folded[v] is not None or (single and "mat" not in u)
                         out = tape.X[v][t] if to_tape else torch.empty((n[src], mlp.sizes[-1]), **f32)
-                        task = mlp.task(y, out, acts[:, t], acts.stride(0))
+                        proj = (self._RNN_cells[v].kx_packed(), tape.ZX[v][t]) if tape.folded[v] is not None else None
+                        task = mlp.task(y, out, acts[:, t], acts.stride(0), proj=proj)
                         if task is None:
                             mlp.forward_saving(y, out, acts[:, t], acts.stride(0))
+                            if proj is not None:
+                                self._RNN_cells[v].premultiply(out, out=tape.ZX[v][t])
                         else:
                             mlp_tasks.setdefault(mlp.sizes[-1], []).append(task)
                         y = out
@@ -644,9 +654,9 @@ class GraphNN(object):
             for v in self.var:
                 if tape.folded[v] is not None:
                     u = tape.folded[v]
-                    if "msg" not in u:
+                    if "msg" not in u:   # with a message MLP, Zx was produced by the MLP launch itself
                         tape.X[v][t].copy_(msg_out[(v, 0)])
-                    self._RNN_cells[v].premultiply(tape.X[v][t], out=tape.ZX[v][t])
+                        self._RNN_cells[v].premultiply(tape.X[v][t], out=tape.ZX[v][t])
                     continue
                 single = len(self.loop[v]) == 1
                 inputs = []

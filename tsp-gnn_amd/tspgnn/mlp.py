@@ -127,13 +127,15 @@ class Mlp(object):
                 mask |= 1 << j
         return mask
 
-    def task(self, x, out, acts=None, acts_stride=0):
-        """An _lib.MlpTask for a single-kernel square chain (None if this Mlp needs several kernels)."""
+    def task(self, x, out, acts=None, acts_stride=0, proj=None):
+        """An _lib.MlpTask for a single-kernel square chain (None if this Mlp needs several kernels).
+        ``proj`` = (packed [d,4d] matrix, output [rows,4d]): also emit out @ P from the same launch."""
         kind, d, n_sq, head = self._plan
         if kind != "square" or head or len(self._chunks()) != 1:
             return None
+        pw, po = (proj if proj is not None else (None, None))
         return _lib.MlpTask(_lib.ptr(x), _lib.ptr(self.wb_packed(0, n_sq - 1, d)), _lib.ptr(out), _lib.ptr(acts),
-                            acts_stride, x.shape[0], n_sq, self.relu_mask(0, n_sq))
+                            acts_stride, x.shape[0], n_sq, self.relu_mask(0, n_sq), _lib.ptr(pw), _lib.ptr(po))
 
     def _chunks(self):
         kind, d, n_sq, head = self._plan

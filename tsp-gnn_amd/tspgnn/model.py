@@ -369,20 +369,23 @@ class Session(object):
     def apply_gradients(self):
         """g += 1e-10*theta; clip_by_global_norm(0.65); Adam(lr=2e-5) -- one fused pass over theta."""
         store = self.store
+        self._ensure_adam()
+        a = self._adam
+        a["step"] += 1   # host mirror; the device counter a["t"] is what the kernel uses (graph-replayable)
+        b1, b2, eps = 0.9, 0.999, 1e-8     # tf.train.AdamOptimizer defaults
+        _lib.call("tspgnn_adam_clip_step_f32", _lib.ptr(store.theta), _lib.ptr(store.grad), _lib.ptr(a["m"]),
+                  _lib.ptr(a["v"]), store.theta.numel(), L2NORM_SCALING, GLOBAL_NORM_CLIP, LEARNING_RATE, b1, b2, eps,
+                  _lib.ptr(a["gnorm"]), _lib.ptr(a["ws"]), _lib.ptr(a["t"]), _lib.current_stream())
+        store.touch()
+        return a["gnorm"]
+
+    def _ensure_adam(self):
+        store = self.store
         if self._adam is None:
             self._adam = {"m": torch.zeros_like(store.theta), "v": torch.zeros_like(store.theta), "step": 0,
                           "gnorm": torch.zeros(1, dtype=torch.float32, device=self.device),
+                          "t": torch.zeros(1, dtype=torch.int32, device=self.device),
                           "ws": _lib.workspace("tspgnn_adam_workspace_floats", device=self.device)}
-        a = self._adam
-        a["step"] += 1
-        t = a["step"]
-        b1, b2, eps = 0.9, 0.999, 1e-8     # tf.train.AdamOptimizer defaults
-        lr_t = LEARNING_RATE * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
-        _lib.call("tspgnn_adam_clip_step_f32", _lib.ptr(store.theta), _lib.ptr(store.grad), _lib.ptr(a["m"]),
-                  _lib.ptr(a["v"]), store.theta.numel(), L2NORM_SCALING, GLOBAL_NORM_CLIP, lr_t, b1, b2, eps,
-                  _lib.ptr(a["gnorm"]), _lib.ptr(a["ws"]), _lib.current_stream())
-        store.touch()
-        return a["gnorm"]
 
     def train_step(self, feed):
         """One ``sess.run(train_step)``: forward, backward, (all-reduce), L2 + clip + Adam."""
@@ -390,3 +393,32 @@ class Session(object):
         self.allreduce_grads(out["batch"].B)
         out["global_norm"] = self.apply_gradients()
         return out
+
+    def capture_train_step(self, batch):
+        """HIP-graph replay of the training step on a resident batch: graph A = zero grads + forward +
+        backward (+ re-packing of the weights, which change every step), then the gradient all-reduce
+        (eager: RCCL), then graph B = L2 + clip + Adam with the step counter on the device.  ~600 kernel
+        launches per step stop costing host time.  Returns ``replay() -> outputs``."""
+        b = batch if isinstance(batch, DeviceBatch) else self.prepare(batch)
+        self._ensure_adam()
+        self.loss_and_grads(b)                # warm-up outside the capture (allocator, caches)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=self.device)
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.store.version += 1               # force every packed-weight copy to be rebuilt INSIDE graph A
+        with torch.cuda.graph(ga, stream=side):
+            out = self.loss_and_grads(b)
+        with torch.cuda.graph(gb, stream=side):
+            gnorm = self.apply_gradients()
+        self._adam["step"] -= 1               # capture does not execute: undo the host mirror's increment
+        out["global_norm"] = gnorm
+
+        def replay():
+            ga.replay()
+            self.allreduce_grads(b.B)
+            gb.replay()
+            self._adam["step"] += 1
+            self.store.touch()
+            return out
+        replay.graphs = (ga, gb)
+        return replay
