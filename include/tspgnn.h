@@ -220,6 +220,23 @@ int tspgnn_mlp_bwd_f32(const float* dY, const float* wt, const float* acts, long
                        const float* Yout, float* dpre, long long dpre_stride, float* dX,
                        int accumulate_dx, int rows, int d, int n_layers, unsigned relu_mask, void* stream);
 
+/* Several independent backward tasks in one launch (see tspgnn_mlp_fwd_multi_f32): the edge-side and
+ * vertex-side cells / message MLPs of one step.  Task arrays live in HOST memory. */
+typedef struct tspgnn_lstm_bwd_task {
+    const float* x; int dx; const float* h; const float* c; const float* K; const float* ln;
+    const float* dh_out; const float* dc_out; float* dz; float* dc_in; float* ln_grad; float* workspace;
+    int rows;
+    const int32_t* uv; const float* Zx;   /* gather-init mode when uv != NULL: dx == 0, K = Kh */
+} tspgnn_lstm_bwd_task;   /* fields as the arguments of tspgnn_lnlstm_bwd_f32 / tspgnn_lnlstm_gather_bwd_f32 */
+
+typedef struct tspgnn_mlp_bwd_task {
+    const float* dY; const float* wt; const float* acts; long long acts_stride; const float* Yout;
+    float* dpre; long long dpre_stride; float* dX; int accumulate_dx; int rows; int n_layers; unsigned relu_mask;
+} tspgnn_mlp_bwd_task;    /* fields as the arguments of tspgnn_mlp_bwd_f32 */
+
+int tspgnn_lnlstm_bwd_multi_f32(const tspgnn_lstm_bwd_task* tasks, int n_tasks, int d, void* stream);
+int tspgnn_mlp_bwd_multi_f32(const tspgnn_mlp_bwd_task* tasks, int n_tasks, int d, void* stream);
+
 /* Workspace (floats) tspgnn_wgrad_f32 needs. */
 long long tspgnn_wgrad_workspace_floats(long long rows, int kin, int nout);
 

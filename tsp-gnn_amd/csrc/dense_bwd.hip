@@ -240,16 +240,37 @@ __device__ __forceinline__ void lstm_tile_backward(f32x4 (&acc)[D / 4], const fl
 }
 
 // LDS: [K chunk or all of K] [ln 10*D] [NW slabs of 10*D] [ticket].
+constexpr int kMaxTasks = 4;
+
+struct LstmBwdTaskTable {
+    tspgnn_lstm_bwd_task task[kMaxTasks];
+    int blk_end[kMaxTasks];  // exclusive prefix: task k owns workgroups [blk_end[k-1], blk_end[k])
+    int qc[kMaxTasks];       // 16-row blocks of K per LDS chunk (>= all of K: resident)
+    int n;
+};
+
 template <int D, int NW>
-__global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const float* __restrict__ x, int dx,
-                                                             const float* __restrict__ h, const float* __restrict__ c,
-                                                             const float* __restrict__ K, const float* __restrict__ ln,
-                                                             const float* __restrict__ dh_out,
-                                                             const float* __restrict__ dc_out_in,
-                                                             float* __restrict__ dz, float* __restrict__ dc_in,
-                                                             float* __restrict__ ln_partial, int rows, int tiles_total,
-                                                             int qc, const int2* __restrict__ uv,
-                                                             const float* __restrict__ Zx) {
+__global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const LstmBwdTaskTable tt) {
+    int k = 0;
+    while (k + 1 < tt.n && (int)blockIdx.x >= tt.blk_end[k]) ++k;
+    const int blk0 = k ? tt.blk_end[k - 1] : 0;
+    const int my_blk = blockIdx.x - blk0, my_grid = tt.blk_end[k] - blk0;
+    const float* __restrict__ x = tt.task[k].x;
+    const int dx = tt.task[k].dx;
+    const float* __restrict__ h = tt.task[k].h;
+    const float* __restrict__ c = tt.task[k].c;
+    const float* __restrict__ K = tt.task[k].K;
+    const float* __restrict__ ln = tt.task[k].ln;
+    const float* __restrict__ dh_out = tt.task[k].dh_out;
+    const float* __restrict__ dc_out_in = tt.task[k].dc_out;
+    float* __restrict__ dz = tt.task[k].dz;
+    float* __restrict__ dc_in = tt.task[k].dc_in;
+    float* __restrict__ ln_partial = tt.task[k].workspace;
+    const int rows = tt.task[k].rows;
+    const int tiles_total = (rows + 15) / 16;
+    const int qc = tt.qc[k];
+    const int2* __restrict__ uv = reinterpret_cast<const int2*>(tt.task[k].uv);
+    const float* __restrict__ Zx = tt.task[k].Zx;
     constexpr int NT4 = D / 4, TPG = D / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int QX = dx >> 4, QT = QX + TPG;
@@ -279,8 +300,8 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const float* __rest
 
     if (resident) {
         copy_to_lds(lds_k, K, (dx + D) * 4 * D, tid, blockDim.x);
-        const int t_beg = (int)((long long)tiles_total * blockIdx.x / gridDim.x);
-        const int t_end = (int)((long long)tiles_total * (blockIdx.x + 1) / gridDim.x);
+        const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
+        const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
         if (tid == 0) *ticket = t_beg;
         __syncthreads();
         for (;;) {
@@ -310,7 +331,7 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const float* __rest
     } else {
         __syncthreads();
         const int rounds = (tiles_total + nw - 1) / nw;
-        for (int r = blockIdx.x; r < rounds; r += gridDim.x) {
+        for (int r = my_blk; r < rounds; r += my_grid) {
             const int tile = r * nw + wave;
             const bool live = tile < tiles_total;
             const int row = tile * 16 + rl;
@@ -334,7 +355,7 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const float* __rest
     for (int i = tid; i < 10 * D; i += blockDim.x) {
         float s = 0.f;
         for (int w = 0; w < nw; ++w) s += slabs[w * 10 * D + i];
-        ln_partial[(size_t)blockIdx.x * 10 * D + i] = s;
+        ln_partial[(size_t)my_blk * 10 * D + i] = s;
     }
 }
 
@@ -373,19 +394,37 @@ void reduce_partials(const float* partial, int n_chunks, long long stride, float
 // ------------------------------------------------------------------------------------ MLP backward (data)
 // g = dY; for l = L-1 .. 0:  g *= [A_l > 0] if layer l had relu;  dPre_l = g;  g = g W_l^T.   dX (+)= g.
 // A_l for l < L-1 comes from the saved activations, A_{L-1} (only if the last layer has relu) from Yout.
+struct MlpBwdTaskTable {
+    tspgnn_mlp_bwd_task task[kMaxTasks];
+    int blk_end[kMaxTasks];
+    int n;
+};
+
 template <int D, int MAXL>
-__global__ __launch_bounds__(512) void mlp_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ wt,
-                                                      const float* __restrict__ acts, long long acts_stride,
-                                                      const float* __restrict__ Yout, float* __restrict__ dpre,
-                                                      long long dpre_stride, float* __restrict__ dX, int acc_dx,
-                                                      int rows, int n_layers, unsigned relu_mask, int tiles_total) {
+__global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdTaskTable tt) {
+    int k = 0;
+    while (k + 1 < tt.n && (int)blockIdx.x >= tt.blk_end[k]) ++k;
+    const int blk0 = k ? tt.blk_end[k - 1] : 0;
+    const int my_blk = blockIdx.x - blk0, my_grid = tt.blk_end[k] - blk0;
+    const float* __restrict__ dY = tt.task[k].dY;
+    const float* __restrict__ wt = tt.task[k].wt;
+    const float* __restrict__ acts = tt.task[k].acts;
+    const long long acts_stride = tt.task[k].acts_stride;
+    const float* __restrict__ Yout = tt.task[k].Yout;
+    float* __restrict__ dpre = tt.task[k].dpre;
+    const long long dpre_stride = tt.task[k].dpre_stride;
+    float* __restrict__ dX = tt.task[k].dX;
+    const int acc_dx = tt.task[k].accumulate_dx;
+    const int rows = tt.task[k].rows, n_layers = tt.task[k].n_layers;
+    const unsigned relu_mask = tt.task[k].relu_mask;
+    const int tiles_total = (rows + 15) / 16;
     constexpr int NT = D / 16;
     __shared__ __attribute__((aligned(16))) float lds[MAXL * D * D + 4];
     int* ticket = reinterpret_cast<int*>(lds + MAXL * D * D);
     const int tid = threadIdx.x;
     copy_to_lds(lds, wt, n_layers * D * D, tid, blockDim.x);
-    const int t_beg = (int)((long long)tiles_total * blockIdx.x / gridDim.x);
-    const int t_end = (int)((long long)tiles_total * (blockIdx.x + 1) / gridDim.x);
+    const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
+    const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
     if (tid == 0) *ticket = t_beg;
     __syncthreads();
     const int lane = tid & 63, rl = lane & 15, g = lane >> 4;
@@ -581,53 +620,92 @@ static int launch_linear(const float* X, int kin, const float* Wp, float* Y1, in
     return launched("tspgnn_linear_f32");
 }
 
+// Workgroups per task, proportional to cost[k] (at least one each); returns the grid.
+static int split_blocks_bwd(const long long* cost, int n, int grid, int* blk_end) {
+    long long total = 0;
+    for (int k = 0; k < n; ++k) total += cost[k] > 0 ? cost[k] : 1;
+    if (grid < n) grid = n;
+    int used = 0;
+    for (int k = 0; k < n; ++k) {
+        const long long ck = cost[k] > 0 ? cost[k] : 1;
+        int bk = (int)((ck * grid + total / 2) / total);
+        if (bk < 1) bk = 1;
+        used += bk;
+        blk_end[k] = used;
+    }
+    return used;
+}
+
 template <int D>
-static int launch_lnlstm_bwd(const float* x, int dx, const float* h, const float* c, const float* K, const float* ln,
-                             const float* dh_out, const float* dc_out, float* dz, float* dc_in, float* ln_grad,
-                             float* workspace, int rows, const int32_t* uv, const float* Zx, hipStream_t st) {
+static int launch_lnlstm_bwd(const tspgnn_lstm_bwd_task* tasks, int n, hipStream_t st) {
     // D=128 keeps 4D/16 + temporaries > 256 registers live: one wavefront per SIMD (512-register budget).
     constexpr int NWMAX = D >= 128 ? 4 : 8;
-    const int tiles = (rows + 15) / 16;
-    const int QT = (dx + D) / 16;
     const size_t per_q = (size_t)16 * 4 * D * sizeof(float);
-    int nw = NWMAX;
     auto extra = [&](int nw_) { return (size_t)(10 * D + nw_ * 10 * D + 4) * sizeof(float); };
-    int qc = QT;
-    if ((size_t)QT * per_q + extra(NWMAX) > 160 * 1024) {
-        qc = (int)((160 * 1024 - extra(NWMAX)) / per_q);
-        if (qc < 1 || uv != nullptr) return fail(TSPGNN_EUNSUPPORTED, "lnlstm_bwd: d=%d does not fit LDS", D);
-    } else if (tiles <= n_cus() * 4) {
-        nw = 4;
+    LstmBwdTaskTable tt;
+    long long cost[kMaxTasks];
+    long long tiles_all = 0;
+    size_t lds_k = 0;
+    bool any_chunked = false;
+    for (int k = 0; k < n; ++k) {
+        tt.task[k] = tasks[k];
+        const int QT = (tasks[k].dx + D) / 16;
+        int qc = QT;
+        if ((size_t)QT * per_q + extra(NWMAX) > 160 * 1024) {
+            qc = (int)((160 * 1024 - extra(NWMAX)) / per_q);
+            if (qc < 1 || tasks[k].uv) return fail(TSPGNN_EUNSUPPORTED, "lnlstm_bwd: d=%d does not fit LDS", D);
+            any_chunked = true;
+        }
+        tt.qc[k] = qc;
+        if ((size_t)qc * per_q > lds_k) lds_k = (size_t)qc * per_q;
+        const long long tiles = ((long long)tasks[k].rows + 15) / 16;
+        cost[k] = tiles * (QT + 8);  // k-blocks + ~8 blocks' worth of elementwise backward
+        tiles_all += tiles;
     }
-    const size_t lds_bytes = (size_t)qc * per_q + extra(nw);
+    tt.n = n;
+    int nw = NWMAX;
+    if (!any_chunked && tiles_all <= (long long)n_cus() * 4) nw = 4;
+    const size_t lds_bytes = lds_k + extra(nw);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlstm_bwd_kernel<D, NWMAX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail((int)e, "lnlstm_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     int grid = n_cus();
-    const int max_grid = (tiles + nw - 1) / nw;
-    if (grid > max_grid) grid = max_grid;
-    lnlstm_bwd_kernel<D, NWMAX><<<grid, nw * 64, lds_bytes, st>>>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in,
-                                                                  workspace, rows, tiles, qc,
-                                                                  reinterpret_cast<const int2*>(uv), Zx);
+    const long long max_grid = (tiles_all + nw - 1) / nw;
+    if (grid > max_grid) grid = (int)max_grid;
+    grid = split_blocks_bwd(cost, n, grid, tt.blk_end);
+    lnlstm_bwd_kernel<D, NWMAX><<<grid, nw * 64, lds_bytes, st>>>(tt);
     int rc = launched("tspgnn_lnlstm_bwd_f32");
     if (rc) return rc;
-    reduce_partials(workspace, grid, 10 * D, ln_grad, 10 * D, 1.0f, 1, st);
-    return launched("tspgnn_lnlstm_bwd_f32(reduce)");
+    for (int k = 0; k < n; ++k) {
+        const int nblk = tt.blk_end[k] - (k ? tt.blk_end[k - 1] : 0);
+        reduce_partials(tasks[k].workspace, nblk, 10 * D, tasks[k].ln_grad, 10 * D, 1.0f, 1, st);
+        if ((rc = launched("tspgnn_lnlstm_bwd_f32(reduce)"))) return rc;
+    }
+    return TSPGNN_OK;
 }
 
 template <int D, int MAXL>
-static int launch_mlp_bwd(const float* dY, const float* wt, const float* acts, long long acts_stride,
-                          const float* Yout, float* dpre, long long dpre_stride, float* dX, int acc_dx, int rows,
-                          int n_layers, unsigned relu_mask, hipStream_t st) {
-    const int tiles = (rows + 15) / 16;
+static int launch_mlp_bwd(const tspgnn_mlp_bwd_task* tasks, int n, hipStream_t st) {
+    MlpBwdTaskTable tt;
+    long long cost[kMaxTasks];
+    long long tiles_all = 0;
+    for (int k = 0; k < n; ++k) {
+        tt.task[k] = tasks[k];
+        if (tt.task[k].acts && tt.task[k].acts_stride == 0) tt.task[k].acts_stride = (long long)tasks[k].rows * D;
+        if (tt.task[k].dpre && tt.task[k].dpre_stride == 0) tt.task[k].dpre_stride = (long long)tasks[k].rows * D;
+        const long long tiles = ((long long)tasks[k].rows + 15) / 16;
+        cost[k] = tiles * tasks[k].n_layers;
+        tiles_all += tiles;
+    }
+    tt.n = n;
     const int lds_bytes = MAXL * D * D * 4 + 16;
     const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
     int grid = n_cus() * per_cu;
-    const int nw = tiles <= grid * 4 ? 4 : 8;
-    const int max_grid = (tiles + nw - 1) / nw;
-    if (grid > max_grid) grid = max_grid;
-    mlp_bwd_kernel<D, MAXL><<<grid, nw * 64, 0, st>>>(dY, wt, acts, acts_stride, Yout, dpre, dpre_stride, dX, acc_dx,
-                                                       rows, n_layers, relu_mask, tiles);
+    const int nw = tiles_all <= (long long)grid * 4 ? 4 : 8;
+    const long long max_grid = (tiles_all + nw - 1) / nw;
+    if (grid > max_grid) grid = (int)max_grid;
+    grid = split_blocks_bwd(cost, n, grid, tt.blk_end);
+    mlp_bwd_kernel<D, MAXL><<<grid, nw * 64, 0, st>>>(tt);
     return launched("tspgnn_mlp_bwd_f32");
 }
 
@@ -663,74 +741,82 @@ extern "C" int tspgnn_linear_f32(const float* X, int kin, const float* Wp, float
     }
 }
 
-extern "C" long long tspgnn_lnlstm_bwd_workspace_floats(int d) { return (long long)n_cus() * 10 * d; }
+extern "C" long long tspgnn_lnlstm_bwd_workspace_floats(int d) { return (long long)(n_cus() + 8) * 10 * d; }
+
+extern "C" int tspgnn_lnlstm_bwd_multi_f32(const tspgnn_lstm_bwd_task* tasks, int n_tasks, int d, void* stream) {
+    TSPGNN_REQUIRE(tasks && n_tasks >= 1 && n_tasks <= kMaxTasks, "lnlstm_bwd_multi: 1..%d tasks", kMaxTasks);
+    TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "lnlstm_bwd: d=%d must be 32, 64 or 128", d);
+    tspgnn_lstm_bwd_task live[kMaxTasks];
+    int n = 0;
+    for (int k = 0; k < n_tasks; ++k) {
+        const tspgnn_lstm_bwd_task& t = tasks[k];
+        TSPGNN_REQUIRE(t.rows >= 0, "lnlstm_bwd: rows=%d", t.rows);
+        TSPGNN_REQUIRE(t.dx >= 0 && t.dx % 16 == 0, "lnlstm_bwd: dx=%d must be a non-negative multiple of 16", t.dx);
+        if (t.rows == 0) continue;
+        TSPGNN_REQUIRE(t.h && t.c && t.K && t.ln && t.dz && t.dc_in && t.ln_grad && t.workspace && (t.dx == 0 || t.x),
+                       "lnlstm_bwd: null pointer");
+        TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx && (d == 32 || d == 64)),
+                       "lnlstm_bwd: gather-init mode needs dx == 0, Zx and d in {32,64}");
+        live[n++] = t;
+    }
+    if (n == 0) return TSPGNN_OK;
+    hipStream_t st = as_stream(stream);
+    switch (d) {
+        case 32: return launch_lnlstm_bwd<32>(live, n, st);
+        case 64: return launch_lnlstm_bwd<64>(live, n, st);
+        default: return launch_lnlstm_bwd<128>(live, n, st);
+    }
+}
 
 extern "C" int tspgnn_lnlstm_bwd_f32(const float* x, int dx, const float* h, const float* c, const float* K,
                                      const float* ln, const float* dh_out, const float* dc_out, float* dz,
                                      float* dc_in, float* ln_grad, float* workspace, int rows, int d, void* stream) {
-    TSPGNN_REQUIRE(rows >= 0, "lnlstm_bwd: rows=%d", rows);
-    TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "lnlstm_bwd: d=%d must be 32, 64 or 128", d);
-    TSPGNN_REQUIRE(dx >= 0 && dx % 16 == 0, "lnlstm_bwd: dx=%d must be a non-negative multiple of 16", dx);
-    if (rows == 0) return TSPGNN_OK;
-    TSPGNN_REQUIRE(h && c && K && ln && dz && dc_in && ln_grad && workspace && (dx == 0 || x),
-                   "lnlstm_bwd: null pointer");
-    hipStream_t st = as_stream(stream);
-    switch (d) {
-        case 32:
-            return launch_lnlstm_bwd<32>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, nullptr,
-                                         nullptr, st);
-        case 64:
-            return launch_lnlstm_bwd<64>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, nullptr,
-                                         nullptr, st);
-        default:
-            return launch_lnlstm_bwd<128>(x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows,
-                                          nullptr, nullptr, st);
-    }
+    const tspgnn_lstm_bwd_task t = {x, dx, h, c, K, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, nullptr, nullptr};
+    return tspgnn_lnlstm_bwd_multi_f32(&t, 1, d, stream);
 }
 
 extern "C" int tspgnn_lnlstm_gather_bwd_f32(const int32_t* uv, const float* Zx, const float* h, const float* c,
                                             const float* Kh, const float* ln, const float* dh_out, const float* dc_out,
                                             float* dz, float* dc_in, float* ln_grad, float* workspace, int rows, int d,
                                             void* stream) {
-    TSPGNN_REQUIRE(rows >= 0, "lnlstm_gather_bwd: rows=%d", rows);
-    TSPGNN_REQUIRE(d == 32 || d == 64, "lnlstm_gather_bwd: d=%d must be 32 or 64", d);
-    if (rows == 0) return TSPGNN_OK;
-    TSPGNN_REQUIRE(uv && Zx && h && c && Kh && ln && dz && dc_in && ln_grad && workspace,
-                   "lnlstm_gather_bwd: null pointer");
+    TSPGNN_REQUIRE(rows == 0 || (uv && Zx), "lnlstm_gather_bwd: null pointer");
+    const tspgnn_lstm_bwd_task t = {nullptr, 0, h, c, Kh, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, uv, Zx};
+    return tspgnn_lnlstm_bwd_multi_f32(&t, 1, d, stream);
+}
+
+extern "C" int tspgnn_mlp_bwd_multi_f32(const tspgnn_mlp_bwd_task* tasks, int n_tasks, int d, void* stream) {
+    TSPGNN_REQUIRE(tasks && n_tasks >= 1 && n_tasks <= kMaxTasks, "mlp_bwd_multi: 1..%d tasks", kMaxTasks);
+    TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "mlp_bwd: d=%d must be 32, 64 or 128", d);
+    tspgnn_mlp_bwd_task live[kMaxTasks];
+    int n = 0;
+    for (int k = 0; k < n_tasks; ++k) {
+        const tspgnn_mlp_bwd_task& t = tasks[k];
+        TSPGNN_REQUIRE(t.rows >= 0, "mlp_bwd: rows=%d", t.rows);
+        TSPGNN_REQUIRE(t.n_layers >= 1 && t.n_layers <= 4, "mlp_bwd: n_layers=%d must be in 1..4", t.n_layers);
+        if (d == 128 && t.n_layers > 2)
+            return fail(TSPGNN_EUNSUPPORTED, "mlp_bwd: d=128 holds at most 2 layers in LDS (got %d)", t.n_layers);
+        if (t.rows == 0) continue;
+        TSPGNN_REQUIRE(t.dY && t.wt, "mlp_bwd: null pointer");
+        const unsigned inner = t.relu_mask & ((1u << (t.n_layers - 1)) - 1u);
+        TSPGNN_REQUIRE(!inner || t.acts, "mlp_bwd: relu layers need the saved activations");
+        TSPGNN_REQUIRE(!((t.relu_mask >> (t.n_layers - 1)) & 1u) || t.Yout, "mlp_bwd: relu on the last layer needs Yout");
+        live[n++] = t;
+    }
+    if (n == 0) return TSPGNN_OK;
     hipStream_t st = as_stream(stream);
-    if (d == 32)
-        return launch_lnlstm_bwd<32>(nullptr, 0, h, c, Kh, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, uv, Zx,
-                                     st);
-    return launch_lnlstm_bwd<64>(nullptr, 0, h, c, Kh, ln, dh_out, dc_out, dz, dc_in, ln_grad, workspace, rows, uv, Zx, st);
+    switch (d) {
+        case 32: return launch_mlp_bwd<32, 4>(live, n, st);
+        case 64: return launch_mlp_bwd<64, 4>(live, n, st);
+        default: return launch_mlp_bwd<128, 2>(live, n, st);
+    }
 }
 
 extern "C" int tspgnn_mlp_bwd_f32(const float* dY, const float* wt, const float* acts, long long acts_stride,
                                   const float* Yout, float* dpre, long long dpre_stride, float* dX, int accumulate_dx,
                                   int rows, int d, int n_layers, unsigned relu_mask, void* stream) {
-    TSPGNN_REQUIRE(rows >= 0, "mlp_bwd: rows=%d", rows);
-    TSPGNN_REQUIRE(n_layers >= 1 && n_layers <= 4, "mlp_bwd: n_layers=%d must be in 1..4", n_layers);
-    TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "mlp_bwd: d=%d must be 32, 64 or 128", d);
-    if (rows == 0) return TSPGNN_OK;
-    TSPGNN_REQUIRE(dY && wt, "mlp_bwd: null pointer");
-    const unsigned inner = relu_mask & ((1u << (n_layers - 1)) - 1u);
-    TSPGNN_REQUIRE(!inner || acts, "mlp_bwd: relu layers need the saved activations");
-    TSPGNN_REQUIRE(!((relu_mask >> (n_layers - 1)) & 1u) || Yout, "mlp_bwd: relu on the last layer needs Yout");
-    if (acts && acts_stride == 0) acts_stride = (long long)rows * d;
-    if (dpre && dpre_stride == 0) dpre_stride = (long long)rows * d;
-    hipStream_t st = as_stream(stream);
-    switch (d) {
-        case 32:
-            return launch_mlp_bwd<32, 4>(dY, wt, acts, acts_stride, Yout, dpre, dpre_stride, dX, accumulate_dx, rows,
-                                         n_layers, relu_mask, st);
-        case 64:
-            return launch_mlp_bwd<64, 4>(dY, wt, acts, acts_stride, Yout, dpre, dpre_stride, dX, accumulate_dx, rows,
-                                         n_layers, relu_mask, st);
-        default:
-            if (n_layers > 2)
-                return fail(TSPGNN_EUNSUPPORTED, "mlp_bwd: d=128 holds at most 2 layers in LDS (got %d)", n_layers);
-            return launch_mlp_bwd<128, 2>(dY, wt, acts, acts_stride, Yout, dpre, dpre_stride, dX, accumulate_dx, rows,
-                                          n_layers, relu_mask, st);
-    }
+    const tspgnn_mlp_bwd_task t = {dY, wt, acts, acts_stride, Yout, dpre, dpre_stride, dX, accumulate_dx, rows, n_layers,
+                                   relu_mask};
+    return tspgnn_mlp_bwd_multi_f32(&t, 1, d, stream);
 }
 
 extern "C" long long tspgnn_wgrad_workspace_floats(long long rows, int kin, int nout) {

@@ -33,6 +33,8 @@ SIGNATURES = {
                               c_int, c_void_p],
     "tspgnn_mlp_fwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_fwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_lnlstm_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_mlp_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_gather_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_gather_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -76,6 +78,20 @@ class LstmTask(ctypes.Structure):
     """tspgnn_lstm_task (include/tspgnn.h)."""
     _fields_ = [("x", c_void_p), ("dx", c_int), ("h", c_void_p), ("c", c_void_p), ("K", c_void_p), ("ln", c_void_p),
                 ("h_out", c_void_p), ("c_out", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p)]
+
+
+class LstmBwdTask(ctypes.Structure):
+    """tspgnn_lstm_bwd_task (include/tspgnn.h)."""
+    _fields_ = [("x", c_void_p), ("dx", c_int), ("h", c_void_p), ("c", c_void_p), ("K", c_void_p), ("ln", c_void_p),
+                ("dh_out", c_void_p), ("dc_out", c_void_p), ("dz", c_void_p), ("dc_in", c_void_p), ("ln_grad", c_void_p),
+                ("workspace", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p)]
+
+
+class MlpBwdTask(ctypes.Structure):
+    """tspgnn_mlp_bwd_task (include/tspgnn.h)."""
+    _fields_ = [("dY", c_void_p), ("wt", c_void_p), ("acts", c_void_p), ("acts_stride", c_longlong), ("Yout", c_void_p),
+                ("dpre", c_void_p), ("dpre_stride", c_longlong), ("dX", c_void_p), ("accumulate_dx", c_int),
+                ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint)]
 
 
 class TspgnnError(RuntimeError):

@@ -230,6 +230,30 @@ class LayerNormBasicLSTMCell(object):
                   self.d, _lib.current_stream())
         return h_out, LSTMStateTuple(c=c_out, h=h_out)
 
+    def backward_task(self, x, h, c, dh_out, dc_out, dz, dc_in, ws):
+        return _lib.LstmBwdTask(_lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(self.kernel_packed()),
+                                _lib.ptr(self.ln()), _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in),
+                                _lib.ptr(self.ln_grad()), _lib.ptr(ws), h.shape[0], None, None)
+
+    def gather_backward_task(self, adj, zx, h, c, dh_out, dc_out, dz, dc_in, ws):
+        return _lib.LstmBwdTask(None, 0, _lib.ptr(h), _lib.ptr(c), _lib.ptr(self.kh_packed()), _lib.ptr(self.ln()),
+                                _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in),
+                                _lib.ptr(self.ln_grad()), _lib.ptr(ws), h.shape[0], _lib.ptr(adj.uv), _lib.ptr(zx))
+
+    def backward_data(self, dz, dx_out, dh_in):
+        """[dx | dh] = dz K^T."""
+        _lib.call("tspgnn_linear_f32", _lib.ptr(dz), 4 * self.d, _lib.ptr(self.kernel_t_packed()), _lib.ptr(dx_out),
+                  self.dx, _lib.ptr(dh_in), self.d, 0, dz.shape[0], _lib.current_stream())
+
+    def gather_backward_data(self, adj, dz, dh_in, dzx, dy):
+        """dh = dz Kh^T, dZx = EV^T dz, dy = dZx Kx^T (folded cell)."""
+        st = _lib.current_stream()
+        _lib.call("tspgnn_linear_f32", _lib.ptr(dz), 4 * self.d, _lib.ptr(self.kh_t_packed()), None, 0, _lib.ptr(dh_in),
+                  self.d, 0, dz.shape[0], st)
+        adj.matmul(dz, transpose=True, out=dzx)
+        _lib.call("tspgnn_linear_f32", _lib.ptr(dzx), 4 * self.d, _lib.ptr(self.kx_t_packed()), None, 0, _lib.ptr(dy),
+                  self.dx, 0, dzx.shape[0], st)
+
     def gather_backward(self, adj, zx, h, c, dh_out, dc_out, dz, dc_in, dh_in, dzx, dy, ws):
         """Backward of gather_call + premultiply: dz, dc_in, dh_in = dz Kh^T, dzx = EV^T dz, dy = dzx Kx^T."""
         rows, st = h.shape[0], _lib.current_stream()
@@ -710,14 +734,29 @@ class GraphNN(object):
             ndH = {v: torch.empty((n[v], d), **f32) for v, d in self.var.items()}
             ndC = {v: torch.empty((n[v], d), **f32) for v, d in self.var.items()}
             dX = {v: torch.empty((tape.X[v].shape[1], self._RNN_cells[v].dx), **f32) for v in self.var}
-            for v in self.var:   # all cells first: they WRITE dh; the message paths below ACCUMULATE into it
+            # ---- 1: every cell's backward (recompute z, LayerNorm / gate gradients) in one launch per width
+            tasks = {}
+            for v, d in self.var.items():
                 cell = self._RNN_cells[v]
-                if folded[v] is not None:   # dX[v] is already the gradient w.r.t. the message y (source rows)
-                    cell.gather_backward(mats[folded[v]["mat"]], tape.ZX[v][t], tape.H[v][t], tape.C[v][t], dH[v], dC[v],
-                                         DZ[v][t], ndC[v], ndH[v], DZX[v][t], dX[v], ws[v])
+                if folded[v] is not None:
+                    task = cell.gather_backward_task(mats[folded[v]["mat"]], tape.ZX[v][t], tape.H[v][t], tape.C[v][t],
+                                                     dH[v], dC[v], DZ[v][t], ndC[v], ws[v])
                 else:
-                    cell.backward(tape.X[v][t], tape.H[v][t], tape.C[v][t], dH[v], dC[v], DZ[v][t], ndC[v], dX[v],
-                                  ndH[v], ws[v])
+                    task = cell.backward_task(tape.X[v][t], tape.H[v][t], tape.C[v][t], dH[v], dC[v], DZ[v][t], ndC[v],
+                                              ws[v])
+                tasks.setdefault(d, []).append(task)
+            for d, ts in tasks.items():
+                for k in range(0, len(ts), 4):
+                    _lib.call_multi("tspgnn_lnlstm_bwd_multi_f32", ts[k:k + 4], d)
+            # ---- 2: data gradients of the cell GEMMs; these WRITE dh, the message paths below ACCUMULATE into it
+            for v in self.var:
+                cell = self._RNN_cells[v]
+                if folded[v] is not None:   # dX[v] becomes the gradient w.r.t. the message y (source rows)
+                    cell.gather_backward_data(mats[folded[v]["mat"]], DZ[v][t], ndH[v], DZX[v][t], dX[v])
+                else:
+                    cell.backward_data(DZ[v][t], dX[v], ndH[v])
+            # ---- 3: adjoint adjacency products, then every message MLP's data gradient in one launch
+            mlp_tasks, targets = [], []
             for v in self.var:
                 off = 0
                 for i, u in enumerate(self.loop[v]):
@@ -730,10 +769,22 @@ class GraphNN(object):
                     if "msg" in u:
                         mlp = self._msg_MLPs[u["msg"]]
                         acts, dpre = tape.acts[(v, i)], DPRE[(v, i)]
-                        mlp.backward_data(dy, acts[:, t], acts.stride(0), None, dpre[:, t], dpre.stride(0), ndH[src],
-                                          accumulate=True)
+                        task = mlp.backward_task(dy, acts[:, t], acts.stride(0), None, dpre[:, t], dpre.stride(0),
+                                                 ndH[src], True)
+                        if task is None or src in targets:   # several kernels, or a second writer of ndH[src]
+                            mlp.backward_data(dy, acts[:, t], acts.stride(0), None, dpre[:, t], dpre.stride(0), ndH[src],
+                                              accumulate=True)
+                        else:
+                            mlp_tasks.append((self.var[src], task, dy))
+                            targets.append(src)
                     else:
                         ndH[src].add_(dy)
+            by_d = {}
+            for d, task, _ in mlp_tasks:
+                by_d.setdefault(d, []).append(task)
+            for d, ts in by_d.items():
+                for k in range(0, len(ts), 4):
+                    _lib.call_multi("tspgnn_mlp_bwd_multi_f32", ts[k:k + 4], d)
             dH, dC = ndH, ndC
         # weight gradients: one reduction per variable over all T steps
         for v, d in self.var.items():

@@ -174,6 +174,15 @@ class Mlp(object):
                       _lib.ptr(dst), 1 if (accumulate and first) else 0, rows, d, n, self.relu_mask(l0, n), st)
             g = dst
 
+    def backward_task(self, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate):
+        """An _lib.MlpBwdTask for a single-kernel chain (None if several kernels are needed)."""
+        kind, d, n_sq, head = self._plan
+        if len(self._chunks()) != 1:
+            return None
+        return _lib.MlpBwdTask(_lib.ptr(dY), _lib.ptr(self.wt_packed(0, n_sq - 1, d)), _lib.ptr(acts), acts_stride,
+                               _lib.ptr(y_out), _lib.ptr(dpre), dpre_stride, _lib.ptr(dX), 1 if accumulate else 0,
+                               dY.shape[0], n_sq, self.relu_mask(0, n_sq))
+
     def backward_weights(self, layer_inputs, layer_dpre, rows):
         """dW_l += X_l^T dPre_l, db_l += colsum(dPre_l) for the square layers; ``rows`` may span all
         time steps (inputs / dpre are [T*rows_per_step, d] contiguous)."""
