@@ -138,6 +138,8 @@ typedef struct tspgnn_lstm_task {
     const float* x; int dx; const float* h; const float* c; const float* K; const float* ln;
     float* h_out; float* c_out; int rows;
     const int32_t* uv; const float* Zx;   /* gather-init mode when uv != NULL: dx == 0, K = Kh */
+    const float* zbias; const float* zscale; /* optional: z starts at zscale[row] * zbias[4d] (a bias folded
+                                                through a row-sum aggregation: degree * (b Kx)) */
 } tspgnn_lstm_task;  /* fields as the arguments of tspgnn_lnlstm_fwd_f32 / tspgnn_lnlstm_gather_fwd_f32 */
 
 int tspgnn_mlp_fwd_multi_f32(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream);

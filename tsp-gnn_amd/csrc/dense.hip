@@ -254,6 +254,8 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_kernel(const LstmTaskTable
     const int rows = tt.task[k].rows;
     const int2* __restrict__ uv = reinterpret_cast<const int2*>(tt.task[k].uv);
     const float* __restrict__ Zx = tt.task[k].Zx;
+    const float* __restrict__ zbias = tt.task[k].zbias;
+    const float* __restrict__ zscale = tt.task[k].zscale;
     const int tiles_total = (rows + 15) / 16;
 
     const int krows = dx + D;
@@ -288,6 +290,12 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_kernel(const LstmTaskTable
             for (int t = 0; t < NT4; ++t) acc[t] = ld4(zu + t * 16);
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] += ld4(zv + t * 16);
+        } else if (zbias != nullptr) {
+            // z starts at zscale[row] * zbias: the bias of a message MLP's last layer pushed through the
+            // aggregation (row-sum of (a W + b) = (row-sum a) W + degree * b) and through K_x.
+            const float sc = zscale[rc];
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] = ld4(zbias + t * 16 + g * 4) * sc;
         } else {
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -415,7 +423,8 @@ static int launch_lnlstm(const tspgnn_lstm_task* tasks, int n, hipStream_t st) {
     }
     if (!all_fit) {  // a K that does not fit LDS: one chunked launch per task
         for (int k = 0; k < n; ++k) {
-            if (tasks[k].uv) return fail(TSPGNN_EUNSUPPORTED, "lnlstm_gather_fwd: K_h[%d,%d] does not fit LDS", D, 4 * D);
+            if (tasks[k].uv || tasks[k].zbias)
+                return fail(TSPGNN_EUNSUPPORTED, "lnlstm_fwd: gather-init / zbias need K[%d,%d] resident in LDS", D, 4 * D);
             const int rc = launch_lnlstm_chunked<D>(tasks[k], st);
             if (rc) return rc;
         }
@@ -462,6 +471,7 @@ static int check_lstm_task(const tspgnn_lstm_task& t, int d) {
     TSPGNN_REQUIRE(t.h_out != t.h && t.c_out != t.c, "lnlstm_fwd: outputs may not alias inputs");
     TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx && (d == 32 || d == 64)),
                    "lnlstm_fwd: gather-init mode needs dx == 0, Zx and d in {32,64}");
+    TSPGNN_REQUIRE(!t.zbias || (t.zscale && !t.uv), "lnlstm_fwd: zbias needs zscale and excludes gather-init mode");
     return TSPGNN_OK;
 }
 
@@ -530,7 +540,7 @@ extern "C" int tspgnn_lnlstm_fwd_multi_f32(const tspgnn_lstm_task* tasks, int n_
 
 extern "C" int tspgnn_lnlstm_fwd_f32(const float* x, int dx, const float* h, const float* c, const float* K,
                                      const float* ln, float* h_out, float* c_out, int rows, int d, void* stream) {
-    const tspgnn_lstm_task t = {x, dx, h, c, K, ln, h_out, c_out, rows, nullptr, nullptr};
+    const tspgnn_lstm_task t = {x, dx, h, c, K, ln, h_out, c_out, rows, nullptr, nullptr, nullptr, nullptr};
     return tspgnn_lnlstm_fwd_multi_f32(&t, 1, d, stream);
 }
 
@@ -539,6 +549,6 @@ extern "C" int tspgnn_lnlstm_gather_fwd_f32(const int32_t* uv, const float* Zx, 
                                             int n_src, int d, void* stream) {
     TSPGNN_REQUIRE(n_src >= 0, "lnlstm_gather_fwd: n_src=%d", n_src);
     TSPGNN_REQUIRE(rows == 0 || (uv && Zx), "lnlstm_gather_fwd: null pointer");
-    const tspgnn_lstm_task t = {nullptr, 0, h, c, Kh, ln, h_out, c_out, rows, uv, Zx};
+    const tspgnn_lstm_task t = {nullptr, 0, h, c, Kh, ln, h_out, c_out, rows, uv, Zx, nullptr, nullptr};
     return tspgnn_lnlstm_fwd_multi_f32(&t, 1, d, stream);
 }

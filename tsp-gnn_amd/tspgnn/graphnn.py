@@ -206,12 +206,43 @@ class LayerNormBasicLSTMCell(object):
 
     def task(self, x, state, out):
         return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(self.kernel_packed()),
-                             _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None)
+                             _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None,
+                             None, None)
 
     def gather_task(self, adj, zx, state, out):
         return _lib.LstmTask(None, 0, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(self.kh_packed()),
                              _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0],
-                             _lib.ptr(adj.uv), _lib.ptr(zx))
+                             _lib.ptr(adj.uv), _lib.ptr(zx), None, None)
+
+    def pushed_bias_pack(self, mlp):
+        """For a cell whose input is a row-sum aggregation of ``mlp``'s output: the message MLP's last
+        (linear) layer W,b pushed through the aggregation and through Kx:
+            (sum_e (a_e W + b)) Kx = (sum_e a_e) (W Kx) + degree (b Kx)
+        Returns (pack([W Kx ; Kh]), b Kx): the cell then takes the row-sum of the LAST HIDDEN activation as
+        its input and starts z at degree * (b Kx).  One Dense(d) layer less on every edge row per step."""
+        d, dx = self.d, self.dx
+        last = mlp.layer_names[-1]
+
+        def build(out):
+            W, b = self.store.view(last + "/kernel"), self.store.view(last + "/bias")
+            if out is None:
+                out = (torch.empty((dx + d, 4 * d), dtype=torch.float32, device=W.device),
+                       torch.empty((1, 4 * d), dtype=torch.float32, device=W.device))
+            kp, zb = out
+            st = _lib.current_stream()
+            kfull = torch.empty((dx + d, 4 * d), dtype=torch.float32, device=W.device)
+            kfull[dx:].copy_(self.kernel()[dx:])
+            _lib.call("tspgnn_linear_f32", _lib.ptr(W), dx, _lib.ptr(self.kx_packed()), None, 0, _lib.ptr(kfull[:dx]),
+                      4 * d, 0, W.shape[0], st)
+            _lib.call("tspgnn_linear_f32", _lib.ptr(b.view(1, -1)), dx, _lib.ptr(self.kx_packed()), None, 0, _lib.ptr(zb),
+                      4 * d, 0, 1, st)
+            _lib.call("tspgnn_pack_weights_f32", _lib.ptr(kfull), _lib.ptr(kp), dx + d, 4 * d, 0, st)
+            return (kp, zb)
+        return self.store.packed(("lstm.pushed", self.base, last), build)
+
+    def pushed_task(self, x, state, out, kp, zb, deg):
+        return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(kp), _lib.ptr(self.ln()),
+                             _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None, _lib.ptr(zb), _lib.ptr(deg))
 
     def premultiply(self, y, out=None):
         """Zx = y Kx  ([n_src, 4d])."""
@@ -413,6 +444,21 @@ class GraphNN(object):
                 raise ValueError("Matrix {m} doesn't have the same number of nodes as the initial embeddings of "
                                  "its variable {v}".format(v=v2, m=mat))
 
+    def _pushable(self, v, mats, folded):
+        """True if v's cell input is a pattern (all-ones) adjacency product of a message MLP whose last
+        layer is linear: that layer can be pushed through the row-sum into the cell (pushed_bias_pack)."""
+        if not self.fold_adjacency or folded[v] is not None or len(self.loop[v]) != 1:
+            return False
+        u = self.loop[v][0]
+        if "var" not in u or "fun" in u or "mat" not in u or "msg" not in u:
+            return False
+        mlp, cell = self._msg_MLPs[u["msg"]], self._RNN_cells[v]
+        adj = mats[u["mat"]]
+        csr = adj.csr_t if u.get("transpose?", False) else adj.csr
+        if csr[2] is not None or mlp.relu[-1] or mlp.n_square < 2 or len(mlp._chunks()) != 1:
+            return False
+        return cell.d == 64 and cell.dx == 64 and mlp.sizes[-1] == cell.dx
+
     def _folded(self, v, mats):
         """The loop entry of v if its cell input is a single gather over a two-ones-per-row matrix
         (then the adjacency product is folded through the cell's GEMM), else None."""
@@ -483,12 +529,17 @@ class GraphNN(object):
         for p in (0, 1):
             src_states, dst_states = buf[p], buf[1 - p]
             mlp_tasks, lstm_tasks, mid, msg_out, zxs = {}, {}, [], {}, {}
+            pushed = {v: self._pushable(v, mats, folded) for v in self.var}
             for v in self.var:
                 for i, u in enumerate(self.loop[v]):
                     y = src_states[u["var"]].h
                     if "msg" in u:
                         mlp = self._msg_MLPs[u["msg"]]
                         out = torch.empty((y.shape[0], mlp.sizes[-1]), **f32)
+                        if pushed[v]:   # last hidden activation only; the last layer is folded into the cell
+                            mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.prefix_task(y, out, mlp.n_square - 1))
+                            msg_out[(v, i)] = out
+                            continue
                         proj = None
                         if folded[v] is not None:   # Zx = msg(y) Kx rides in the MLP launch
                             zxs[v] = torch.empty((y.shape[0], 4 * self.var[v]), **f32)
@@ -524,7 +575,15 @@ class GraphNN(object):
                     mid.append((lambda ins, o: torch.cat(ins, dim=1, out=o), (inputs, x)))
                 if x.shape[0] != st.h.shape[0] or x.shape[1] != cell.dx:
                     raise ValueError("cell input must be [%d,%d], got %s" % (st.h.shape[0], cell.dx, tuple(x.shape)))
-                lstm_tasks.setdefault(d, []).append(cell.task(x, st, out))
+                if pushed[v]:
+                    u0 = self.loop[v][0]
+                    kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]])
+                    rowptr = (mats[u0["mat"]].csr_t if u0.get("transpose?", False) else mats[u0["mat"]].csr)[0]
+                    deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
+                    lstm_tasks.setdefault(d, []).append(cell.pushed_task(x, st, out, kp, zb, deg))
+                    keep.append(deg)
+                else:
+                    lstm_tasks.setdefault(d, []).append(cell.task(x, st, out))
                 keep.append(x)
             keep.append(msg_out)
 

@@ -137,6 +137,14 @@ class Mlp(object):
         return _lib.MlpTask(_lib.ptr(x), _lib.ptr(self.wb_packed(0, n_sq - 1, d)), _lib.ptr(out), _lib.ptr(acts),
                             acts_stride, x.shape[0], n_sq, self.relu_mask(0, n_sq), _lib.ptr(pw), _lib.ptr(po))
 
+    def prefix_task(self, x, out, n_layers):
+        """Task running only the first ``n_layers`` square layers (the rest is folded elsewhere)."""
+        kind, d, n_sq, head = self._plan
+        if kind != "square" or head or len(self._chunks()) != 1 or not (1 <= n_layers <= n_sq):
+            return None
+        return _lib.MlpTask(_lib.ptr(x), _lib.ptr(self.wb_packed(0, n_layers - 1, d)), _lib.ptr(out), None, 0,
+                            x.shape[0], n_layers, self.relu_mask(0, n_layers), None, None)
+
     def _chunks(self):
         kind, d, n_sq, head = self._plan
         step = 2 if d == 128 else 4   # layers whose weights fit LDS together
