@@ -291,6 +291,24 @@ int tspgnn_adam_clip_step_f32(float* theta, float* g, float* m, float* v, int n,
                               float clip_norm, float lr_t, float beta1, float beta2, float eps,
                               float* gnorm_out, float* workspace, int* step_counter, void* stream);
 
+/* ------------------------------------------------------------------ host-side batch packing (no GPU work) */
+
+/*
+ * Appends the edges of one instance to a batch under construction: for every non-zero Ma[i,j] in np.nonzero
+ * (row-major) order writes uv = (v_off+i, v_off+j) and W = Mw[i,j] (instance_loader.py:56-67, without the dense
+ * EV).  Ma:[n,n] of kind 0=int8/bool 1=int32 2=int64 3=float32 4=float64; Mw:[n,n] float64.  HOST pointers.
+ * Returns the number of edges written, or -1 on a bad argument.
+ */
+long long tspgnn_host_pack_instance(const void* Ma, int ma_kind, const double* Mw, int n, int v_off,
+                                    int32_t* uv, double* W);
+
+/* Tour cost per vertex exactly as instance_loader.py:70 (closing pair (route[-1], route[1])). HOST pointers. */
+double tspgnn_host_route_cost(const double* Mw, int n, const int64_t* route, int len);
+
+/* CSR of EV^T (rowptr:[N+1], eid:[2M], ascending edge ids per vertex) from the endpoint list; HOST pointers.
+ * 0 = OK, -2 = endpoint out of range. */
+int tspgnn_host_csr_by_vertex(const int32_t* uv, long long M, int N, int32_t* rowptr, int32_t* eid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,8 @@ SIGNATURES = {
                                   c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 
+HOST_FUNCTIONS = ("tspgnn_host_pack_instance", "tspgnn_host_route_cost", "tspgnn_host_csr_by_vertex")
+
 # size queries: name -> argtypes; these return long long (floats of workspace)
 SIZE_QUERIES = {
     "tspgnn_lnlstm_bwd_workspace_floats": [c_int],
@@ -123,6 +125,13 @@ def _load():
         fn = getattr(lib, name)
         fn.restype = c_longlong
         fn.argtypes = argtypes
+    # host-side packer entry points (plain C, no device work)
+    lib.tspgnn_host_pack_instance.restype = c_longlong
+    lib.tspgnn_host_pack_instance.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.tspgnn_host_route_cost.restype = ctypes.c_double
+    lib.tspgnn_host_route_cost.argtypes = [c_void_p, c_int, c_void_p, c_int]
+    lib.tspgnn_host_csr_by_vertex.restype = c_int
+    lib.tspgnn_host_csr_by_vertex.argtypes = [c_void_p, c_longlong, c_int, c_void_p, c_void_p]
     return lib
 
 
