@@ -66,7 +66,7 @@ struct MlpTaskTable {
 };
 
 template <int D, int MAXL>
-__global__ __launch_bounds__(512, 4) void mlp_fwd_kernel(const MlpTaskTable tt) {
+__global__ __launch_bounds__(1024) void mlp_fwd_kernel(const MlpTaskTable tt) {
     constexpr int NT = D / 16;
     __shared__ __attribute__((aligned(16))) float lds[MAXL * (D * D + D) + 4];
     float* lds_w = lds;
@@ -384,7 +384,13 @@ static int launch_mlp(const tspgnn_mlp_task* tasks, int n, hipStream_t st) {
     const int lds_bytes = MAXL * (D * D + D) * 4 + 16;
     const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
     int grid = n_cus() * per_cu;
-    const int nw = tiles_all <= (long long)grid * 4 ? 4 : 8;  // few tiles: one wavefront per SIMD, more workgroups
+    int nw = tiles_all <= (long long)grid * 4 ? 4 : 8;  // few tiles: one wavefront per SIMD, more workgroups
+    if (per_cu == 2 && tiles_all > (long long)grid * 16) {
+        // many tiles: ONE workgroup of 16 wavefronts per CU instead of two of 8 -- the whole CU shares one
+        // ticket counter, so its four SIMDs finish within one tile of each other
+        grid = n_cus();
+        nw = 16;
+    }
     const long long max_grid = (tiles_all + nw - 1) / nw;     // at least one tile per wave
     if (grid > max_grid) grid = (int)max_grid;
     grid = split_blocks(cost, n, grid, tt.blk_end);
