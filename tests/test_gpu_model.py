@@ -336,3 +336,27 @@ def test_captured_training_step_matches_eager(cuda_device):
     assert finals[0][2] == finals[1][2] == 3
     assert finals[0][1] == finals[1][1]
     assert torch.equal(finals[0][0], finals[1][0])
+
+
+def test_batch_prefetcher_feeds_identical_batches(cuda_device):
+    """parallel.BatchPrefetcher (background packing + pinned, side-stream upload) must deliver the same
+    device batches as Session.prepare, in order."""
+    rng = np.random.RandomState(3)
+    host_batches = []
+    for _ in range(4):
+        base = [tspgnn.random_instance(int(rng.randint(6, 15)), rng) for _ in range(3)]
+        host_batches.append(tspgnn.InstanceLoader.create_batch([i for i in base for _ in (0, 1)], dev=0.02))
+    params = P.init_params(32, seed=1)
+    model = tspgnn.build_network(32)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    want = []
+    for t in host_batches:
+        EV, W, C, r, nv, ne = t
+        feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: 3, model["route_exists"]: r,
+                model["n_vertices"]: nv, model["n_edges"]: ne}
+        want.append(sess.forward(feed)["predictions"].clone())
+    got = [sess.forward_device(b)["predictions"].clone() for b in tspgnn.BatchPrefetcher(sess, host_batches, 3)]
+    torch.cuda.synchronize()
+    assert len(got) == 4 and all(torch.equal(a, b) for a, b in zip(got, want))

@@ -91,3 +91,19 @@ def test_product_does_not_import_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+
+
+def test_shard_instances_balances_edges_and_keeps_pairs():
+    rng = np.random.RandomState(0)
+    sizes = rng.randint(20, 81, size=64)
+    base = [tspgnn.random_instance(int(n), rng) for n in sizes]
+    instances = [inst for inst in base for _ in (0, 1)]          # the loader yields every instance twice
+    shards = tspgnn.shard_instances(instances, 8)
+    assert sorted(i for s in shards for i in s) == list(range(128))
+    for s in shards:                                             # +/- pairs stay together, in order
+        assert all(s[k] % 2 == 0 and s[k + 1] == s[k] + 1 for k in range(0, len(s), 2))
+    loads = [sum(np.count_nonzero(instances[i][0]) for i in s) for s in shards]
+    assert max(loads) <= 1.10 * (sum(loads) / 8.0)               # within 10 % of the mean edge load
+    by_count = [len(instances) // 8] * 8                         # what naive equal-count sharding would give
+    naive = [sum(np.count_nonzero(instances[i][0]) for i in range(r * 16, r * 16 + 16)) for r in range(8)]
+    assert max(loads) <= max(naive)

@@ -10,11 +10,12 @@ from .graphnn import GraphNN, LSTMStateTuple, DeviceAdjacency, LayerNormBasicLST
 from .instance_loader import InstanceLoader, SparseEV, read_graph, write_graph, synthetic_batch, random_instance
 from .binary_search import get_cost
 from .mlp import Mlp
+from .parallel import BatchPrefetcher, shard_instances
 from .model import build_network, Session, global_variables_initializer
 from .variables import VariableStore, get_default_store, reset_default_store
 
 __all__ = [
     "TspgnnError", "GraphNN", "LSTMStateTuple", "DeviceAdjacency", "LayerNormBasicLSTMCell", "InstanceLoader",
     "SparseEV", "read_graph", "write_graph", "synthetic_batch", "random_instance", "Mlp", "build_network",
-    "Session", "global_variables_initializer", "get_cost", "VariableStore", "get_default_store", "reset_default_store",
+    "Session", "global_variables_initializer", "get_cost", "BatchPrefetcher", "shard_instances", "VariableStore", "get_default_store", "reset_default_store",
 ]

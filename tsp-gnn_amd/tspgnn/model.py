@@ -158,8 +158,11 @@ class Session(object):
         pass
 
     # ------------------------------------------------------------------ feeding
-    def _f32(self, a):
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+    def _f32(self, a, pinned=False):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        if pinned and self.device.type == "cuda":
+            return t.pin_memory().to(self.device, non_blocking=True)
+        return t.to(self.device)
 
     def _adjacency(self, EV):
         from .graphnn import DeviceAdjacency
@@ -179,9 +182,11 @@ class Session(object):
         return adj
 
     # ------------------------------------------------------------------ forward
-    def prepare(self, feed):
+    def prepare(self, feed, pinned=False):
         """Validates a feed_dict and makes the batch resident in HBM (adjacency in index/CSR form,
-        (W,C) pairs, labels, segment offsets).  The returned DeviceBatch can be run many times."""
+        (W,C) pairs, labels, segment offsets).  The returned DeviceBatch can be run many times.
+        ``pinned``: stage through pinned host memory with non-blocking copies on the current stream
+        (used by parallel.BatchPrefetcher on its side stream)."""
         m = self.model
         adj = self._adjacency(feed[m["EV"]])
         M, N = adj.shape
@@ -192,7 +197,7 @@ class Session(object):
         n_edges = np.asarray(feed[m["n_edges"]]).astype(np.int64).reshape(-1)
         n_vertices = np.asarray(feed[m["n_vertices"]]).astype(np.int64).reshape(-1)
         B = n_vertices.shape[0]
-        labels = self._f32(np.asarray(feed[m["route_exists"]]).reshape(-1))
+        labels = self._f32(np.asarray(feed[m["route_exists"]]).reshape(-1), pinned)
         if n_edges.shape[0] != B or labels.shape[0] != B:
             raise ValueError("route_exists, n_vertices and n_edges must have one entry per problem")
         if int(n_edges.sum()) != M:
@@ -202,7 +207,7 @@ class Session(object):
         b = DeviceBatch()
         b.adj, b.M, b.N, b.B = adj, M, N, B
         b.T = int(feed[m["time_steps"]])
-        b.WC = self._f32(np.stack([W, C], axis=1))
+        b.WC = self._f32(np.stack([W, C], axis=1), pinned)
         b.labels = labels
         b.seg = torch.from_numpy(np.concatenate([[0], np.cumsum(n_edges)]).astype(np.int32)).to(self.device)
         return b
