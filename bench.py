@@ -28,6 +28,7 @@ for p in (ROOT, os.path.join(ROOT, "tsp-gnn_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* peak = fp32 vector peak
 
 WORKLOADS = {
@@ -222,15 +223,21 @@ def main():
             "incidences_per_s": round(4 * M * 1e6 / t_pair, 1),
         }
         dense_names = ("tspgnn_mlp_fwd_f32", "tspgnn_mlp_fwd_multi_f32", "tspgnn_lnlstm_fwd_f32",
-                       "tspgnn_lnlstm_fwd_multi_f32", "tspgnn_lnlstm_gather_fwd_f32", "tspgnn_linear_f32")
+                       "tspgnn_lnlstm_fwd_multi_f32", "tspgnn_lnlstm_gather_fwd_f32", "tspgnn_linear_f32",
+                       "tspgnn_mlp_fwd_multi_x3", "tspgnn_lnlstm_fwd_multi_x3")
         dense_us = sum(v["total_us"] for k, v in kernels_us.items() if k in dense_names)
+        x3 = "tspgnn_lnlstm_fwd_multi_x3" in kernels_us
+        # bf16x3: every fp32 product costs six bf16 MFMA terms -> the matrix-pipe ceiling in fp32-equivalent flops
+        dense_peak = BF16_MFMA_PEAK_TF / 6.0 if x3 else FP32_MFMA_PEAK_TF
         # E_vote's 3 hidden layers also run through mlp_fwd: count their flops too
         dense_flops = T * dense_flops_per_step(N, M, d, folded=True) + M * 3 * 2 * d * d
         roofline_dense = {
-            "kernel": "mlp_fwd_multi + lnlstm_fwd_multi + linear (fp32 MFMA v_mfma_f32_16x16x4_f32)",
+            "kernel": ("mlp_fwd_multi_x3 + lnlstm_fwd_multi_x3 (v_mfma_f32_16x16x32_bf16 on exact 3-way bf16 splits, "
+                       "6 terms per fp32 product; peak = bf16 dense peak / 6)") if x3 else
+                      "mlp_fwd_multi + lnlstm_fwd_multi + linear (fp32 MFMA v_mfma_f32_16x16x4_f32)",
             "bound": "mfma", "achieved": round(dense_flops / (dense_us * 1e-6) / 1e12, 2) if dense_us else None,
-            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "frac": round(dense_flops / (dense_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4) if dense_us else None,
+            "peak": round(dense_peak, 1), "unit": "TFLOP/s (fp32-equivalent)" if x3 else "TFLOP/s",
+            "frac": round(dense_flops / (dense_us * 1e-6) / 1e12 / dense_peak, 4) if dense_us else None,
             "executed_gflop_per_mp_step": round(dense_flops_per_step(N, M, d, True) / 1e9, 3),
             "reference_gflop_per_mp_step": round(dense_flops_per_step(N, M, d, False) / 1e9, 3),
             "note": "executed flops (the adjacency product is folded through the edge cell's GEMM); the reference "

@@ -145,6 +145,20 @@ typedef struct tspgnn_lstm_task {
 int tspgnn_mlp_fwd_multi_f32(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream);
 int tspgnn_lnlstm_fwd_multi_f32(const tspgnn_lstm_task* tasks, int n_tasks, int d, void* stream);
 
+/*
+ * The same two launches on the bf16 matrix cores with fp32-class accuracy ("bf16x3": every fp32 operand is
+ * split exactly into three bf16 pieces, six piece products accumulate in fp32; dropped terms <= 2^-24
+ * relative).  d in {32, 64}.  Weight operands are bf16x3 packings made by tspgnn_pack_weights_x3:
+ *   mlp task:  wb = n_layers blocks of { packed[3*d*d] bf16, bias[d] float };  proj_w = packed [d,4d].
+ *   lstm task: K  = packed [dx+d, 4d] (dx a multiple of 32; a kernel larger than LDS is streamed in k-block
+ *              chunks with the workgroup in lock step);  every other field as in the _f32 functions.
+ * tspgnn_pack_weights_x3: W:[krows,ncols] row-major fp32 (krows % 32 == 0, ncols % 16 == 0) ->
+ *   P: 3*krows*ncols bf16 (2 bytes each), piece-major, each piece in MFMA fragment order.
+ */
+int tspgnn_pack_weights_x3(const float* W, void* P, int krows, int ncols, void* stream);
+int tspgnn_mlp_fwd_multi_x3(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream);
+int tspgnn_lnlstm_fwd_multi_x3(const tspgnn_lstm_task* tasks, int n_tasks, int d, void* stream);
+
 /* ------------------------------------------------------------------ pre / post loop */
 
 /*

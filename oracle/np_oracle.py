@@ -40,11 +40,15 @@ def layer_norm(x, gamma, beta):
     return x * inv + (beta - mean * inv)
 
 
-def lnlstm(x, h, c, K, ln):
+def lnlstm(x, h, c, K, ln, z0=None):
     """LayerNormBasicLSTMCell.call as used at graphnn.py:168-170.
-    ln: dict gate -> (gamma, beta) for gates input/transform/forget/output/state."""
+    ln: dict gate -> (gamma, beta) for gates input/transform/forget/output/state.
+    z0: optional pre-activation offset (the part of [x,h] K a caller has already formed, e.g. an
+    aggregation pushed through Kx); None for the plain cell."""
     d = h.shape[1]
     z = np.concatenate([x, h], axis=1) @ K
+    if z0 is not None:
+        z = z + z0
     i, j, f, o = z[:, :d], z[:, d:2 * d], z[:, 2 * d:3 * d], z[:, 3 * d:]
     i = layer_norm(i, *ln["input"])
     j = layer_norm(j, *ln["transform"])

@@ -1,0 +1,189 @@
+"""bf16x3 (fp32-accurate, bf16 matrix cores) dense kernels vs the float64 numpy oracle, through the C ABI.
+
+The tolerance is the same as for the fp32 kernels: the split keeps every term down to 2^-24 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import np_oracle as NO
+from tspgnn import _lib
+
+pytestmark = pytest.mark.gpu
+
+_KEEP = []
+
+
+def dev(a, device, dtype=np.float32):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(device)
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _release_uploads():
+    yield
+    torch.cuda.synchronize()
+    del _KEEP[:]
+
+
+def packed_x3(W, device):
+    """tspgnn_pack_weights_x3 -> uint8 tensor of 3*krows*ncols*2 bytes."""
+    src = dev(W, device)
+    out = torch.empty(3 * W.size * 2, dtype=torch.uint8, device=device)
+    _KEEP.append(out)
+    _lib.call("tspgnn_pack_weights_x3", _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], None)
+    return out
+
+
+def bf16_to_f64(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def test_pack_x3_pieces_sum_to_the_weight(cuda_device):
+    for kr, nc in ((64, 64), (32, 32), (64, 256), (128, 256)):
+        rng = np.random.RandomState(kr + nc)
+        W = (rng.randn(kr, nc) * np.exp(rng.randn(kr, nc))).astype(np.float32)
+        P = packed_x3(W, cuda_device).cpu().numpy().view(np.uint16).reshape(3, kr // 32, 4, nc // 16, 16, 8)
+        pieces = bf16_to_f64(P)
+        back = np.zeros((kr, nc))
+        for kb in range(kr // 32):
+            for g in range(4):
+                for j in range(8):
+                    k = 16 * (2 * kb + (j >> 2)) + 4 * g + (j & 3)
+                    back[k] = pieces[:, kb, g, :, :, j].sum(0).reshape(-1)   # [3, NT, 16] -> columns t*16+jl
+        # three bf16 pieces carry 24 mantissa bits: the sum is the fp32 value up to its last bit
+        assert np.max(np.abs(back - W) / np.abs(W)) < 2.0 ** -22
+        assert np.array_equal(pieces[0, 0, 0, 0, :, 0].astype(np.float32),
+                              torch.from_numpy(W[0, :16].copy()).to(torch.bfloat16).to(torch.float32).numpy())
+
+
+def mlp_blocks(layers, device):
+    """{packed bf16x3, bias} per layer as one byte tensor."""
+    parts = []
+    for W, b in layers:
+        parts.append(packed_x3(W, device).cpu().numpy())
+        parts.append(np.ascontiguousarray(b, dtype=np.float32).view(np.uint8))
+    return dev(np.concatenate(parts), device, np.uint8)
+
+
+@pytest.mark.parametrize("d,n_layers,mask", [(64, 4, 0b0111), (64, 3, 0b111), (32, 4, 0b0111), (32, 1, 0), (64, 2, 0b10)])
+@pytest.mark.parametrize("rows", [1, 16, 333, 70000])
+def test_mlp_fwd_x3(cuda_device, d, n_layers, mask, rows):
+    rng = np.random.RandomState(rows + d)
+    X = rng.randn(rows, d).astype(np.float32)
+    layers = [((rng.randn(d, d) / np.sqrt(d)).astype(np.float32), (0.1 * rng.randn(d)).astype(np.float32))
+              for _ in range(n_layers)]
+    wb = mlp_blocks(layers, cuda_device)
+    Y = torch.empty((rows, d), dtype=torch.float32, device=cuda_device)
+    acts = torch.empty((max(n_layers - 1, 1), rows, d), dtype=torch.float32, device=cuda_device)
+    task = _lib.MlpTask(_lib.ptr(dev(X, cuda_device)), _lib.ptr(wb), _lib.ptr(Y), _lib.ptr(acts), 0, rows, n_layers, mask,
+                        None, None)
+    _lib.call_multi("tspgnn_mlp_fwd_multi_x3", [task], d)
+    torch.cuda.synchronize()
+    x = X.astype(np.float64)
+    for l, (W, b) in enumerate(layers):
+        x = NO.dense(x, W.astype(np.float64), b.astype(np.float64), bool((mask >> l) & 1))
+        if l < n_layers - 1:
+            assert rel_err(acts[l].cpu().numpy(), x) < 2e-6
+    assert rel_err(Y.cpu().numpy(), x) < 2e-6
+
+
+@pytest.mark.parametrize("d", [32, 64])
+def test_mlp_x3_two_tasks_with_projection(cuda_device, d):
+    rng = np.random.RandomState(d)
+    rows_a, rows_b = 9000, 700
+    Xa = rng.randn(rows_a, d).astype(np.float32)
+    Xb = rng.randn(rows_b, d).astype(np.float32)
+    la = [((rng.randn(d, d) / np.sqrt(d)).astype(np.float32), (0.1 * rng.randn(d)).astype(np.float32)) for _ in range(3)]
+    lb = [((rng.randn(d, d) / np.sqrt(d)).astype(np.float32), (0.1 * rng.randn(d)).astype(np.float32)) for _ in range(4)]
+    P = (rng.randn(d, 4 * d) / np.sqrt(d)).astype(np.float32)
+    Ya = torch.empty((rows_a, d), dtype=torch.float32, device=cuda_device)
+    Yb = torch.empty((rows_b, d), dtype=torch.float32, device=cuda_device)
+    Zb = torch.empty((rows_b, 4 * d), dtype=torch.float32, device=cuda_device)
+    ta = _lib.MlpTask(_lib.ptr(dev(Xa, cuda_device)), _lib.ptr(mlp_blocks(la, cuda_device)), _lib.ptr(Ya), None, 0, rows_a, 3,
+                      0b111, None, None)
+    tb = _lib.MlpTask(_lib.ptr(dev(Xb, cuda_device)), _lib.ptr(mlp_blocks(lb, cuda_device)), _lib.ptr(Yb), None, 0, rows_b, 4,
+                      0b0111, _lib.ptr(packed_x3(P, cuda_device)), _lib.ptr(Zb))
+    _lib.call_multi("tspgnn_mlp_fwd_multi_x3", [ta, tb], d)
+    torch.cuda.synchronize()
+    xa = Xa.astype(np.float64)
+    for W, b in la:
+        xa = NO.dense(xa, W.astype(np.float64), b.astype(np.float64), True)
+    xb = Xb.astype(np.float64)
+    for l, (W, b) in enumerate(lb):
+        xb = NO.dense(xb, W.astype(np.float64), b.astype(np.float64), l < 3)
+    assert rel_err(Ya.cpu().numpy(), xa) < 2e-6
+    assert rel_err(Yb.cpu().numpy(), xb) < 2e-6
+    assert rel_err(Zb.cpu().numpy(), xb @ P.astype(np.float64)) < 2e-6
+
+
+def ln_params(rng, d):
+    ln = np.stack([np.stack([1 + 0.2 * rng.randn(d), 0.2 * rng.randn(d)]) for _ in range(5)]).astype(np.float32)
+    names = ("input", "transform", "forget", "output", "state")
+    return ln, {g: (ln[i, 0].astype(np.float64), ln[i, 1].astype(np.float64)) for i, g in enumerate(names)}
+
+
+@pytest.mark.parametrize("d,dx", [(64, 64), (32, 32), (32, 64), (64, 0), (64, 192), (64, 32)])
+@pytest.mark.parametrize("rows", [1, 17, 1000, 40000])
+def test_lnlstm_fwd_x3(cuda_device, d, dx, rows):
+    """dx+d = 128 at d=64 does not fit LDS in three pieces: the streamed (lock-step) mode is exercised too."""
+    rng = np.random.RandomState(rows * 7 + d + dx)
+    x = rng.randn(rows, dx).astype(np.float32)
+    h = rng.randn(rows, d).astype(np.float32)
+    c = rng.randn(rows, d).astype(np.float32)
+    K = (rng.randn(dx + d, 4 * d) / np.sqrt(dx + d)).astype(np.float32)
+    ln, lnd = ln_params(rng, d)
+    h_out = torch.empty((rows, d), dtype=torch.float32, device=cuda_device)
+    c_out = torch.empty((rows, d), dtype=torch.float32, device=cuda_device)
+    xd = dev(x, cuda_device) if dx else None
+    task = _lib.LstmTask(_lib.ptr(xd), dx, _lib.ptr(dev(h, cuda_device)), _lib.ptr(dev(c, cuda_device)),
+                         _lib.ptr(packed_x3(K, cuda_device)), _lib.ptr(dev(ln, cuda_device)), _lib.ptr(h_out), _lib.ptr(c_out),
+                         rows, None, None, None, None)
+    _lib.call_multi("tspgnn_lnlstm_fwd_multi_x3", [task], d)
+    torch.cuda.synchronize()
+    rh, rc = NO.lnlstm(x.astype(np.float64), h.astype(np.float64), c.astype(np.float64), K.astype(np.float64), lnd)
+    assert rel_err(c_out.cpu().numpy(), rc) < 5e-6
+    assert rel_err(h_out.cpu().numpy(), rh) < 5e-6
+
+
+@pytest.mark.parametrize("d", [32, 64])
+def test_lnlstm_x3_gather_init_and_zbias_tasks_in_one_launch(cuda_device, d):
+    rng = np.random.RandomState(d)
+    N, M = 300, 5000
+    uv = np.stack([rng.randint(0, N, M), rng.randint(0, N, M)], 1).astype(np.int32)
+    Zx = rng.randn(N, 4 * d).astype(np.float32)
+    he = rng.randn(M, d).astype(np.float32); ce = rng.randn(M, d).astype(np.float32)
+    Kh = (rng.randn(d, 4 * d) / np.sqrt(d)).astype(np.float32)
+    ln_e, lnd_e = ln_params(rng, d)
+    # vertex task: z = deg * zbias + [x|h] K
+    xv = rng.randn(N, d).astype(np.float32)
+    hv = rng.randn(N, d).astype(np.float32); cv = rng.randn(N, d).astype(np.float32)
+    Kv = (rng.randn(2 * d, 4 * d) / np.sqrt(2 * d)).astype(np.float32)
+    zb = rng.randn(4 * d).astype(np.float32)
+    deg = rng.randint(0, 40, N).astype(np.float32)
+    ln_v, lnd_v = ln_params(rng, d)
+    he_o = torch.empty((M, d), dtype=torch.float32, device=cuda_device); ce_o = torch.empty_like(he_o)
+    hv_o = torch.empty((N, d), dtype=torch.float32, device=cuda_device); cv_o = torch.empty_like(hv_o)
+    te = _lib.LstmTask(None, 0, _lib.ptr(dev(he, cuda_device)), _lib.ptr(dev(ce, cuda_device)), _lib.ptr(packed_x3(Kh, cuda_device)),
+                       _lib.ptr(dev(ln_e, cuda_device)), _lib.ptr(he_o), _lib.ptr(ce_o), M,
+                       _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev(Zx, cuda_device)), None, None)
+    tv = _lib.LstmTask(_lib.ptr(dev(xv, cuda_device)), d, _lib.ptr(dev(hv, cuda_device)), _lib.ptr(dev(cv, cuda_device)),
+                       _lib.ptr(packed_x3(Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o), N,
+                       None, None, _lib.ptr(dev(zb, cuda_device)), _lib.ptr(dev(deg, cuda_device)))
+    _lib.call_multi("tspgnn_lnlstm_fwd_multi_x3", [te, tv], d)
+    torch.cuda.synchronize()
+    z0 = Zx.astype(np.float64)[uv[:, 0]] + Zx.astype(np.float64)[uv[:, 1]]
+    rh, rc = NO.lnlstm(np.zeros((M, 0)), he.astype(np.float64), ce.astype(np.float64), Kh.astype(np.float64), lnd_e, z0=z0)
+    assert rel_err(ce_o.cpu().numpy(), rc) < 5e-6
+    assert rel_err(he_o.cpu().numpy(), rh) < 5e-6
+    z0 = deg.astype(np.float64)[:, None] * zb.astype(np.float64)[None]
+    rh, rc = NO.lnlstm(xv.astype(np.float64), hv.astype(np.float64), cv.astype(np.float64), Kv.astype(np.float64), lnd_v, z0=z0)
+    assert rel_err(cv_o.cpu().numpy(), rc) < 5e-6
+    assert rel_err(hv_o.cpu().numpy(), rh) < 5e-6
+
+
+def test_x3_rejects_unsupported_width(cuda_device):
+    t = _lib.MlpTask(None, None, None, None, 0, 0, 1, 0, None, None)
+    with pytest.raises(_lib.TspgnnError):
+        _lib.call_multi("tspgnn_mlp_fwd_multi_x3", [t], 128)

@@ -74,6 +74,45 @@ t = timeit(lambda: _lib.call("tspgnn_gather2_sum_f32", _lib.ptr(adj.uv), _lib.pt
 res["gather2"] = (t, gb / t / 1e3)
 t = timeit(lambda: _lib.call("tspgnn_csr_rowsum_f32", _lib.ptr(rowptr), _lib.ptr(eid), _lib.ptr(Ze), _lib.ptr(Yv), N, M, d, None))
 res["rowsum"] = (t, rb / t / 1e3)
+
+# bf16x3 variants (multi entry points; single task and the step's real task pairs)
+def pack3(W):
+    out = torch.empty(3 * W.numel() * 2, dtype=torch.uint8, device=dev)
+    _lib.call("tspgnn_pack_weights_x3", _lib.ptr(W), _lib.ptr(out), W.shape[0], W.shape[1], None)
+    return out
+
+
+if d in (32, 64):
+    def mlp3_blocks(n):
+        return torch.cat([torch.cat([pack3(torch.randn(d, d, device=dev) / 8), torch.randn(d, device=dev).view(torch.uint8)])
+                          for _ in range(n)])
+    Xe = torch.randn(M, d, device=dev); Ye3 = torch.empty_like(Xe)
+    Xv3 = torch.randn(N, d, device=dev); Yv3 = torch.empty_like(Xv3); Zv3 = torch.empty(N, 4 * d, device=dev)
+    wbe, wbv = mlp3_blocks(4), mlp3_blocks(4)
+    proj = pack3(torch.randn(d, 4 * d, device=dev) / 8)
+    for nl in (4, 3):
+        te = _lib.task_array([_lib.MlpTask(_lib.ptr(Xe), _lib.ptr(wbe), _lib.ptr(Ye3), None, 0, M, nl, 7, None, None)])
+        t = timeit(lambda: _lib.call_multi("tspgnn_mlp_fwd_multi_x3", te, d))
+        res["x3_mlp%d_E" % nl] = (t, M * nl * 2 * d * d / t / 1e6)
+    tev = _lib.task_array([_lib.MlpTask(_lib.ptr(Xe), _lib.ptr(wbe), _lib.ptr(Ye3), None, 0, M, 3, 7, None, None),
+                           _lib.MlpTask(_lib.ptr(Xv3), _lib.ptr(wbv), _lib.ptr(Yv3), None, 0, N, 4, 7, _lib.ptr(proj), _lib.ptr(Zv3))])
+    t = timeit(lambda: _lib.call_multi("tspgnn_mlp_fwd_multi_x3", tev, d))
+    res["x3_mlp_step"] = (t, (M * 3 + N * 8) * 2 * d * d / t / 1e6)
+    Kh3 = pack3(torch.randn(d, 4 * d, device=dev) / 8)
+    Kv3 = pack3(torch.randn(2 * d, 4 * d, device=dev) / 11)
+    Hv = torch.randn(N, d, device=dev); Cv = torch.randn(N, d, device=dev); Hvo, Cvo = torch.empty_like(Hv), torch.empty_like(Cv)
+    zb = torch.randn(4 * d, device=dev); deg = torch.rand(N, device=dev)
+    tg = _lib.task_array([_lib.LstmTask(None, 0, _lib.ptr(H), _lib.ptr(C), _lib.ptr(Kh3), _lib.ptr(ln), _lib.ptr(Ho), _lib.ptr(Co), M,
+                                        _lib.ptr(adj.uv), _lib.ptr(Zx), None, None)])
+    t = timeit(lambda: _lib.call_multi("tspgnn_lnlstm_fwd_multi_x3", tg, d))
+    res["x3_lstm_gather_E"] = (t, M * 2 * d * 4 * d / t / 1e6)
+    tv = _lib.task_array([_lib.LstmTask(_lib.ptr(Xv3), d, _lib.ptr(Hv), _lib.ptr(Cv), _lib.ptr(Kv3), _lib.ptr(ln), _lib.ptr(Hvo),
+                                        _lib.ptr(Cvo), N, None, None, _lib.ptr(zb), _lib.ptr(deg))])
+    t = timeit(lambda: _lib.call_multi("tspgnn_lnlstm_fwd_multi_x3", tv, d))
+    res["x3_lstm_V"] = (t, N * 2 * 2 * d * 4 * d / t / 1e6)
+    tgv = _lib.task_array([tg[0], tv[0]])
+    t = timeit(lambda: _lib.call_multi("tspgnn_lnlstm_fwd_multi_x3", tgv, d))
+    res["x3_lstm_step"] = (t, (M + 2 * N) * 2 * d * 4 * d / t / 1e6)
 for k, (t, r) in res.items():
     unit = "GB/s" if k in ("gather2", "rowsum") else "TFLOP/s"
     print("%-12s %8.2f us  %8.1f %s" % (k, t, r, unit))

@@ -33,6 +33,9 @@ SIGNATURES = {
                               c_int, c_void_p],
     "tspgnn_mlp_fwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_fwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_pack_weights_x3": [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_mlp_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_lnlstm_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_mlp_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_gather_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

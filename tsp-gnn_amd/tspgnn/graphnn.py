@@ -12,6 +12,8 @@ gather path.
 """
 from collections import namedtuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -192,6 +194,21 @@ class LayerNormBasicLSTMCell(object):
             return out
         return self.store.packed((key, self.base), build)
 
+    def _packed_x3(self, key, rows_lo, rows_hi):
+        """bf16x3 packing (tspgnn_pack_weights_x3) of kernel rows [rows_lo, rows_hi) as a byte tensor."""
+        def build(out):
+            K = self.kernel()[rows_lo:rows_hi]
+            if out is None:
+                out = torch.empty(6 * K.numel(), dtype=torch.uint8, device=K.device)
+            _lib.call("tspgnn_pack_weights_x3", _lib.ptr(K), _lib.ptr(out), rows_hi - rows_lo, 4 * self.d,
+                      _lib.current_stream())
+            return out
+        return self.store.packed((key, self.base), build)
+
+    def x3_ok(self):
+        """The bf16x3 cell kernel covers this shape (tspgnn_lnlstm_fwd_multi_x3)."""
+        return self.d in (32, 64) and self.dx % 32 == 0
+
     def kx_packed(self):
         return self._packed_slice("lstm.kx", 0, self.dx, False)
 
@@ -204,17 +221,19 @@ class LayerNormBasicLSTMCell(object):
     def kh_t_packed(self):
         return self._packed_slice("lstm.khT", self.dx, self.dx + self.d, True)
 
-    def task(self, x, state, out):
-        return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(self.kernel_packed()),
+    def task(self, x, state, out, x3=False):
+        K = self._packed_x3("lstm.x3", 0, self.dx + self.d) if x3 else self.kernel_packed()
+        return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(K),
                              _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None,
                              None, None)
 
-    def gather_task(self, adj, zx, state, out):
-        return _lib.LstmTask(None, 0, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(self.kh_packed()),
+    def gather_task(self, adj, zx, state, out, x3=False):
+        K = self._packed_x3("lstm.kh.x3", self.dx, self.dx + self.d) if x3 else self.kh_packed()
+        return _lib.LstmTask(None, 0, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(K),
                              _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0],
                              _lib.ptr(adj.uv), _lib.ptr(zx), None, None)
 
-    def pushed_bias_pack(self, mlp):
+    def pushed_bias_pack(self, mlp, x3=False):
         """For a cell whose input is a row-sum aggregation of ``mlp``'s output: the message MLP's last
         (linear) layer W,b pushed through the aggregation and through Kx:
             (sum_e (a_e W + b)) Kx = (sum_e a_e) (W Kx) + degree (b Kx)
@@ -226,8 +245,9 @@ class LayerNormBasicLSTMCell(object):
         def build(out):
             W, b = self.store.view(last + "/kernel"), self.store.view(last + "/bias")
             if out is None:
-                out = (torch.empty((dx + d, 4 * d), dtype=torch.float32, device=W.device),
-                       torch.empty((1, 4 * d), dtype=torch.float32, device=W.device))
+                kp = torch.empty(6 * (dx + d) * 4 * d, dtype=torch.uint8, device=W.device) if x3 \
+                    else torch.empty((dx + d, 4 * d), dtype=torch.float32, device=W.device)
+                out = (kp, torch.empty((1, 4 * d), dtype=torch.float32, device=W.device))
             kp, zb = out
             st = _lib.current_stream()
             kfull = torch.empty((dx + d, 4 * d), dtype=torch.float32, device=W.device)
@@ -236,9 +256,12 @@ class LayerNormBasicLSTMCell(object):
                       4 * d, 0, W.shape[0], st)
             _lib.call("tspgnn_linear_f32", _lib.ptr(b.view(1, -1)), dx, _lib.ptr(self.kx_packed()), None, 0, _lib.ptr(zb),
                       4 * d, 0, 1, st)
-            _lib.call("tspgnn_pack_weights_f32", _lib.ptr(kfull), _lib.ptr(kp), dx + d, 4 * d, 0, st)
+            if x3:
+                _lib.call("tspgnn_pack_weights_x3", _lib.ptr(kfull), _lib.ptr(kp), dx + d, 4 * d, st)
+            else:
+                _lib.call("tspgnn_pack_weights_f32", _lib.ptr(kfull), _lib.ptr(kp), dx + d, 4 * d, 0, st)
             return (kp, zb)
-        return self.store.packed(("lstm.pushed", self.base, last), build)
+        return self.store.packed(("lstm.pushed.x3" if x3 else "lstm.pushed", self.base, last), build)
 
     def pushed_task(self, x, state, out, kp, zb, deg):
         return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(kp), _lib.ptr(self.ln()),
@@ -354,6 +377,12 @@ class GraphNN(object):
         self.float_dtype = float_dtype
         self.store = store if store is not None else V.get_default_store()
         self.fold_adjacency = True   # (EV y) Kx = EV (y Kx) fast path; False = op-for-op reference order
+        # GEMM arithmetic of the inference forward: "bf16x3" = bf16 matrix cores on exact three-way splits of
+        # the fp32 operands (fp32-class accuracy, see csrc/dense_x3.hip); "f32" = fp32 MFMA.  TSPGNN_GEMM=f32
+        # in the environment selects the latter; shapes the x3 kernels do not cover fall back to it as well.
+        self.gemm = os.environ.get("TSPGNN_GEMM", "bf16x3")
+        if self.gemm not in ("bf16x3", "f32"):
+            raise ValueError("TSPGNN_GEMM must be 'bf16x3' or 'f32', got %r" % self.gemm)
         self.check_model()
         self._init_parameters()
 
@@ -526,6 +555,8 @@ class GraphNN(object):
         buf = [{v: LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) for v, st in states.items()},
                {v: LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h)) for v, st in states.items()}]
         runs, keep = [], []
+        x3 = self.gemm == "bf16x3" and all(c.x3_ok() for c in self._RNN_cells.values()) \
+            and all(m.sizes[-1] in (32, 64) for m in self._msg_MLPs.values())
         for p in (0, 1):
             src_states, dst_states = buf[p], buf[1 - p]
             mlp_tasks, lstm_tasks, mid, msg_out, zxs = {}, {}, [], {}, {}
@@ -537,14 +568,15 @@ class GraphNN(object):
                         mlp = self._msg_MLPs[u["msg"]]
                         out = torch.empty((y.shape[0], mlp.sizes[-1]), **f32)
                         if pushed[v]:   # last hidden activation only; the last layer is folded into the cell
-                            mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.prefix_task(y, out, mlp.n_square - 1))
+                            mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.prefix_task(y, out, mlp.n_square - 1, x3=x3))
                             msg_out[(v, i)] = out
                             continue
                         proj = None
                         if folded[v] is not None:   # Zx = msg(y) Kx rides in the MLP launch
                             zxs[v] = torch.empty((y.shape[0], 4 * self.var[v]), **f32)
-                            proj = (self._RNN_cells[v].kx_packed(), zxs[v])
-                        mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.task(y, out, proj=proj))
+                            cv = self._RNN_cells[v]
+                            proj = (cv._packed_x3("lstm.kx.x3", 0, cv.dx) if x3 else cv.kx_packed(), zxs[v])
+                        mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.task(y, out, proj=proj, x3=x3))
                         y = out
                     msg_out[(v, i)] = y
             for v, d in self.var.items():
@@ -556,7 +588,7 @@ class GraphNN(object):
                     else:
                         zx = torch.empty((msg_out[(v, 0)].shape[0], 4 * d), **f32)
                         mid.append((cell.premultiply, (msg_out[(v, 0)], zx)))
-                    lstm_tasks.setdefault(d, []).append(cell.gather_task(mats[folded[v]["mat"]], zx, st, out))
+                    lstm_tasks.setdefault(d, []).append(cell.gather_task(mats[folded[v]["mat"]], zx, st, out, x3=x3))
                     keep.append(zx)
                     continue
                 inputs = []
@@ -577,26 +609,29 @@ class GraphNN(object):
                     raise ValueError("cell input must be [%d,%d], got %s" % (st.h.shape[0], cell.dx, tuple(x.shape)))
                 if pushed[v]:
                     u0 = self.loop[v][0]
-                    kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]])
+                    kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], x3=x3)
                     rowptr = (mats[u0["mat"]].csr_t if u0.get("transpose?", False) else mats[u0["mat"]].csr)[0]
                     deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
                     lstm_tasks.setdefault(d, []).append(cell.pushed_task(x, st, out, kp, zb, deg))
                     keep.append(deg)
                 else:
-                    lstm_tasks.setdefault(d, []).append(cell.task(x, st, out))
+                    lstm_tasks.setdefault(d, []).append(cell.task(x, st, out, x3=x3))
                 keep.append(x)
             keep.append(msg_out)
 
             mlp_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in mlp_tasks.items() for k in range(0, len(ts), 4)]
             lstm_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in lstm_tasks.items() for k in range(0, len(ts), 4)]
 
-            def run(mlp_calls=mlp_calls, mid=mid, lstm_calls=lstm_calls):
+            mlp_fn = "tspgnn_mlp_fwd_multi_x3" if x3 else "tspgnn_mlp_fwd_multi_f32"
+            lstm_fn = "tspgnn_lnlstm_fwd_multi_x3" if x3 else "tspgnn_lnlstm_fwd_multi_f32"
+
+            def run(mlp_calls=mlp_calls, mid=mid, lstm_calls=lstm_calls, mlp_fn=mlp_fn, lstm_fn=lstm_fn):
                 for arr, d in mlp_calls:
-                    _lib.call_multi("tspgnn_mlp_fwd_multi_f32", arr, d)
+                    _lib.call_multi(mlp_fn, arr, d)
                 for fn, args in mid:
                     fn(*args)
                 for arr, d in lstm_calls:
-                    _lib.call_multi("tspgnn_lnlstm_fwd_multi_f32", arr, d)
+                    _lib.call_multi(lstm_fn, arr, d)
             runs.append(run)
         self._plan_keep = keep   # buffers referenced by raw pointers inside the task structures
         return runs[0], runs[1], (buf[0], buf[1])

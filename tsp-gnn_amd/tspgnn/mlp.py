@@ -104,6 +104,22 @@ class Mlp(object):
             return out
         return self.store.packed(("mlp", self.name, first, last), build)
 
+    def wb_packed_x3(self, first, last, d):
+        """Byte tensor of {bf16x3 pack(W) [3*d*d*2 B], b [d*4 B]} per square layer first..last
+        (tspgnn_pack_weights_x3) for the bf16x3 kernels, cached until the variables change."""
+        def build(out):
+            src = self.wb(first, last)
+            per_src, per = d * d + d, 6 * d * d + 4 * d
+            if out is None:
+                out = torch.empty((last - first + 1) * per, dtype=torch.uint8, device=src.device)
+            st = _lib.current_stream()
+            for j in range(last - first + 1):
+                o, q = j * per_src, j * per
+                _lib.call("tspgnn_pack_weights_x3", _lib.ptr(src[o:o + d * d]), _lib.ptr(out[q:q + 6 * d * d]), d, d, st)
+                out[q + 6 * d * d:q + per].copy_(src[o + d * d:o + per_src].view(torch.uint8))
+            return out
+        return self.store.packed(("mlp.x3", self.name, first, last), build)
+
     def wt_packed(self, first, last, d):
         """pack(W_l^T) for square layers first..last back to back (data-gradient kernels)."""
         def build(out):
@@ -127,22 +143,25 @@ class Mlp(object):
                 mask |= 1 << j
         return mask
 
-    def task(self, x, out, acts=None, acts_stride=0, proj=None):
+    def task(self, x, out, acts=None, acts_stride=0, proj=None, x3=False):
         """An _lib.MlpTask for a single-kernel square chain (None if this Mlp needs several kernels).
-        ``proj`` = (packed [d,4d] matrix, output [rows,4d]): also emit out @ P from the same launch."""
+        ``proj`` = (packed [d,4d] matrix, output [rows,4d]): also emit out @ P from the same launch.
+        ``x3``: weights in the bf16x3 packing (for tspgnn_mlp_fwd_multi_x3; proj packed likewise)."""
         kind, d, n_sq, head = self._plan
         if kind != "square" or head or len(self._chunks()) != 1:
             return None
         pw, po = (proj if proj is not None else (None, None))
-        return _lib.MlpTask(_lib.ptr(x), _lib.ptr(self.wb_packed(0, n_sq - 1, d)), _lib.ptr(out), _lib.ptr(acts),
+        wb = self.wb_packed_x3(0, n_sq - 1, d) if x3 else self.wb_packed(0, n_sq - 1, d)
+        return _lib.MlpTask(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(out), _lib.ptr(acts),
                             acts_stride, x.shape[0], n_sq, self.relu_mask(0, n_sq), _lib.ptr(pw), _lib.ptr(po))
 
-    def prefix_task(self, x, out, n_layers):
+    def prefix_task(self, x, out, n_layers, x3=False):
         """Task running only the first ``n_layers`` square layers (the rest is folded elsewhere)."""
         kind, d, n_sq, head = self._plan
         if kind != "square" or head or len(self._chunks()) != 1 or not (1 <= n_layers <= n_sq):
             return None
-        return _lib.MlpTask(_lib.ptr(x), _lib.ptr(self.wb_packed(0, n_layers - 1, d)), _lib.ptr(out), None, 0,
+        wb = self.wb_packed_x3(0, n_layers - 1, d) if x3 else self.wb_packed(0, n_layers - 1, d)
+        return _lib.MlpTask(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(out), None, 0,
                             x.shape[0], n_layers, self.relu_mask(0, n_layers), None, None)
 
     def _chunks(self):
