@@ -159,6 +159,21 @@ int tspgnn_pack_weights_x3(const float* W, void* P, int krows, int ncols, void* 
 int tspgnn_mlp_fwd_multi_x3(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream);
 int tspgnn_lnlstm_fwd_multi_x3(const tspgnn_lstm_task* tasks, int n_tasks, int d, void* stream);
 
+/*
+ * Cell update fused with the message MLP that consumes the new h in the NEXT time step (graphnn.py:150-170 read
+ * across the step boundary: msg(h') is the same value whether it is computed at the end of step t or at the start
+ * of step t+1).  Per task: the cell exactly as in tspgnn_lnlstm_fwd_multi_x3, then, on the same rows,
+ *   Y = Dense chain (mlp_layers <= 4 square layers, weights/bias blocks as in tspgnn_mlp_fwd_multi_x3) of h';
+ *   mlp_out:[rows,d] = Y (optional);  proj_out:[rows,4d] = Y P (optional, P = pack_weights_x3 of [d,4d]).
+ * mlp_layers == 0: plain cell.
+ */
+typedef struct tspgnn_cell_mlp_task {
+    tspgnn_lstm_task cell;
+    const void* mlp_wb; int mlp_layers; unsigned relu_mask; float* mlp_out;
+    const void* proj_w; float* proj_out;
+} tspgnn_cell_mlp_task;
+int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream);
+
 /* ------------------------------------------------------------------ pre / post loop */
 
 /*

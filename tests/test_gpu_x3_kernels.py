@@ -183,6 +183,58 @@ def test_lnlstm_x3_gather_init_and_zbias_tasks_in_one_launch(cuda_device, d):
     assert rel_err(hv_o.cpu().numpy(), rh) < 5e-6
 
 
+@pytest.mark.parametrize("d", [32, 64])
+def test_cell_fused_with_next_step_mlp(cuda_device, d):
+    """tspgnn_lnlstm_mlp_fwd_multi_x3: edge cell (gather-init, resident) + 3-layer message MLP, and vertex cell
+    (bias-init, streamed) + 4-layer MLP + projection, one launch; both against the float64 oracle."""
+    rng = np.random.RandomState(100 + d)
+    N, M = 333, 7001
+    uv = np.stack([rng.randint(0, N, M), rng.randint(0, N, M)], 1).astype(np.int32)
+    Zx = rng.randn(N, 4 * d).astype(np.float32)
+    he = rng.randn(M, d).astype(np.float32); ce = rng.randn(M, d).astype(np.float32)
+    Kh = (rng.randn(d, 4 * d) / np.sqrt(d)).astype(np.float32)
+    ln_e, lnd_e = ln_params(rng, d)
+    le = [((rng.randn(d, d) / np.sqrt(d)).astype(np.float32), (0.1 * rng.randn(d)).astype(np.float32)) for _ in range(3)]
+    xv = rng.randn(N, d).astype(np.float32)
+    hv = rng.randn(N, d).astype(np.float32); cv = rng.randn(N, d).astype(np.float32)
+    Kv = (rng.randn(2 * d, 4 * d) / np.sqrt(2 * d)).astype(np.float32)
+    zb = rng.randn(4 * d).astype(np.float32)
+    deg = rng.randint(0, 40, N).astype(np.float32)
+    ln_v, lnd_v = ln_params(rng, d)
+    lv = [((rng.randn(d, d) / np.sqrt(d)).astype(np.float32), (0.1 * rng.randn(d)).astype(np.float32)) for _ in range(4)]
+    P = (rng.randn(d, 4 * d) / np.sqrt(d)).astype(np.float32)
+    f32 = dict(dtype=torch.float32, device=cuda_device)
+    he_o, ce_o, ae_o = torch.empty((M, d), **f32), torch.empty((M, d), **f32), torch.empty((M, d), **f32)
+    hv_o, cv_o, yv_o = torch.empty((N, d), **f32), torch.empty((N, d), **f32), torch.empty((N, d), **f32)
+    zv_o = torch.empty((N, 4 * d), **f32)
+    te = _lib.LstmTask(None, 0, _lib.ptr(dev(he, cuda_device)), _lib.ptr(dev(ce, cuda_device)), _lib.ptr(packed_x3(Kh, cuda_device)),
+                       _lib.ptr(dev(ln_e, cuda_device)), _lib.ptr(he_o), _lib.ptr(ce_o), M,
+                       _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev(Zx, cuda_device)), None, None)
+    tv = _lib.LstmTask(_lib.ptr(dev(xv, cuda_device)), d, _lib.ptr(dev(hv, cuda_device)), _lib.ptr(dev(cv, cuda_device)),
+                       _lib.ptr(packed_x3(Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o), N,
+                       None, None, _lib.ptr(dev(zb, cuda_device)), _lib.ptr(dev(deg, cuda_device)))
+    tasks = [_lib.CellMlpTask(te, _lib.ptr(mlp_blocks(le, cuda_device)), 3, 0b111, _lib.ptr(ae_o), None, None),
+             _lib.CellMlpTask(tv, _lib.ptr(mlp_blocks(lv, cuda_device)), 4, 0b0111, _lib.ptr(yv_o),
+                              _lib.ptr(packed_x3(P, cuda_device)), _lib.ptr(zv_o))]
+    _lib.call_multi("tspgnn_lnlstm_mlp_fwd_multi_x3", tasks, d)
+    torch.cuda.synchronize()
+    z0 = Zx.astype(np.float64)[uv[:, 0]] + Zx.astype(np.float64)[uv[:, 1]]
+    rh, rc = NO.lnlstm(np.zeros((M, 0)), he.astype(np.float64), ce.astype(np.float64), Kh.astype(np.float64), lnd_e, z0=z0)
+    assert rel_err(ce_o.cpu().numpy(), rc) < 5e-6 and rel_err(he_o.cpu().numpy(), rh) < 5e-6
+    a = rh
+    for W, b in le:
+        a = NO.dense(a, W.astype(np.float64), b.astype(np.float64), True)
+    assert rel_err(ae_o.cpu().numpy(), a) < 5e-6
+    z0 = deg.astype(np.float64)[:, None] * zb.astype(np.float64)[None]
+    rh, rc = NO.lnlstm(xv.astype(np.float64), hv.astype(np.float64), cv.astype(np.float64), Kv.astype(np.float64), lnd_v, z0=z0)
+    assert rel_err(cv_o.cpu().numpy(), rc) < 5e-6 and rel_err(hv_o.cpu().numpy(), rh) < 5e-6
+    y = rh
+    for l, (W, b) in enumerate(lv):
+        y = NO.dense(y, W.astype(np.float64), b.astype(np.float64), l < 3)
+    assert rel_err(yv_o.cpu().numpy(), y) < 5e-6
+    assert rel_err(zv_o.cpu().numpy(), y @ P.astype(np.float64)) < 5e-6
+
+
 def test_x3_rejects_unsupported_width(cuda_device):
     t = _lib.MlpTask(None, None, None, None, 0, 0, 1, 0, None, None)
     with pytest.raises(_lib.TspgnnError):

@@ -182,42 +182,7 @@ __global__ __launch_bounds__(1024) void mlp_fwd_kernel(const MlpTaskTable tt) {
 }
 
 // ---------------------------------------------------------------------------------- LN-LSTM
-// split(z) = i, j, f, o (that order); LN each; c' = LN(c*sig(f+1) + sig(i)*relu(j)); h' = relu(c')*sig(o)
-template <int D>
-__device__ __forceinline__ void lstm_epilogue(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 16], const float* lds_ln, int g,
-                                              bool valid, float* hd, float* cd) {
-    constexpr int TPG = D / 16;
-    f32x4 gi[TPG], gj[TPG], gf[TPG], go[TPG];
-#pragma unroll
-    for (int t = 0; t < TPG; ++t) {
-        gi[t] = acc[t];
-        gj[t] = acc[TPG + t];
-        gf[t] = acc[2 * TPG + t];
-        go[t] = acc[3 * TPG + t];
-    }
-    ln_gate<TPG>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D);
-    ln_gate<TPG>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D);
-    ln_gate<TPG>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D);
-    ln_gate<TPG>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D);
-    f32x4 nc[TPG];
-#pragma unroll
-    for (int t = 0; t < TPG; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            nc[t][r] = cf[t][r] * sigmoidf_(gf[t][r] + 1.0f) + sigmoidf_(gi[t][r]) * fmaxf(gj[t][r], 0.f);
-    }
-    ln_gate<TPG>(nc, lds_ln + 8 * D, lds_ln + 9 * D, g, D);
-    if (valid) {
-#pragma unroll
-        for (int t = 0; t < TPG; ++t) {
-            f32x4 hn;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hn[r] = fmaxf(nc[t][r], 0.f) * sigmoidf_(go[t][r]);
-            st4(hd + t * 16, hn);
-            st4(cd + t * 16, nc[t]);
-        }
-    }
-}
+// lstm_epilogue<D> (mfma_tile.h): split(z) = i, j, f, o; LN each; c' = LN(c*sig(f+1) + sig(i)*relu(j)); h' = relu(c')*sig(o)
 
 // Resident variant: K ([dx+D, 4D], packed) and the five LayerNorm (gamma,beta) pairs stay in LDS
 // for the lifetime of the block; requires (dx+D)*4D*4 + 10*D*4 + 16 bytes <= 160 KiB

@@ -239,7 +239,7 @@ __device__ __forceinline__ void lstm_tile_backward(f32x4 (&acc)[D / 4], const fl
     }
 }
 
-// LDS: [K chunk or all of K] [ln 10*D] [NW slabs of 10*D] [ticket].
+// LDS: [K chunk or all of K] [ln 10*D] [NW slabs of 10*D].
 constexpr int kMaxTasks = 4;
 
 struct LstmBwdTaskTable {
@@ -280,7 +280,6 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const LstmBwdTaskTa
     float* lds_k = lds;
     float* lds_ln = lds + (size_t)(resident ? QT : qc) * 16 * 4 * D;
     float* slabs = lds_ln + 10 * D;
-    int* ticket = reinterpret_cast<int*>(slabs + nw * 10 * D);
     float* slab = slabs + wave * 10 * D;
     for (int i = tid; i < 10 * D; i += blockDim.x) lds_ln[i] = ln[i];
     for (int i = tid; i < nw * 10 * D; i += blockDim.x) slabs[i] = 0.f;
@@ -302,13 +301,10 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const LstmBwdTaskTa
         copy_to_lds(lds_k, K, (dx + D) * 4 * D, tid, blockDim.x);
         const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
         const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
-        if (tid == 0) *ticket = t_beg;
         __syncthreads();
-        for (;;) {
-            int tile = 0;
-            if (lane == 0) tile = atomicAdd(ticket, 1);
-            tile = __builtin_amdgcn_readfirstlane(tile);
-            if (tile >= t_end) break;
+        // static round-robin over the workgroup's tiles (not a ticket): which tiles a wavefront sums into its
+        // LayerNorm-gradient slab must not depend on timing, or the gradients differ in the last bit from run to run
+        for (int tile = t_beg + (tid >> 6); tile < t_end; tile += (int)(blockDim.x >> 6)) {
             const int row = tile * 16 + rl;
             const bool valid = row < rows;
             const size_t rc = (size_t)(valid ? row : rows - 1);

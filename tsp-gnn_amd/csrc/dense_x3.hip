@@ -63,19 +63,18 @@ __global__ __launch_bounds__(256) void pack_weights_x3_kernel(const float* __res
 
 __device__ __forceinline__ bf16x8 ldw(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
-// acc[t] += W-block(kb, all NT tiles) x B for one 32-feature k-block.  lds_w: packed matrix (piece-major),
-// `total` = krows*ncols elements per piece.
+// acc[t] += W-block(kb, all NT tiles) x B for one 32-feature k-block of the packed matrix whose three pieces start
+// at wh / wm / wl (LDS; wl may also be a global pointer: the lo piece feeds one MFMA in six and can stay in L1/L2
+// when LDS is full).  (bh, bm, bl) = split3 of the lane's eight B values.
 template <int NT>
-__device__ __forceinline__ void kblock_x3(f32x4 (&acc)[NT], const __bf16* lds_w, int total, int kb, int g, int jl,
-                                          const float (&x)[8]) {
-    bf16x8 bh, bm, bl;
-    split3(x, bh, bm, bl);
-    const __bf16* base = lds_w + ((size_t)(kb * 4 + g) * NT * 16 + jl) * 8;
+__device__ __forceinline__ void kblock_p3(f32x4 (&acc)[NT], const __bf16* wh, const __bf16* wm, const __bf16* wl, int kb,
+                                          int g, int jl, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
+    const int off = ((kb * 4 + g) * NT * 16 + jl) * 8;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const bf16x8 ah = ldw(base + t * 128);
-        const bf16x8 am = ldw(base + total + t * 128);
-        const bf16x8 al = ldw(base + 2 * (size_t)total + t * 128);
+        const bf16x8 ah = ldw(wh + off + t * 128);
+        const bf16x8 am = ldw(wm + off + t * 128);
+        const bf16x8 al = ldw(wl + off + t * 128);
         f32x4 c = acc[t];
         c = MFMA_BF16(al, bh, c);  // smallest terms first
         c = MFMA_BF16(am, bm, c);
@@ -84,6 +83,42 @@ __device__ __forceinline__ void kblock_x3(f32x4 (&acc)[NT], const __bf16* lds_w,
         c = MFMA_BF16(ah, bm, c);
         c = MFMA_BF16(ah, bh, c);
         acc[t] = c;
+    }
+}
+
+// lds_w: packed matrix, piece-major, `total` = krows*ncols elements per piece.
+template <int NT>
+__device__ __forceinline__ void kblock_x3(f32x4 (&acc)[NT], const __bf16* lds_w, int total, int kb, int g, int jl,
+                                          const float (&x)[8]) {
+    bf16x8 bh, bm, bl;
+    split3(x, bh, bm, bl);
+    kblock_p3<NT>(acc, lds_w, lds_w + total, lds_w + 2 * (size_t)total, kb, g, jl, bh, bm, bl);
+}
+
+// One Dense(D) layer on the lane's part of a 16-row tile, activations chained in registers (D layout).
+template <int D>
+__device__ __forceinline__ void dense_layer_x3(f32x4 (&a)[D / 16], const __bf16* wh, const __bf16* wm, const __bf16* wl,
+                                               const float* bias, bool relu, int g, int rl) {
+    constexpr int NT = D / 16, KB = D / 32;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = ld4(bias + t * 16 + g * 4);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = a[2 * kb + (j >> 2)][j & 3];
+        bf16x8 bh, bm, bl;
+        split3(x, bh, bm, bl);
+        kblock_p3<NT>(acc, wh, wm, wl, kb, g, rl, bh, bm, bl);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
+        }
+        a[t] = acc[t];
     }
 }
 
@@ -214,42 +249,56 @@ __global__ __launch_bounds__(1024) void mlp_fwd_x3_kernel(const MlpTaskTableX3 t
     }
 }
 
-// ---------------------------------------------------------------------------------- LN-LSTM (x3)
+// ---------------------------------------------------------------------------------- LN-LSTM (+ MLP) (x3)
 // z = [x|h] K (+ gather-init / bias-init), five LayerNorms and the gate arithmetic of dense.hip's cell, with
-// the GEMM on the bf16 matrix cores.  A kernel that fits LDS in three pieces (Kh of the edge cell in gather-init
-// mode: 96 KB at D=64) stays resident and 16-row tiles are handed out by an LDS ticket; a larger one (the vertex
-// cell's [2D,4D]) is streamed in k-block chunks with the workgroup in lock step.
+// the GEMM on the bf16 matrix cores -- optionally followed, on the same 16 rows while h' is still in registers,
+// by the message MLP that consumes h' in the NEXT time step (and its projection through the receiving cell's
+// Kx): the step's "cell" and the next step's "message" launches become one, h' is not re-read from HBM and the
+// per-launch fixed cost (weight staging, ramp, tail) is paid once.
+//   resident mode  -- K fits LDS in three pieces (Kh of the edge cell in gather-init mode, 96 KB at D=64): K, the
+//     MLP's hi/mid pieces and as many lo pieces as still fit stay in LDS for the lifetime of the workgroup (the
+//     other lo pieces are read through L1: one MFMA operand in six); 16-row tiles are handed out by an LDS ticket.
+//   lock-step mode -- a larger K (the vertex cell's [2D,4D]) is streamed in k-block chunks, then the MLP weights,
+//     then the projection matrix are staged into the same LDS region, one tile per wavefront per round.
 // Measured (tools/mfma_probe_bf16.hip): bf16 MFMAs and VALU instructions do not co-execute on a gfx950 SIMD
-// either, so kernel time ~ MFMA cycles + VALU cycles; what bf16x3 buys is 2.5x fewer MFMA cycles.
-struct LstmTaskTableX3 {
-    tspgnn_lstm_task task[kMaxTasks];
+// either, so kernel time ~ MFMA cycles + VALU cycles + what HBM does not hide.
+struct CellTaskTableX3 {
+    tspgnn_cell_mlp_task task[kMaxTasks];
     int blk_end[kMaxTasks];
-    int kbc[kMaxTasks];  // k-blocks (32 rows of K) per LDS chunk; >= all of K: resident
+    int kbc[kMaxTasks];       // k-blocks (32 rows of K) per LDS chunk; >= all of K: resident
+    int n_lo_lds[kMaxTasks];  // resident mode: MLP layers whose lo piece is in LDS
     int n;
 };
 
-// K is the bf16x3 packing of kernel[dx+D, 4D] (or of Kh[D,4D] in gather-init mode).
 template <int D>
-__global__ __launch_bounds__(512) void lnlstm_fwd_x3_kernel(const LstmTaskTableX3 tt) {
-    constexpr int NT4 = D / 4, TPG = D / 16;
+__global__ __launch_bounds__(512) void lnlstm_mlp_fwd_x3_kernel(const CellTaskTableX3 tt) {
+    constexpr int NT4 = D / 4, TPG = D / 16, KBH = D / 32;
+    constexpr int LAYER_BYTES = 3 * D * D * 2 + D * 4;  // { hi, mid, lo, bias } of one MLP layer in global memory
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     int k = 0;
     while (k + 1 < tt.n && (int)blockIdx.x >= tt.blk_end[k]) ++k;
     const int blk0 = k ? tt.blk_end[k - 1] : 0;
     const int my_blk = blockIdx.x - blk0, my_grid = tt.blk_end[k] - blk0;
-    const float* __restrict__ x = tt.task[k].x;
-    const int dx = tt.task[k].dx;
-    const float* __restrict__ h = tt.task[k].h;
-    const float* __restrict__ c = tt.task[k].c;
-    const __bf16* __restrict__ K = reinterpret_cast<const __bf16*>(tt.task[k].K);
-    const float* __restrict__ ln = tt.task[k].ln;
-    float* __restrict__ h_out = tt.task[k].h_out;
-    float* __restrict__ c_out = tt.task[k].c_out;
-    const int rows = tt.task[k].rows;
-    const int2* __restrict__ uv = reinterpret_cast<const int2*>(tt.task[k].uv);
-    const float* __restrict__ Zx = tt.task[k].Zx;
-    const float* __restrict__ zbias = tt.task[k].zbias;
-    const float* __restrict__ zscale = tt.task[k].zscale;
+    const tspgnn_lstm_task& tk = tt.task[k].cell;
+    const float* __restrict__ x = tk.x;
+    const int dx = tk.dx;
+    const float* __restrict__ h = tk.h;
+    const float* __restrict__ c = tk.c;
+    const __bf16* __restrict__ K = reinterpret_cast<const __bf16*>(tk.K);
+    const float* __restrict__ ln = tk.ln;
+    float* __restrict__ h_out = tk.h_out;
+    float* __restrict__ c_out = tk.c_out;
+    const int rows = tk.rows;
+    const int2* __restrict__ uv = reinterpret_cast<const int2*>(tk.uv);
+    const float* __restrict__ Zx = tk.Zx;
+    const float* __restrict__ zbias = tk.zbias;
+    const float* __restrict__ zscale = tk.zscale;
+    const unsigned char* __restrict__ mlp_wb = reinterpret_cast<const unsigned char*>(tt.task[k].mlp_wb);
+    const int n_layers = tt.task[k].mlp_layers;
+    const unsigned relu_mask = tt.task[k].relu_mask;
+    float* __restrict__ mlp_out = tt.task[k].mlp_out;
+    const __bf16* __restrict__ proj_w = reinterpret_cast<const __bf16*>(tt.task[k].proj_w);
+    float* __restrict__ proj_out = tt.task[k].proj_out;
     const int tiles_total = (rows + 15) / 16;
     const int KBT = (dx + D) >> 5;       // k-blocks in total
     const int kbc = tt.kbc[k];
@@ -258,10 +307,11 @@ __global__ __launch_bounds__(512) void lnlstm_fwd_x3_kernel(const LstmTaskTableX
     const int total = (dx + D) * 4 * D;  // elements per piece of the whole matrix
     const int chunk_total = (resident ? KBT : kbc) * 32 * 4 * D;
 
-    // LDS: [3 pieces x chunk] [ln 10*D floats] [ticket]
-    __bf16* lds_w = reinterpret_cast<__bf16*>(ldsb);
-    float* lds_ln = reinterpret_cast<float*>(ldsb + (size_t)3 * chunk_total * 2);
+    // LDS: [ln 10*D floats][ticket, pad][weights region]
+    float* lds_ln = reinterpret_cast<float*>(ldsb);
     int* ticket = reinterpret_cast<int*>(lds_ln + 10 * D);
+    unsigned char* lds_wb = ldsb + (10 * D + 4) * sizeof(float);
+    __bf16* lds_w = reinterpret_cast<__bf16*>(lds_wb);
     const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4, wave = tid >> 6;
     const int nw = blockDim.x >> 6;
     for (int i = tid; i < 10 * D; i += blockDim.x) lds_ln[i] = ln[i];
@@ -303,43 +353,34 @@ __global__ __launch_bounds__(512) void lnlstm_fwd_x3_kernel(const LstmTaskTableX
             kblock_x3<NT4>(acc, lds_w, chunk_total, kb - kb_base, g, rl, xv);
         }
     };
-    auto epilogue = [&](f32x4 (&acc)[NT4], f32x4 (&cf)[TPG], unsigned rc, bool valid) {
-        f32x4 gi[TPG], gj[TPG], gf[TPG], go[TPG];
-#pragma unroll
-        for (int t = 0; t < TPG; ++t) {
-            gi[t] = acc[t];
-            gj[t] = acc[TPG + t];
-            gf[t] = acc[2 * TPG + t];
-            go[t] = acc[3 * TPG + t];
-        }
-        ln_gate<TPG>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D);
-        ln_gate<TPG>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D);
-        ln_gate<TPG>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D);
-        ln_gate<TPG>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D);
+    // gates + state stores; returns h' in registers (the D layout is the next GEMM's B operand)
+    auto cell = [&](f32x4 (&acc)[NT4], f32x4 (&cf)[TPG], unsigned rc, bool valid, f32x4 (&hn)[TPG]) {
         f32x4 nc[TPG];
-#pragma unroll
-        for (int t = 0; t < TPG; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                nc[t][r] = cf[t][r] * sigmoidf_(gf[t][r] + 1.0f) + sigmoidf_(gi[t][r]) * fmaxf(gj[t][r], 0.f);
-        }
-        ln_gate<TPG>(nc, lds_ln + 8 * D, lds_ln + 9 * D, g, D);
+        lstm_gates<D>(acc, cf, lds_ln, g, hn, nc);
         if (valid) {
             float* hd = h_out + (rc * D + g * 4);
             float* cd = c_out + (rc * D + g * 4);
 #pragma unroll
             for (int t = 0; t < TPG; ++t) {
-                f32x4 hn;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hn[r] = fmaxf(nc[t][r], 0.f) * sigmoidf_(go[t][r]);
-                st4(hd + t * 16, hn);
+                st4(hd + t * 16, hn[t]);
                 st4(cd + t * 16, nc[t]);
             }
         }
     };
 
     if (resident) {
+        // weights region: [K 3 pieces][per layer hi, mid][lo of the first n_lo layers][biases]
+        const int n_lo = tt.n_lo_lds[k];
+        __bf16* lds_hm = lds_w + (size_t)3 * chunk_total;
+        __bf16* lds_lo = lds_hm + (size_t)n_layers * 2 * D * D;
+        float* lds_bias = reinterpret_cast<float*>(lds_lo + (size_t)n_lo * D * D);
         stage(0, KBT);
+        for (int l = 0; l < n_layers; ++l) {
+            const unsigned char* src = mlp_wb + (size_t)l * LAYER_BYTES;
+            copy_bytes_to_lds(lds_hm + (size_t)l * 2 * D * D, src, 2 * D * D * 2, tid, blockDim.x);
+            if (l < n_lo) copy_bytes_to_lds(lds_lo + (size_t)l * D * D, src + 2 * D * D * 2, D * D * 2, tid, blockDim.x);
+            copy_bytes_to_lds(lds_bias + l * D, src + 3 * D * D * 2, D * 4, tid, blockDim.x);
+        }
         const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
         const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
         if (tid == 0) *ticket = t_beg;
@@ -352,15 +393,34 @@ __global__ __launch_bounds__(512) void lnlstm_fwd_x3_kernel(const LstmTaskTableX
             const int row = tile * 16 + rl;
             const bool valid = row < rows;
             const unsigned rc = (unsigned)(valid ? row : rows - 1);
-            f32x4 acc[NT4], cf[TPG];
-            init_acc(acc, rc);
+            f32x4 hn[TPG];
+            {
+                f32x4 acc[NT4], cf[TPG];
+                init_acc(acc, rc);
 #pragma unroll
-            for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + (rc * D + g * 4 + t * 16));
-            kloop(acc, rc, 0, 0, KBT);
-            epilogue(acc, cf, rc, valid);
+                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + (rc * D + g * 4 + t * 16));
+                kloop(acc, rc, 0, 0, KBT);
+                cell(acc, cf, rc, valid, hn);
+            }
+            if (n_layers > 0) {
+                for (int l = 0; l < n_layers; ++l) {
+                    const __bf16* wh = lds_hm + (size_t)l * 2 * D * D;
+                    const bool relu = (relu_mask >> l) & 1u;
+                    if (l < n_lo)
+                        dense_layer_x3<D>(hn, wh, wh + D * D, lds_lo + (size_t)l * D * D, lds_bias + l * D, relu, g, rl);
+                    else
+                        dense_layer_x3<D>(hn, wh, wh + D * D,
+                                          reinterpret_cast<const __bf16*>(mlp_wb + (size_t)l * LAYER_BYTES) + 2 * D * D,
+                                          lds_bias + l * D, relu, g, rl);
+                }
+                if (valid && mlp_out != nullptr) {
+#pragma unroll
+                    for (int t = 0; t < TPG; ++t) st4(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                }
+            }
         }
     } else {
-        // lock-step rounds: one tile per wavefront, K walked chunk by chunk
+        // lock-step rounds: one tile per wavefront; K walked chunk by chunk, then the MLP, then the projection
         const int rounds = (tiles_total + nw - 1) / nw;
         for (int r = my_blk; r < rounds; r += my_grid) {
             const int tile = r * nw + wave;
@@ -368,18 +428,54 @@ __global__ __launch_bounds__(512) void lnlstm_fwd_x3_kernel(const LstmTaskTableX
             const int row = tile * 16 + rl;
             const bool valid = live && row < rows;
             const unsigned rc = (unsigned)(valid ? row : rows - 1);
-            f32x4 acc[NT4], cf[TPG];
-            init_acc(acc, rc);
+            f32x4 hn[TPG];
+            {
+                f32x4 acc[NT4], cf[TPG];
+                init_acc(acc, rc);
 #pragma unroll
-            for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + (rc * D + g * 4 + t * 16));
-            for (int kb0 = 0; kb0 < KBT; kb0 += kbc) {
-                const int kb1 = min(KBT, kb0 + kbc);
-                __syncthreads();
-                stage(kb0, kb1);
-                __syncthreads();
-                if (live) kloop(acc, rc, kb0, kb0, kb1);
+                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + (rc * D + g * 4 + t * 16));
+                for (int kb0 = 0; kb0 < KBT; kb0 += kbc) {
+                    const int kb1 = min(KBT, kb0 + kbc);
+                    __syncthreads();
+                    stage(kb0, kb1);
+                    __syncthreads();
+                    if (live) kloop(acc, rc, kb0, kb0, kb1);
+                }
+                cell(acc, cf, rc, valid, hn);
             }
-            epilogue(acc, cf, rc, valid);
+            if (n_layers > 0) {
+                __syncthreads();
+                copy_bytes_to_lds(lds_wb, mlp_wb, n_layers * LAYER_BYTES, tid, blockDim.x);
+                __syncthreads();
+                for (int l = 0; l < n_layers; ++l) {
+                    const __bf16* wh = reinterpret_cast<const __bf16*>(lds_wb + (size_t)l * LAYER_BYTES);
+                    const float* bias = reinterpret_cast<const float*>(lds_wb + (size_t)l * LAYER_BYTES + 3 * D * D * 2);
+                    dense_layer_x3<D>(hn, wh, wh + D * D, wh + 2 * D * D, bias, (relu_mask >> l) & 1u, g, rl);
+                }
+                if (valid && mlp_out != nullptr) {
+#pragma unroll
+                    for (int t = 0; t < TPG; ++t) st4(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                }
+                if (proj_w != nullptr) {  // proj_out = mlp(h') P, P packed [D, 4D]
+                    __syncthreads();
+                    copy_bytes_to_lds(lds_wb, proj_w, 3 * D * 4 * D * 2, tid, blockDim.x);
+                    __syncthreads();
+                    f32x4 acc[NT4];
+#pragma unroll
+                    for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < KBH; ++kb) {
+                        float xv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xv[j] = hn[2 * kb + (j >> 2)][j & 3];
+                        kblock_x3<NT4>(acc, lds_w, D * 4 * D, kb, g, rl, xv);
+                    }
+                    if (valid) {
+#pragma unroll
+                        for (int t = 0; t < NT4; ++t) st4(proj_out + (rc * (4 * D) + t * 16 + g * 4), acc[t]);
+                    }
+                }
+            }
         }
     }
 }
@@ -422,38 +518,57 @@ static int launch_mlp_x3(const tspgnn_mlp_task* tasks, int n, hipStream_t st) {
 }
 
 template <int D>
-static int launch_lnlstm_x3(const tspgnn_lstm_task* tasks, int n, hipStream_t st) {
-    const size_t extra = (10 * D + 4) * sizeof(float);
+static int launch_cell_x3(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t st, const char* what) {
+    const size_t head = (10 * D + 4) * sizeof(float);
     const size_t per_kb = (size_t)3 * 32 * 4 * D * 2;  // bytes of one k-block, three pieces
-    const size_t budget = 152 * 1024 - extra;
-    LstmTaskTableX3 tt;
+    const size_t budget = 160 * 1024 - head;
+    const size_t layer_hm = (size_t)2 * D * D * 2, layer_lo = (size_t)D * D * 2, layer_all = 3 * D * D * 2 + D * 4;
+    CellTaskTableX3 tt;
     long long cost[kMaxTasks];
     long long tiles_all = 0;
     size_t lds_w = 0;
     for (int k = 0; k < n; ++k) {
         tt.task[k] = tasks[k];
-        const int KBT = (tasks[k].dx + D) / 32;
-        int kbc = KBT;
-        if ((size_t)KBT * per_kb > budget) kbc = (int)(budget / per_kb);
-        if (kbc < 1) return fail(TSPGNN_EUNSUPPORTED, "lnlstm_fwd_x3: d=%d does not fit LDS", D);
-        tt.kbc[k] = kbc;
-        if ((size_t)kbc * per_kb > lds_w) lds_w = (size_t)kbc * per_kb;
-        const long long tiles = ((long long)tasks[k].rows + 15) / 16;
-        cost[k] = tiles * (KBT + 2) * (kbc < KBT ? 2 : 1);
+        const tspgnn_lstm_task& c = tasks[k].cell;
+        const int L = tasks[k].mlp_layers;
+        const int KBT = (c.dx + D) / 32;
+        const size_t k_bytes = (size_t)KBT * per_kb;
+        const size_t mlp_min = L * (layer_hm + D * 4);  // resident: hi, mid and biases must be in LDS
+        size_t need;
+        if (k_bytes + mlp_min <= budget && !tasks[k].proj_w) {
+            tt.kbc[k] = KBT;
+            int n_lo = (int)((budget - k_bytes - mlp_min) / layer_lo);
+            if (n_lo > L) n_lo = L;
+            tt.n_lo_lds[k] = n_lo;
+            need = k_bytes + mlp_min + n_lo * layer_lo;
+        } else {
+            int kbc = k_bytes <= budget ? KBT : (int)(budget / per_kb);
+            if (kbc >= KBT) kbc = KBT - 1;  // lock-step mode is selected by kbc < KBT
+            if (kbc < 1 || L * layer_all > budget || (tasks[k].proj_w && (size_t)3 * D * 4 * D * 2 > budget))
+                return fail(TSPGNN_EUNSUPPORTED, "%s: dx=%d, d=%d, %d MLP layers do not fit LDS", what, c.dx, D, L);
+            tt.kbc[k] = kbc;
+            tt.n_lo_lds[k] = L;
+            need = (size_t)kbc * per_kb;
+            if (L * layer_all > need) need = L * layer_all;
+            if (tasks[k].proj_w && (size_t)3 * D * 4 * D * 2 > need) need = (size_t)3 * D * 4 * D * 2;
+        }
+        if (need > lds_w) lds_w = need;
+        const long long tiles = ((long long)c.rows + 15) / 16;
+        cost[k] = tiles * (KBT * 4 + 2 * L + (tasks[k].proj_w ? 8 : 0) + 6) * (tt.kbc[k] < KBT ? 2 : 1);
         tiles_all += tiles;
     }
     tt.n = n;
-    const size_t lds_bytes = lds_w + extra;
+    const size_t lds_bytes = lds_w + head;
     int grid = n_cus();
     const int nw = tiles_all <= (long long)grid * 4 ? 4 : 8;
     const long long max_grid = (tiles_all + nw - 1) / nw;
     if (grid > max_grid) grid = (int)max_grid;
     grid = split_blocks_x3(cost, n, grid, tt.blk_end);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlstm_fwd_x3_kernel<D>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlstm_mlp_fwd_x3_kernel<D>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return fail((int)e, "lnlstm_fwd_x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    lnlstm_fwd_x3_kernel<D><<<grid, nw * 64, lds_bytes, st>>>(tt);
-    return launched("tspgnn_lnlstm_fwd_multi_x3");
+    if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute(%d B): %s", what, (int)lds_bytes, hipGetErrorString(e));
+    lnlstm_mlp_fwd_x3_kernel<D><<<grid, nw * 64, lds_bytes, st>>>(tt);
+    return launched(what);
 }
 
 }  // namespace tspgnn
@@ -489,24 +604,43 @@ extern "C" int tspgnn_mlp_fwd_multi_x3(const tspgnn_mlp_task* tasks, int n_tasks
     return d == 32 ? launch_mlp_x3<32>(live, n, as_stream(stream)) : launch_mlp_x3<64>(live, n, as_stream(stream));
 }
 
-extern "C" int tspgnn_lnlstm_fwd_multi_x3(const tspgnn_lstm_task* tasks, int n_tasks, int d, void* stream) {
-    TSPGNN_REQUIRE(tasks && n_tasks >= 1 && n_tasks <= kMaxTasks, "lnlstm_fwd_multi_x3: 1..%d tasks", kMaxTasks);
-    TSPGNN_REQUIRE(d == 32 || d == 64, "lnlstm_fwd_x3: d=%d must be 32 or 64", d);
-    tspgnn_lstm_task live[kMaxTasks];
+static int cell_mlp_x3(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream, const char* what) {
+    TSPGNN_REQUIRE(tasks && n_tasks >= 1 && n_tasks <= kMaxTasks, "%s: 1..%d tasks", what, kMaxTasks);
+    TSPGNN_REQUIRE(d == 32 || d == 64, "%s: d=%d must be 32 or 64", what, d);
+    tspgnn_cell_mlp_task live[kMaxTasks];
     int n = 0;
     for (int k = 0; k < n_tasks; ++k) {
-        const tspgnn_lstm_task& t = tasks[k];
-        TSPGNN_REQUIRE(t.rows >= 0, "lnlstm_fwd_x3: rows=%d", t.rows);
-        TSPGNN_REQUIRE((long long)t.rows * (4 * d > t.dx ? 4 * d : t.dx) < (1ll << 30),
-                       "lnlstm_fwd_x3: rows=%d too large for 32-bit offsets", t.rows);
-        TSPGNN_REQUIRE(t.dx >= 0 && t.dx % 32 == 0, "lnlstm_fwd_x3: dx=%d must be a non-negative multiple of 32", t.dx);
+        const tspgnn_lstm_task& t = tasks[k].cell;
+        TSPGNN_REQUIRE(t.rows >= 0, "%s: rows=%d", what, t.rows);
+        TSPGNN_REQUIRE((long long)t.rows * (4 * d > t.dx ? 4 * d : t.dx) < (1ll << 30), "%s: rows=%d too large for 32-bit offsets",
+                       what, t.rows);
+        TSPGNN_REQUIRE(t.dx >= 0 && t.dx % 32 == 0, "%s: dx=%d must be a non-negative multiple of 32", what, t.dx);
+        TSPGNN_REQUIRE(tasks[k].mlp_layers >= 0 && tasks[k].mlp_layers <= 4, "%s: mlp_layers=%d must be in 0..4", what,
+                       tasks[k].mlp_layers);
         if (t.rows == 0) continue;
-        TSPGNN_REQUIRE(t.h && t.c && t.K && t.ln && t.h_out && t.c_out && (t.dx == 0 || t.x), "lnlstm_fwd_x3: null pointer");
-        TSPGNN_REQUIRE(t.h_out != t.h && t.c_out != t.c, "lnlstm_fwd_x3: outputs may not alias inputs");
-        TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx), "lnlstm_fwd_x3: gather-init mode needs dx == 0 and Zx");
-        TSPGNN_REQUIRE(!t.zbias || (t.zscale && !t.uv), "lnlstm_fwd_x3: zbias needs zscale and excludes gather-init mode");
-        live[n++] = t;
+        TSPGNN_REQUIRE(t.h && t.c && t.K && t.ln && t.h_out && t.c_out && (t.dx == 0 || t.x), "%s: null pointer", what);
+        TSPGNN_REQUIRE(t.h_out != t.h && t.c_out != t.c, "%s: outputs may not alias inputs", what);
+        TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx), "%s: gather-init mode needs dx == 0 and Zx", what);
+        TSPGNN_REQUIRE(!t.zbias || (t.zscale && !t.uv), "%s: zbias needs zscale and excludes gather-init mode", what);
+        TSPGNN_REQUIRE(tasks[k].mlp_layers == 0 || tasks[k].mlp_wb, "%s: mlp_layers > 0 needs mlp_wb", what);
+        TSPGNN_REQUIRE(!tasks[k].proj_w || (tasks[k].proj_out && tasks[k].mlp_layers > 0),
+                       "%s: a projection needs proj_out and at least one MLP layer", what);
+        live[n++] = tasks[k];
     }
     if (n == 0) return TSPGNN_OK;
-    return d == 32 ? launch_lnlstm_x3<32>(live, n, as_stream(stream)) : launch_lnlstm_x3<64>(live, n, as_stream(stream));
+    return d == 32 ? launch_cell_x3<32>(live, n, as_stream(stream), what) : launch_cell_x3<64>(live, n, as_stream(stream), what);
+}
+
+extern "C" int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream) {
+    return cell_mlp_x3(tasks, n_tasks, d, stream, "tspgnn_lnlstm_mlp_fwd_multi_x3");
+}
+
+extern "C" int tspgnn_lnlstm_fwd_multi_x3(const tspgnn_lstm_task* tasks, int n_tasks, int d, void* stream) {
+    TSPGNN_REQUIRE(tasks && n_tasks >= 1 && n_tasks <= kMaxTasks, "lnlstm_fwd_multi_x3: 1..%d tasks", kMaxTasks);
+    tspgnn_cell_mlp_task wrapped[kMaxTasks];
+    for (int k = 0; k < n_tasks; ++k) {
+        wrapped[k] = tspgnn_cell_mlp_task{};
+        wrapped[k].cell = tasks[k];
+    }
+    return cell_mlp_x3(wrapped, n_tasks, d, stream, "tspgnn_lnlstm_fwd_multi_x3");
 }

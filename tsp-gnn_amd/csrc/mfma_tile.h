@@ -90,35 +90,96 @@ __device__ __forceinline__ void ksteps(f32x4 (&acc)[NT], const float* w0, const 
     }
 }
 
-// Sum of the lane's D/4 values of one gate, reduced over the 4 lane groups that share a row.
+// LayerNorm of one gate of the lane's row: the lane holds D/4 of the D values (TPG tiles x 4), the other three
+// lane groups of the row hold the rest.  Written on float pairs so that it compiles to packed fp32 VALU
+// instructions (v_pk_add/mul/fma_f32: two values per lane per issue) -- the LayerNorm / gate arithmetic shares
+// the SIMD's issue port with the MFMAs (no co-execution), so every VALU instruction saved
+// is kernel time.  tf.contrib.layers.layer_norm semantics: biased variance, variance_epsilon = 1e-12.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 template <int TPG>
 __device__ __forceinline__ void ln_gate(f32x4 (&v)[TPG], const float* gamma, const float* beta, int g, int D) {
-    float s = 0.f;
+    f32x2 s2 = v[0].lo + v[0].hi;
 #pragma unroll
-    for (int t = 0; t < TPG; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
-    s = sum_over_lane_groups16(s);
-    const float mean = s / (float)D;
-    float q = 0.f;
+    for (int t = 1; t < TPG; ++t) s2 += v[t].lo + v[t].hi;
+    const float mean = sum_over_lane_groups16(s2[0] + s2[1]) * (1.0f / (float)D);
+    const f32x2 m2 = {mean, mean};
+    f32x2 q2 = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < TPG; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float dlt = v[t][r] - mean;
-            q = fmaf(dlt, dlt, q);
-        }
+    for (int t = 0; t < TPG; ++t) {  // centred values replace v: y = (x - mean) * (rstd * gamma) + beta
+        const f32x2 a = v[t].lo - m2, b = v[t].hi - m2;
+        q2 = fma2(a, a, q2);
+        q2 = fma2(b, b, q2);
+        v[t].lo = a;
+        v[t].hi = b;
     }
-    q = sum_over_lane_groups16(q);
-    const float var = q / (float)D;
-    // tf.contrib.layers.layer_norm: variance_epsilon = 1e-12; x*inv + (beta - mean*inv)
+    const float var = sum_over_lane_groups16(q2[0] + q2[1]) * (1.0f / (float)D);
     const float rstd = __builtin_amdgcn_rsqf(var + 1e-12f);  // v_rsq_f32, ~1 ulp
+    const f32x2 r2 = {rstd, rstd};
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
         const f32x4 ga = ld4(gamma + t * 16 + g * 4);
         const f32x4 be = ld4(beta + t * 16 + g * 4);
+        v[t].lo = fma2(v[t].lo, ga.lo * r2, be.lo);
+        v[t].hi = fma2(v[t].hi, ga.hi * r2, be.hi);
+    }
+}
+
+// 1/(1+e^-(x+shift)) on a pair: packed multiply-add feeding the two transcendental pairs (v_exp_f32, v_rcp_f32).
+__device__ __forceinline__ f32x2 sigmoid2(f32x2 x, float shift = 0.f) {
+    constexpr float L = -1.4426950408889634f;
+    const f32x2 l2 = {L, L}, sh = {L * shift, L * shift}, one = {1.f, 1.f};
+    const f32x2 t = fma2(x, l2, sh);
+    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    const f32x2 d = e + one;
+    return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ f32x2 relu2(f32x2 x) { return f32x2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)}; }
+
+// The cell arithmetic on the lane's part of a 16-row tile.  acc = z in the kernel's column order i, j, f, o (TPG
+// tiles each); cf = old c.  LN each gate; c' = LN_s(c*sig(f+1) + sig(i)*relu(j)); h' = relu(c')*sig(o); stores.
+template <int D>
+__device__ __forceinline__ void lstm_gates(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 16], const float* lds_ln, int g,
+                                           f32x4 (&hn)[D / 16], f32x4 (&nc)[D / 16]) {
+    constexpr int TPG = D / 16;
+    f32x4 gi[TPG], gj[TPG], gf[TPG], go[TPG];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float inv = rstd * ga[r];
-            v[t][r] = fmaf(v[t][r], inv, be[r] - mean * inv);
+    for (int t = 0; t < TPG; ++t) {
+        gi[t] = acc[t];
+        gj[t] = acc[TPG + t];
+        gf[t] = acc[2 * TPG + t];
+        go[t] = acc[3 * TPG + t];
+    }
+    ln_gate<TPG>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D);
+    ln_gate<TPG>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D);
+    ln_gate<TPG>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D);
+    ln_gate<TPG>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D);
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        nc[t].lo = fma2(sigmoid2(gi[t].lo), relu2(gj[t].lo), cf[t].lo * sigmoid2(gf[t].lo, 1.0f));
+        nc[t].hi = fma2(sigmoid2(gi[t].hi), relu2(gj[t].hi), cf[t].hi * sigmoid2(gf[t].hi, 1.0f));
+    }
+    ln_gate<TPG>(nc, lds_ln + 8 * D, lds_ln + 9 * D, g, D);
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        hn[t].lo = relu2(nc[t].lo) * sigmoid2(go[t].lo);
+        hn[t].hi = relu2(nc[t].hi) * sigmoid2(go[t].hi);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void lstm_epilogue(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 16], const float* lds_ln, int g,
+                                              bool valid, float* hd, float* cd) {
+    constexpr int TPG = D / 16;
+    f32x4 hn[TPG], nc[TPG];
+    lstm_gates<D>(acc, cf, lds_ln, g, hn, nc);
+    if (valid) {
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) {
+            st4(hd + t * 16, hn[t]);
+            st4(cd + t * 16, nc[t]);
         }
     }
 }

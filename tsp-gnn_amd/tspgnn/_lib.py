@@ -36,6 +36,7 @@ SIGNATURES = {
     "tspgnn_pack_weights_x3": [c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_mlp_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_lnlstm_mlp_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_mlp_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_gather_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -84,6 +85,12 @@ class LstmTask(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("dx", c_int), ("h", c_void_p), ("c", c_void_p), ("K", c_void_p), ("ln", c_void_p),
                 ("h_out", c_void_p), ("c_out", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p),
                 ("zbias", c_void_p), ("zscale", c_void_p)]
+
+
+class CellMlpTask(ctypes.Structure):
+    """tspgnn_cell_mlp_task (include/tspgnn.h): a cell update followed by the MLP that consumes the new h."""
+    _fields_ = [("cell", LstmTask), ("mlp_wb", c_void_p), ("mlp_layers", c_int), ("relu_mask", c_uint),
+                ("mlp_out", c_void_p), ("proj_w", c_void_p), ("proj_out", c_void_p)]
 
 
 class LstmBwdTask(ctypes.Structure):

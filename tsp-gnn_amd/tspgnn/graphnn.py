@@ -264,6 +264,7 @@ class LayerNormBasicLSTMCell(object):
         return self.store.packed(("lstm.pushed.x3" if x3 else "lstm.pushed", self.base, last), build)
 
     def pushed_task(self, x, state, out, kp, zb, deg):
+        """Cell task whose kernel operand is pushed_bias_pack's K' (either packing) and z starts at deg * zb."""
         return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(kp), _lib.ptr(self.ln()),
                              _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None, _lib.ptr(zb), _lib.ptr(deg))
 
@@ -529,14 +530,146 @@ class GraphNN(object):
             states[v] = LSTMStateTuple(c=c0, h=h0)
         folded = {v: self._folded(v, mats) for v in self.var}
         T = int(time_steps)
-        plan = self._plan(states, mats, folded) if T > 0 else None
-        if plan is not None:
-            for t in range(T):
-                plan[t & 1]()
-            return plan[2][T & 1]
+        if T > 0:
+            plan = self._plan_fused(states, mats, folded)
+            if plan is not None:
+                return plan(T)
+            plan = self._plan(states, mats, folded)
+            if plan is not None:
+                for t in range(T):
+                    plan[t & 1]()
+                return plan[2][T & 1]
         for _ in range(T):
             states = self._step(states, mats, dense_mats, folded)
         return states
+
+    def _x3_ok(self):
+        return self.gemm == "bf16x3" and all(c.x3_ok() for c in self._RNN_cells.values()) \
+            and all(m.sizes[-1] in (32, 64) for m in self._msg_MLPs.values())
+
+    def _plan_fused(self, states, mats, folded):
+        """bf16x3 plan with every message MLP fused behind the cell of its SOURCE variable: the launch that
+        updates the states of step t also evaluates msg(h') -- the messages of step t+1 -- on the rows it
+        still holds in registers (tspgnn_lnlstm_mlp_fwd_multi_x3), so a step is {adjacency products, one
+        cell+message launch}.  The messages of step 0 come from one plain MLP launch, the last step runs
+        the cells alone.  Applies when every variable's h feeds exactly one loop entry and that entry has a
+        single-kernel message MLP; returns run(T) -> states, or None."""
+        if not self._x3_ok():
+            return None
+        consumers = {u: [] for u in self.var}
+        for v in self.var:
+            for i, u in enumerate(self.loop[v]):
+                if "var" not in u or "fun" in u or "msg" not in u:
+                    return None
+                mlp = self._msg_MLPs[u["msg"]]
+                if len(mlp._chunks()) != 1 or mlp.n_square < 1 or mlp._plan[3]:
+                    return None
+                consumers[u["var"]].append((v, i))
+        if any(len(c) != 1 for c in consumers.values()):
+            return None
+        f32 = dict(dtype=torch.float32, device=self.store.theta.device)
+        buf = [{v: LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) for v, st in states.items()},
+               {v: LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h)) for v, st in states.items()}]
+        pushed = {v: self._pushable(v, mats, folded) for v in self.var}
+        # message outputs / projected messages, double-buffered by step parity (a launch reads one set and
+        # writes the other)
+        mo = [{}, {}]
+        zxs = [{}, {}]
+        for v in self.var:
+            for i, u in enumerate(self.loop[v]):
+                rows, width = states[u["var"]].h.shape[0], self._msg_MLPs[u["msg"]].sizes[-1]
+                for p in (0, 1):
+                    if folded[v] is not None:
+                        zxs[p][v] = torch.empty((rows, 4 * self.var[v]), **f32)
+                    else:
+                        mo[p][(v, i)] = torch.empty((rows, width), **f32)
+        keep = [buf, mo, zxs]
+
+        def message(v, i, p):
+            """(wb, n_layers, relu_mask, out, proj_w, proj_out) of loop entry (v, i) writing parity-p buffers."""
+            mlp = self._msg_MLPs[self.loop[v][i]["msg"]]
+            d = mlp.sizes[-1]
+            n = mlp.n_square - 1 if pushed[v] else mlp.n_square   # >= 1 (_pushable needs two square layers)
+            pw = po = None
+            if folded[v] is not None:
+                cv = self._RNN_cells[v]
+                pw, po = cv._packed_x3("lstm.kx.x3", 0, cv.dx), zxs[p][v]
+            out = mo[p].get((v, i))
+            return (mlp.wb_packed_x3(0, n - 1, d), n, mlp.relu_mask(0, n), out, pw, po)
+
+        def cell_tasks(p, with_messages):
+            src, dst = buf[p], buf[1 - p]
+            mid, tasks = [], {}
+            for v, d in self.var.items():
+                cell, st = self._RNN_cells[v], src[v]
+                out = (dst[v].h, dst[v].c)
+                if folded[v] is not None:
+                    t = cell.gather_task(mats[folded[v]["mat"]], zxs[p][v], st, out, x3=True)
+                else:
+                    inputs = []
+                    for i, u in enumerate(self.loop[v]):
+                        y = mo[p][(v, i)]
+                        if "mat" in u:
+                            adj, tr = mats[u["mat"]], u.get("transpose?", False)
+                            o = torch.empty((adj.shape[1] if tr else adj.shape[0], y.shape[1]), **f32)
+                            mid.append((adj.matmul, (y, tr, o)))
+                            y = o
+                        inputs.append(y)
+                    if len(inputs) == 1:
+                        x = inputs[0]
+                    else:
+                        x = torch.empty((st.h.shape[0], cell.dx), **f32)
+                        mid.append((lambda ins, o: torch.cat(ins, dim=1, out=o), (inputs, x)))
+                    if x.shape[0] != st.h.shape[0] or x.shape[1] != cell.dx:
+                        raise ValueError("cell input must be [%d,%d], got %s" % (st.h.shape[0], cell.dx, tuple(x.shape)))
+                    keep.append(x)
+                    if pushed[v]:
+                        u0 = self.loop[v][0]
+                        kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], x3=True)
+                        rowptr = (mats[u0["mat"]].csr_t if u0.get("transpose?", False) else mats[u0["mat"]].csr)[0]
+                        deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
+                        keep.append(deg)
+                        t = cell.pushed_task(x, st, out, kp, zb, deg)
+                    else:
+                        t = cell.task(x, st, out, x3=True)
+                if with_messages:   # the message MLP that reads this variable's new h in the next step
+                    (cv, ci), = consumers[v]
+                    wb, n, mask, mout, pw, po = message(cv, ci, 1 - p)
+                    ct = _lib.CellMlpTask(t, _lib.ptr(wb), n, mask, _lib.ptr(mout), _lib.ptr(pw), _lib.ptr(po))
+                else:
+                    ct = _lib.CellMlpTask(t, None, 0, 0, None, None, None)
+                tasks.setdefault(d, []).append(ct)
+            calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in tasks.items() for k in range(0, len(ts), 4)]
+            return mid, calls
+
+        # messages of step 0 from the initial states
+        pre = {}
+        for v in self.var:
+            for i, u in enumerate(self.loop[v]):
+                wb, n, mask, mout, pw, po = message(v, i, 0)
+                y = buf[0][u["var"]].h
+                if mout is None:
+                    mout = torch.empty((y.shape[0], self._msg_MLPs[u["msg"]].sizes[-1]), **f32)
+                    keep.append(mout)
+                pre.setdefault(self._msg_MLPs[u["msg"]].sizes[-1], []).append(
+                    _lib.MlpTask(_lib.ptr(y), _lib.ptr(wb), _lib.ptr(mout), None, 0, y.shape[0], n, mask,
+                                 _lib.ptr(pw), _lib.ptr(po)))
+        pre_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in pre.items() for k in range(0, len(ts), 4)]
+        steps = [cell_tasks(p, True) for p in (0, 1)]
+        lasts = [cell_tasks(p, False) for p in (0, 1)]
+        self._plan_keep = keep
+
+        def run(T):
+            for arr, d in pre_calls:
+                _lib.call_multi("tspgnn_mlp_fwd_multi_x3", arr, d)
+            for t in range(T):
+                mid, calls = (steps if t < T - 1 else lasts)[t & 1]
+                for fn, args in mid:
+                    fn(*args)
+                for arr, d in calls:
+                    _lib.call_multi("tspgnn_lnlstm_mlp_fwd_multi_x3", arr, d)
+            return buf[T & 1]
+        return run
 
     def _plan(self, states, mats, folded):
         """Pre-builds the launches of an even and an odd step over two ping-pong state buffers, so that
@@ -555,8 +688,7 @@ class GraphNN(object):
         buf = [{v: LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) for v, st in states.items()},
                {v: LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h)) for v, st in states.items()}]
         runs, keep = [], []
-        x3 = self.gemm == "bf16x3" and all(c.x3_ok() for c in self._RNN_cells.values()) \
-            and all(m.sizes[-1] in (32, 64) for m in self._msg_MLPs.values())
+        x3 = self._x3_ok()
         for p in (0, 1):
             src_states, dst_states = buf[p], buf[1 - p]
             mlp_tasks, lstm_tasks, mid, msg_out, zxs = {}, {}, [], {}, {}
