@@ -271,7 +271,7 @@ struct CellTaskTableX3 {
 };
 
 template <int D>
-__global__ __launch_bounds__(512) void lnlstm_mlp_fwd_x3_kernel(const CellTaskTableX3 tt) {
+__global__ __launch_bounds__(768) void lnlstm_mlp_fwd_x3_kernel(const CellTaskTableX3 tt) {
     constexpr int NT4 = D / 4, TPG = D / 16, KBH = D / 32;
     constexpr int LAYER_BYTES = 3 * D * D * 2 + D * 4;  // { hi, mid, lo, bias } of one MLP layer in global memory
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -554,13 +554,14 @@ static int launch_cell_x3(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
         }
         if (need > lds_w) lds_w = need;
         const long long tiles = ((long long)c.rows + 15) / 16;
+        // a lock-step task is a latency chain (several LDS re-stagings per round): it gets workgroups for one round
         cost[k] = tiles * (KBT * 4 + 2 * L + (tasks[k].proj_w ? 8 : 0) + 6) * (tt.kbc[k] < KBT ? 2 : 1);
         tiles_all += tiles;
     }
     tt.n = n;
     const size_t lds_bytes = lds_w + head;
     int grid = n_cus();
-    const int nw = tiles_all <= (long long)grid * 4 ? 4 : 8;
+    const int nw = tiles_all <= (long long)grid * 4 ? 4 : (tiles_all <= (long long)grid * 8 ? 8 : 12);
     const long long max_grid = (tiles_all + nw - 1) / nw;
     if (grid > max_grid) grid = (int)max_grid;
     grid = split_blocks_x3(cost, n, grid, tt.blk_end);
