@@ -48,10 +48,11 @@ def spmm_bytes(N, M, d, eb=4, ib=4):
 def dense_flops_per_step(N, M, d, folded=True):
     """MFMA work per message-passing step.  Reference op count: two 4-layer d x d MLPs and two [2d,4d]
     LSTM GEMMs on M+N rows.  Executed (folded=True): the x-half of the edge cell's GEMM runs on the N
-    vertex rows ((EV y)Kx = EV(y Kx)) instead of the M edge rows."""
-    mlp = (M + N) * 4 * 2 * d * d
+    vertex rows ((EV y)Kx = EV(y Kx)) instead of the M edge rows, and the edge message MLP's last (linear)
+    layer is pushed through the row-sum into the vertex cell's kernel (3 layers on the M edge rows)."""
     if not folded:
-        return mlp + (M + N) * 2 * 2 * d * 4 * d
+        return (M + N) * 4 * 2 * d * d + (M + N) * 2 * 2 * d * 4 * d
+    mlp = M * 3 * 2 * d * d + N * 4 * 2 * d * d
     return mlp + M * 2 * d * 4 * d + N * 2 * 2 * d * 4 * d + N * 2 * d * 4 * d
 
 
@@ -224,16 +225,16 @@ def main():
         }
         dense_names = ("tspgnn_mlp_fwd_f32", "tspgnn_mlp_fwd_multi_f32", "tspgnn_lnlstm_fwd_f32",
                        "tspgnn_lnlstm_fwd_multi_f32", "tspgnn_lnlstm_gather_fwd_f32", "tspgnn_linear_f32",
-                       "tspgnn_mlp_fwd_multi_x3", "tspgnn_lnlstm_fwd_multi_x3")
+                       "tspgnn_mlp_fwd_multi_x3", "tspgnn_lnlstm_fwd_multi_x3", "tspgnn_lnlstm_mlp_fwd_multi_x3")
         dense_us = sum(v["total_us"] for k, v in kernels_us.items() if k in dense_names)
-        x3 = "tspgnn_lnlstm_fwd_multi_x3" in kernels_us
+        x3 = any(k.endswith("_x3") and "pack" not in k for k in kernels_us)
         # bf16x3: every fp32 product costs six bf16 MFMA terms -> the matrix-pipe ceiling in fp32-equivalent flops
         dense_peak = BF16_MFMA_PEAK_TF / 6.0 if x3 else FP32_MFMA_PEAK_TF
         # E_vote's 3 hidden layers also run through mlp_fwd: count their flops too
         dense_flops = T * dense_flops_per_step(N, M, d, folded=True) + M * 3 * 2 * d * d
         roofline_dense = {
-            "kernel": ("mlp_fwd_multi_x3 + lnlstm_fwd_multi_x3 (v_mfma_f32_16x16x32_bf16 on exact 3-way bf16 splits, "
-                       "6 terms per fp32 product; peak = bf16 dense peak / 6)") if x3 else
+            "kernel": ("lnlstm_mlp_fwd_multi_x3 (+ mlp_fwd_multi_x3, fp32 vote MLP): v_mfma_f32_16x16x32_bf16 on exact "
+                       "3-way bf16 splits, 6 terms per fp32 product; peak = bf16 dense peak / 6") if x3 else
                       "mlp_fwd_multi + lnlstm_fwd_multi + linear (fp32 MFMA v_mfma_f32_16x16x4_f32)",
             "bound": "mfma", "achieved": round(dense_flops / (dense_us * 1e-6) / 1e12, 2) if dense_us else None,
             "peak": round(dense_peak, 1), "unit": "TFLOP/s (fp32-equivalent)" if x3 else "TFLOP/s",

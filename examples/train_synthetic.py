@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Drop-in demonstration: the reference's run_batch (/root/reference/train.py:17-63) running unchanged on
+"""Drop-in demonstration: the reference's run_batch (/root/reference/train.py:17-63; tspgnn/train.py) running on
 the MI355X path, over synthetic Euclidean instances (no Concorde, no dataset on disk).
 
     python examples/train_synthetic.py -d 64 -timesteps 32 -batchsize 8 -epochs 2 --batches 8
@@ -18,24 +18,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tsp-gnn_amd"))
 from tspgnn import InstanceLoader, Session, build_network, global_variables_initializer, random_instance  # noqa: E402
-
-
-def run_batch(sess, model, batch, batch_i, epoch_i, time_steps, train=False, verbose=True):
-    # body identical in structure to train.py:17-63
-    EV, W, C, route_exists, n_vertices, n_edges = batch
-    feed_dict = {model['EV']: EV, model['W']: W, model['C']: C, model['time_steps']: time_steps,
-                 model['route_exists']: route_exists, model['n_vertices']: n_vertices, model['n_edges']: n_edges}
-    if train:
-        outputs = [model['train_step'], model['loss'], model['acc'], model['predictions'], model['TP'], model['FP'],
-                   model['TN'], model['FN']]
-    else:
-        outputs = [model['loss'], model['acc'], model['predictions'], model['TP'], model['FP'], model['TN'], model['FN']]
-    loss, acc, predictions, TP, FP, TN, FN = sess.run(outputs, feed_dict=feed_dict)[-7:]
-    if verbose:
-        print('{} Epoch {} Batch {}\t|\t(n,m,batch size)=({},{},{})\t|\t(Loss,Acc)=({:.4f},{:.4f})\t|\tAvg. (Sat,Prediction)=({:.4f},{:.4f})'
-              .format('Train' if train else 'Test', epoch_i, batch_i, np.sum(n_vertices), np.sum(n_edges),
-                      n_vertices.shape[0], loss, acc, np.mean(route_exists), np.mean(np.round(predictions))), flush=True)
-    return loss, acc, np.mean(route_exists), np.mean(predictions), TP, FP, TN, FN
+from tspgnn.train import run_batch, summarize_epoch  # noqa: E402,F401
 
 
 if __name__ == '__main__':

@@ -368,3 +368,48 @@ def test_batch_prefetcher_feeds_identical_batches(cuda_device):
     got = [sess.forward_device(b)["predictions"].clone() for b in tspgnn.BatchPrefetcher(sess, host_batches, 3)]
     torch.cuda.synchronize()
     assert len(got) == 4 and all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+def test_save_and_load_weights_roundtrip_with_optimizer_state(cuda_device, tmp_path, capsys):
+    """util.save_weights / load_weights (reference util.py:5-37): TensorFlow-bundle files keyed by TF variable names;
+    a restored session continues training on exactly the trajectory of the one that saved."""
+    from tspgnn.train import run_batch
+    t = pack_tuple("ragged_B6", 0)
+    params = P.init_params(32, seed=4, perturb=True)
+
+    def fresh():
+        model = tspgnn.build_network(32)
+        sess = tspgnn.Session(model)
+        sess.run(tspgnn.global_variables_initializer())
+        return model, sess
+    model, sess = fresh()
+    model.store.load(params)
+    for i in range(2):
+        run_batch(sess, model, t, i, 0, 3, train=True, verbose=(i == 0))
+    assert "Train Epoch 0 Batch 0" in capsys.readouterr().out
+    path = str(tmp_path / "checkpoints" / "epoch=7")
+    tspgnn.save_weights(sess, path)
+    names = set(tspgnn.tf_checkpoint.read_bundle(path + "/model.ckpt"))
+    assert "TSP/E_cell/layer_norm_basic_lstm_cell/kernel" in names and "TSP/V_init/Adam" not in names
+    assert "V_init/Adam_1" in names and "beta2_power" in names
+    out_a = run_batch(sess, model, t, 2, 0, 3, train=True, verbose=False)
+    theta_a = model.store.theta.clone()
+
+    model_b, sess_b = fresh()
+    assert tspgnn.load_weights(sess_b, path) == 7
+    assert int(sess_b._adam["t"].item()) == 2
+    out_b = run_batch(sess_b, model_b, t, 2, 0, 3, train=True, verbose=False)
+    assert out_a[0] == out_b[0] and torch.equal(theta_a, model_b.store.theta)
+    # scope-restricted restore only touches that scope
+    model_c, sess_c = fresh()
+    before = model_c.store.state_dict()
+    tspgnn.load_weights(sess_c, path, scope="TSP/")
+    after = model_c.store.state_dict()
+    saved = tspgnn.tf_checkpoint.read_bundle(path + "/model.ckpt")
+    for k in before:
+        if k.startswith("TSP/"):
+            assert np.array_equal(after[k], saved[k])
+        else:
+            assert np.array_equal(after[k], before[k])
+    with pytest.raises(Exception):
+        tspgnn.load_weights(sess_c, str(tmp_path / "nope" / "epoch=1"))

@@ -13,9 +13,13 @@ from .mlp import Mlp
 from .parallel import BatchPrefetcher, shard_instances
 from .model import build_network, Session, global_variables_initializer
 from .variables import VariableStore, get_default_store, reset_default_store
+from . import tf_checkpoint
+from .util import load_weights, save_weights
+from .train import run_batch, summarize_epoch
 
 __all__ = [
     "TspgnnError", "GraphNN", "LSTMStateTuple", "DeviceAdjacency", "LayerNormBasicLSTMCell", "InstanceLoader",
     "SparseEV", "read_graph", "write_graph", "synthetic_batch", "random_instance", "Mlp", "build_network",
     "Session", "global_variables_initializer", "get_cost", "BatchPrefetcher", "shard_instances", "VariableStore", "get_default_store", "reset_default_store",
+    "load_weights", "save_weights", "run_batch", "summarize_epoch",
 ]
