@@ -413,3 +413,48 @@ def test_save_and_load_weights_roundtrip_with_optimizer_state(cuda_device, tmp_p
             assert np.array_equal(after[k], before[k])
     with pytest.raises(Exception):
         tspgnn.load_weights(sess_c, str(tmp_path / "nope" / "epoch=1"))
+
+
+@pytest.mark.parametrize("d", [32, 64])
+@pytest.mark.parametrize("sizes,T", [((2,), 3), ((2, 3), 1), ((3, 2, 5, 2), 4), ((17,), 2)])
+def test_tiny_and_single_graph_batches(cuda_device, d, sizes, T):
+    """Degenerate shapes: a 2-vertex graph is ONE edge (M=1 < one 16-row tile), batches of one graph,
+    tiles that straddle several graphs.  Same parity bar as the full-size cases."""
+    rng = np.random.RandomState(sum(sizes) + d)
+    instances = [tspgnn.random_instance(n, rng) for n in sizes]
+    t = tspgnn.InstanceLoader.create_batch(instances, dev=0.02)
+    params = P.init_params(d, seed=21, perturb=True)
+    hip = run_hip(d, params, t, T)
+    batch = {"ev_uv": t[0].uv, "W": t[1], "C": t[2], "route_exists": t[3], "n_vertices": t[4], "n_edges": t[5]}
+    ref = TO.forward(TO.to_torch(params, torch.float64), batch, T)
+    assert hip["predictions"].shape == (len(sizes),)
+    assert rel_err(hip["predictions"], ref["predictions"].numpy()) < REL_TOL
+    assert rel_err(hip["last_states"]["E"].h, ref["last_states"]["E"][0].numpy()) < REL_TOL
+    assert rel_err(hip["last_states"]["V"].c, ref["last_states"]["V"][1].numpy()) < REL_TOL
+    assert abs(float(hip["loss"]) - ref["loss"].item()) < REL_TOL
+
+
+def test_vertex_without_edges_and_training_on_tiny_batch(cuda_device):
+    """A vertex of degree 0 (empty CSR row: its cell input is the zero vector, its bias-init scale is 0) and a
+    training step on a batch smaller than one tile."""
+    d, T = 64, 3
+    Ma = np.zeros((4, 4), dtype=int)
+    Ma[0, 1] = Ma[1, 2] = 1                      # vertex 3 is isolated
+    Mw = np.random.RandomState(0).rand(4, 4)
+    t = tspgnn.InstanceLoader.create_batch([(Ma, Mw, [0, 1, 2, 3]), (Ma, Mw, [0, 1, 2, 3])], dev=0.02)
+    params = P.init_params(d, seed=2, perturb=True)
+    hip = run_hip(d, params, t, T)
+    batch = {"ev_uv": t[0].uv, "W": t[1], "C": t[2], "route_exists": t[3], "n_vertices": t[4], "n_edges": t[5]}
+    ref = TO.forward(TO.to_torch(params, torch.float64), batch, T)
+    assert rel_err(hip["last_states"]["V"].h, ref["last_states"]["V"][0].numpy()) < REL_TOL
+    assert rel_err(hip["predictions"], ref["predictions"].numpy()) < REL_TOL
+    model = tspgnn.build_network(d)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    out = tspgnn.run_batch(sess, model, t, 0, 0, T, train=True, verbose=False)
+    ref_out, _, _, _, gn = TO.train_step({k: v.copy() for k, v in params.items()}, batch, T,
+                                         {k: np.zeros_like(v) for k, v in params.items()},
+                                         {k: np.zeros_like(v) for k, v in params.items()}, 1)
+    assert abs(float(out[0]) - ref_out["loss"].item()) < REL_TOL
+    assert abs(float(sess._adam["gnorm"].item()) - gn) < 2e-5 * gn
