@@ -866,6 +866,9 @@ class GraphNN(object):
             if u is not None:
                 tape.ZX[v] = torch.empty((T, rows_x, 4 * self.var[v]), **f32)
         tape.acts = {}
+        x3 = self._x3_ok()   # forward GEMMs on the bf16 matrix cores (fp32-class accuracy); backward stays fp32 MFMA
+        mlp_fn = "tspgnn_mlp_fwd_multi_x3" if x3 else "tspgnn_mlp_fwd_multi_f32"
+        lstm_fn = "tspgnn_lnlstm_fwd_multi_x3" if x3 else "tspgnn_lnlstm_fwd_multi_f32"
         for v in self.var:
             tape.H[v][0].copy_(initial_embeddings[v])
             tape.C[v][0].zero_()
@@ -887,9 +890,14 @@ class GraphNN(object):
                         acts = tape.acts[(v, i)]
                         to_tape = tape.folded[v] is not None or (single and "mat" not in u)
                         out = tape.X[v][t] if to_tape else torch.empty((n[src], mlp.sizes[-1]), **f32)
-                        proj = (self._RNN_cells[v].kx_packed(), tape.ZX[v][t]) if tape.folded[v] is not None else None
-                        task = mlp.task(y, out, acts[:, t], acts.stride(0), proj=proj)
+                        proj = None
+                        if tape.folded[v] is not None:
+                            cv = self._RNN_cells[v]
+                            proj = (cv._packed_x3("lstm.kx.x3", 0, cv.dx) if x3 else cv.kx_packed(), tape.ZX[v][t])
+                        task = mlp.task(y, out, acts[:, t], acts.stride(0), proj=proj, x3=x3)
                         if task is None:
+                            if x3:
+                                raise NotImplementedError("bf16x3 training forward needs single-kernel message MLPs")
                             mlp.forward_saving(y, out, acts[:, t], acts.stride(0))
                             if proj is not None:
                                 self._RNN_cells[v].premultiply(out, out=tape.ZX[v][t])
@@ -899,7 +907,7 @@ class GraphNN(object):
                     msg_out[(v, i)] = y
             for d, ts in mlp_tasks.items():
                 for k in range(0, len(ts), 4):
-                    _lib.call_multi("tspgnn_mlp_fwd_multi_f32", ts[k:k + 4], d)
+                    _lib.call_multi(mlp_fn, ts[k:k + 4], d)
             # ---- B: adjacency products / vertex-side pre-multiplication
             for v in self.var:
                 if tape.folded[v] is not None:
@@ -927,13 +935,13 @@ class GraphNN(object):
                 st = LSTMStateTuple(c=tape.C[v][t], h=tape.H[v][t])
                 out = (tape.H[v][t + 1], tape.C[v][t + 1])
                 if tape.folded[v] is not None:
-                    task = cell.gather_task(mats[tape.folded[v]["mat"]], tape.ZX[v][t], st, out)
+                    task = cell.gather_task(mats[tape.folded[v]["mat"]], tape.ZX[v][t], st, out, x3=x3)
                 else:
-                    task = cell.task(tape.X[v][t], st, out)
+                    task = cell.task(tape.X[v][t], st, out, x3=x3)
                 lstm_tasks.setdefault(d, []).append(task)
             for d, ts in lstm_tasks.items():
                 for k in range(0, len(ts), 4):
-                    _lib.call_multi("tspgnn_lnlstm_fwd_multi_f32", ts[k:k + 4], d)
+                    _lib.call_multi(lstm_fn, ts[k:k + 4], d)
         states = {v: LSTMStateTuple(c=tape.C[v][T], h=tape.H[v][T]) for v in self.var}
         return states, tape
 
