@@ -113,6 +113,14 @@ if d in (32, 64):
     tgv = _lib.task_array([tg[0], tv[0]])
     t = timeit(lambda: _lib.call_multi("tspgnn_lnlstm_fwd_multi_x3", tgv, d))
     res["x3_lstm_step"] = (t, (M + 2 * N) * 2 * d * 4 * d / t / 1e6)
+    # fused cell + next step's message MLP (tspgnn_lnlstm_mlp_fwd_multi_x3): edge task, vertex task, both
+    Ae = torch.empty(M, d, device=dev); Yv = torch.empty(N, d, device=dev)
+    ce = _lib.CellMlpTask(tg[0], _lib.ptr(wbe), 3, 7, _lib.ptr(Ae), None, None)
+    cv = _lib.CellMlpTask(tv[0], _lib.ptr(wbv), 4, 7, None, _lib.ptr(proj), _lib.ptr(Zv3))
+    for tag, ts in (("E", [ce]), ("V", [cv]), ("step", [ce, cv])):
+        arr = _lib.task_array(ts)
+        t = timeit(lambda: _lib.call_multi("tspgnn_lnlstm_mlp_fwd_multi_x3", arr, d))
+        res["x3_fused_" + tag] = (t, 0.0)
 for k, (t, r) in res.items():
     unit = "GB/s" if k in ("gather2", "rowsum") else "TFLOP/s"
     print("%-12s %8.2f us  %8.1f %s" % (k, t, r, unit))
