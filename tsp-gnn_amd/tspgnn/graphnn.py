@@ -543,7 +543,11 @@ class GraphNN(object):
             states = self._step(states, mats, dense_mats, folded)
         return states
 
-    def _x3_ok(self):
+    def _x3_ok(self, n_rows=None):
+        """The bf16x3 kernels cover this network (widths 32/64, cell inputs in multiples of 32) and, when the row
+        counts are given, this batch (they address rows with 32-bit element offsets: rows * 4d < 2^30)."""
+        if n_rows is not None and any(int(n) * 4 * self.var[v] >= 2 ** 30 for v, n in n_rows.items()):
+            return False
         return self.gemm == "bf16x3" and all(c.x3_ok() for c in self._RNN_cells.values()) \
             and all(m.sizes[-1] in (32, 64) for m in self._msg_MLPs.values())
 
@@ -554,7 +558,7 @@ class GraphNN(object):
         cell+message launch}.  The messages of step 0 come from one plain MLP launch, the last step runs
         the cells alone.  Applies when every variable's h feeds exactly one loop entry and that entry has a
         single-kernel message MLP; returns run(T) -> states, or None."""
-        if not self._x3_ok():
+        if not self._x3_ok({v: st.h.shape[0] for v, st in states.items()}):
             return None
         consumers = {u: [] for u in self.var}
         for v in self.var:
@@ -688,7 +692,7 @@ class GraphNN(object):
         buf = [{v: LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) for v, st in states.items()},
                {v: LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h)) for v, st in states.items()}]
         runs, keep = [], []
-        x3 = self._x3_ok()
+        x3 = self._x3_ok({v: st.h.shape[0] for v, st in states.items()})
         for p in (0, 1):
             src_states, dst_states = buf[p], buf[1 - p]
             mlp_tasks, lstm_tasks, mid, msg_out, zxs = {}, {}, [], {}, {}
@@ -866,7 +870,8 @@ class GraphNN(object):
             if u is not None:
                 tape.ZX[v] = torch.empty((T, rows_x, 4 * self.var[v]), **f32)
         tape.acts = {}
-        x3 = self._x3_ok()   # forward GEMMs on the bf16 matrix cores (fp32-class accuracy); backward stays fp32 MFMA
+        # forward GEMMs on the bf16 matrix cores (fp32-class accuracy); backward stays fp32 MFMA
+        x3 = self._x3_ok({v: initial_embeddings[v].shape[0] for v in self.var})
         mlp_fn = "tspgnn_mlp_fwd_multi_x3" if x3 else "tspgnn_mlp_fwd_multi_f32"
         lstm_fn = "tspgnn_lnlstm_fwd_multi_x3" if x3 else "tspgnn_lnlstm_fwd_multi_f32"
         for v in self.var:
