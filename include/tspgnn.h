@@ -174,6 +174,35 @@ typedef struct tspgnn_cell_mlp_task {
 } tspgnn_cell_mlp_task;
 int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream);
 
+/* ------------------------------------------------------------------ bf16 storage, fp32 accumulate
+ *
+ * BASELINE config 5 ("bf16 embeddings with fp32 accumulate"): the same forward operators with
+ * the embeddings h, the messages, the aggregates and the projected messages Zx stored as bf16 (void* = bf16
+ * rows, row-major, 16-byte aligned), GEMMs as bf16 MFMA products accumulated in fp32, and the cell state c, the
+ * LayerNorm statistics / parameters, the biases and the gate arithmetic in fp32.  Weight operands are the fp32
+ * variables rounded to bf16: piece 0 (the first krows*ncols bf16) of tspgnn_pack_weights_x3.
+ *   tspgnn_gather2_sum_bf16 / tspgnn_csr_rowsum_bf16: tf.matmul(EV, y [, adjoint_a]) (graphnn.py:156-160), sums in
+ *     fp32, one rounding at the store; d % 8 == 0 (gather), d in {32..512} (row-sum).
+ *   mlp task:  wb = n_layers blocks of { bf16 packed[d*d], float bias[d] }, hidden activations rounded to bf16
+ *     between layers (what a stored embedding would be); proj_w = bf16 packed [d,4d], proj_out bf16 [rows,4d].
+ *   lstm task: x, h, h_out, Zx bf16; c, c_out, ln fp32; K = bf16 packed kernel[dx+d,4d] (Kh[d,4d] in gather-init
+ *     mode, uv != NULL); a kernel larger than LDS is streamed in k-block chunks.  d in {32, 64, 128}.
+ */
+int tspgnn_gather2_sum_bf16(const int32_t* ev_uv, const void* X, void* Y, int M, int N, int d, void* stream);
+int tspgnn_csr_rowsum_bf16(const int32_t* rowptr, const int32_t* eid, const void* X, void* Y, int N, int M, int d,
+                           void* stream);
+typedef struct tspgnn_mlp_task_bf16 {
+    const void* X; const void* wb; void* Y; int rows; int n_layers; unsigned relu_mask;
+    const void* proj_w; void* proj_out;
+} tspgnn_mlp_task_bf16;
+typedef struct tspgnn_lstm_task_bf16 {
+    const void* x; int dx; const void* h; const float* c; const void* K; const float* ln;
+    void* h_out; float* c_out; int rows;
+    const int32_t* uv; const void* Zx;
+} tspgnn_lstm_task_bf16;
+int tspgnn_mlp_fwd_multi_bf16(const tspgnn_mlp_task_bf16* tasks, int n_tasks, int d, void* stream);
+int tspgnn_lnlstm_fwd_multi_bf16(const tspgnn_lstm_task_bf16* tasks, int n_tasks, int d, void* stream);
+
 /* ------------------------------------------------------------------ pre / post loop */
 
 /*

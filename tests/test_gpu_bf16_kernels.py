@@ -1,0 +1,161 @@
+"""bf16-storage / fp32-accumulate kernels (BASELINE config 5) vs a float64 NumPy restatement that rounds to bf16
+at the same points: inputs, weights, every stored activation.  Quantities that are not rounded on the way (the
+cell state c') are held to the fp32 bar; bf16 outputs may differ by one bf16 ulp (2^-8 relative) where the two
+sides land on different sides of a rounding boundary."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import np_oracle as NO
+from tspgnn import _lib
+
+pytestmark = pytest.mark.gpu
+
+_KEEP = []
+BF16_TOL = 1.2e-2     # max-norm relative: a few bf16 ulps through a 4-layer chain
+F32_TOL = 5e-6
+
+
+def rb(x):
+    """Round to bf16 (nearest even), back in float64."""
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+def dev(a, device, dtype=np.float32):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(device)
+    _KEEP.append(t)
+    return t
+
+
+def dev_bf16(a, device):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).to(device)
+    _KEEP.append(t)
+    return t
+
+
+def f64(t):
+    return t.to(torch.float64).cpu().numpy()
+
+
+@pytest.fixture(autouse=True)
+def _release_uploads():
+    yield
+    torch.cuda.synchronize()
+    del _KEEP[:]
+
+
+def packed_bf16(W, device):
+    """Piece 0 of tspgnn_pack_weights_x3 = the weights rounded to bf16 in MFMA fragment order (bytes)."""
+    src = dev(W, device)
+    out = torch.empty(3 * W.size * 2, dtype=torch.uint8, device=device)
+    _KEEP.append(out)
+    _lib.call("tspgnn_pack_weights_x3", _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], None)
+    return out[:W.size * 2]
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 24])
+def test_gather2_and_rowsum_bf16(cuda_device, d):
+    rng = np.random.RandomState(d)
+    N, M = 257, 3001
+    uv = np.stack([rng.randint(0, N, M), rng.randint(0, N, M)], 1).astype(np.int32)
+    X = rng.randn(N, d)
+    Y = torch.empty((M, d), dtype=torch.bfloat16, device=cuda_device)
+    _lib.call("tspgnn_gather2_sum_bf16", _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev_bf16(X, cuda_device)), _lib.ptr(Y),
+              M, N, d, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(f64(Y), rb(rb(X)[uv[:, 0]] + rb(X)[uv[:, 1]]))      # one fp32 add, one rounding: exact
+    if d == 24:
+        return
+    counts = rng.randint(0, 50, N)
+    counts[3] = 0
+    rowptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    eid = rng.randint(0, M, int(rowptr[-1])).astype(np.int32)
+    Z = rng.randn(M, d)
+    out = torch.empty((N, d), dtype=torch.bfloat16, device=cuda_device)
+    _lib.call("tspgnn_csr_rowsum_bf16", _lib.ptr(dev(rowptr, cuda_device, np.int32)), _lib.ptr(dev(eid, cuda_device, np.int32)),
+              _lib.ptr(dev_bf16(Z, cuda_device)), _lib.ptr(out), N, M, d, None)
+    torch.cuda.synchronize()
+    ref = np.stack([rb(Z)[eid[rowptr[r]:rowptr[r + 1]]].sum(0) for r in range(N)])
+    got = f64(out)
+    assert np.all(got[3] == 0)
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) < 2.0 ** -8 + 1e-6       # one bf16 rounding
+
+
+def mlp_blocks_bf16(layers, device):
+    parts = []
+    for W, b in layers:
+        parts.append(packed_bf16(W, device).cpu().numpy())
+        parts.append(np.ascontiguousarray(b, dtype=np.float32).view(np.uint8))
+    return dev(np.concatenate(parts), device, np.uint8)
+
+
+@pytest.mark.parametrize("d", [32, 64, 128])
+@pytest.mark.parametrize("rows", [1, 333, 20000])
+def test_mlp_bf16_two_tasks_with_projection(cuda_device, d, rows):
+    rng = np.random.RandomState(d + rows)
+    rows_b = max(1, rows // 7)
+    Xa, Xb = rng.randn(rows, d), rng.randn(rows_b, d)
+    la = [((rng.randn(d, d) / np.sqrt(d)).astype(np.float32), (0.1 * rng.randn(d)).astype(np.float32)) for _ in range(3)]
+    lb = [((rng.randn(d, d) / np.sqrt(d)).astype(np.float32), (0.1 * rng.randn(d)).astype(np.float32)) for _ in range(4)]
+    P = (rng.randn(d, 4 * d) / np.sqrt(d)).astype(np.float32)
+    Ya = torch.empty((rows, d), dtype=torch.bfloat16, device=cuda_device)
+    Yb = torch.empty((rows_b, d), dtype=torch.bfloat16, device=cuda_device)
+    Zb = torch.empty((rows_b, 4 * d), dtype=torch.bfloat16, device=cuda_device)
+    ta = _lib.MlpTaskB(_lib.ptr(dev_bf16(Xa, cuda_device)), _lib.ptr(mlp_blocks_bf16(la, cuda_device)), _lib.ptr(Ya), rows, 3, 0b111,
+                       None, None)
+    tb = _lib.MlpTaskB(_lib.ptr(dev_bf16(Xb, cuda_device)), _lib.ptr(mlp_blocks_bf16(lb, cuda_device)), _lib.ptr(Yb), rows_b, 4,
+                       0b0111, _lib.ptr(packed_bf16(P, cuda_device)), _lib.ptr(Zb))
+    _lib.call_multi("tspgnn_mlp_fwd_multi_bf16", [ta, tb], d)
+    torch.cuda.synchronize()
+
+    def chain(x, layers, relus):
+        x = rb(x)
+        for (W, b), r in zip(layers, relus):
+            x = rb(NO.dense(x, rb(W), b.astype(np.float64), r))
+        return x
+    ra, rbb = chain(Xa, la, [True] * 3), chain(Xb, lb, [True, True, True, False])
+    assert rel_err(f64(Ya), ra) < BF16_TOL
+    assert rel_err(f64(Yb), rbb) < BF16_TOL
+    assert rel_err(f64(Zb), f64(Yb) @ rb(P)) < 2.0 ** -7       # projection of the kernel's own (stored) Y: one rounding
+
+
+def ln_params(rng, d):
+    ln = np.stack([np.stack([1 + 0.2 * rng.randn(d), 0.2 * rng.randn(d)]) for _ in range(5)]).astype(np.float32)
+    names = ("input", "transform", "forget", "output", "state")
+    return ln, {g: (ln[i, 0].astype(np.float64), ln[i, 1].astype(np.float64)) for i, g in enumerate(names)}
+
+
+@pytest.mark.parametrize("d", [32, 64, 128])
+def test_lnlstm_bf16_gather_and_plain_tasks(cuda_device, d):
+    """Edge-style task (gather-init from bf16 Zx, Kh resident) and vertex-style task (x|h with the [2d,4d] kernel,
+    streamed through LDS at d=128) in one launch."""
+    rng = np.random.RandomState(7 + d)
+    N, M = 301, 5003
+    uv = np.stack([rng.randint(0, N, M), rng.randint(0, N, M)], 1).astype(np.int32)
+    Zx = rng.randn(N, 4 * d)
+    he, ce = rng.randn(M, d), rng.randn(M, d).astype(np.float32)
+    Kh = (rng.randn(d, 4 * d) / np.sqrt(d)).astype(np.float32)
+    ln_e, lnd_e = ln_params(rng, d)
+    xv, hv, cv = rng.randn(N, d), rng.randn(N, d), rng.randn(N, d).astype(np.float32)
+    Kv = (rng.randn(2 * d, 4 * d) / np.sqrt(2 * d)).astype(np.float32)
+    ln_v, lnd_v = ln_params(rng, d)
+    he_o = torch.empty((M, d), dtype=torch.bfloat16, device=cuda_device)
+    ce_o = torch.empty((M, d), dtype=torch.float32, device=cuda_device)
+    hv_o = torch.empty((N, d), dtype=torch.bfloat16, device=cuda_device)
+    cv_o = torch.empty((N, d), dtype=torch.float32, device=cuda_device)
+    te = _lib.LstmTaskB(None, 0, _lib.ptr(dev_bf16(he, cuda_device)), _lib.ptr(dev(ce, cuda_device)), _lib.ptr(packed_bf16(Kh, cuda_device)),
+                        _lib.ptr(dev(ln_e, cuda_device)), _lib.ptr(he_o), _lib.ptr(ce_o), M,
+                        _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev_bf16(Zx, cuda_device)))
+    tv = _lib.LstmTaskB(_lib.ptr(dev_bf16(xv, cuda_device)), d, _lib.ptr(dev_bf16(hv, cuda_device)), _lib.ptr(dev(cv, cuda_device)),
+                        _lib.ptr(packed_bf16(Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o), N,
+                        None, None)
+    _lib.call_multi("tspgnn_lnlstm_fwd_multi_bf16", [te, tv], d)
+    torch.cuda.synchronize()
+    z0 = rb(Zx)[uv[:, 0]] + rb(Zx)[uv[:, 1]]
+    rh, rc = NO.lnlstm(np.zeros((M, 0)), rb(he), ce.astype(np.float64), rb(Kh), lnd_e, z0=z0)
+    assert rel_err(ce_o.cpu().numpy(), rc) < F32_TOL            # nothing is rounded on the way to c'
+    assert rel_err(f64(he_o), rb(rh)) < 2.0 ** -7
+    rh, rc = NO.lnlstm(rb(xv), rb(hv), cv.astype(np.float64), rb(Kv), lnd_v)
+    assert rel_err(cv_o.cpu().numpy(), rc) < F32_TOL
+    assert rel_err(f64(hv_o), rb(rh)) < 2.0 ** -7

@@ -43,6 +43,10 @@ SIGNATURES = {
                                      c_int, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_gather_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_gather2_sum_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tspgnn_csr_rowsum_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tspgnn_mlp_fwd_multi_bf16": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_lnlstm_fwd_multi_bf16": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_einit_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_tile_rows_f32": [c_void_p, c_float, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_rowdot_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
@@ -91,6 +95,18 @@ class CellMlpTask(ctypes.Structure):
     """tspgnn_cell_mlp_task (include/tspgnn.h): a cell update followed by the MLP that consumes the new h."""
     _fields_ = [("cell", LstmTask), ("mlp_wb", c_void_p), ("mlp_layers", c_int), ("relu_mask", c_uint),
                 ("mlp_out", c_void_p), ("proj_w", c_void_p), ("proj_out", c_void_p)]
+
+
+class MlpTaskB(ctypes.Structure):
+    """tspgnn_mlp_task_bf16 (include/tspgnn.h)."""
+    _fields_ = [("X", c_void_p), ("wb", c_void_p), ("Y", c_void_p), ("rows", c_int), ("n_layers", c_int),
+                ("relu_mask", c_uint), ("proj_w", c_void_p), ("proj_out", c_void_p)]
+
+
+class LstmTaskB(ctypes.Structure):
+    """tspgnn_lstm_task_bf16 (include/tspgnn.h)."""
+    _fields_ = [("x", c_void_p), ("dx", c_int), ("h", c_void_p), ("c", c_void_p), ("K", c_void_p), ("ln", c_void_p),
+                ("h_out", c_void_p), ("c_out", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p)]
 
 
 class LstmBwdTask(ctypes.Structure):
