@@ -458,3 +458,35 @@ def test_vertex_without_edges_and_training_on_tiny_batch(cuda_device):
                                          {k: np.zeros_like(v) for k, v in params.items()}, 1)
     assert abs(float(out[0]) - ref_out["loss"].item()) < REL_TOL
     assert abs(float(sess._adam["gnorm"].item()) - gn) < 2e-5 * gn
+
+
+@pytest.mark.parametrize("name,d,T", [("n5_B2", 32, 3), ("ragged_B6", 64, 4), ("n20_B32", 64, 8), ("n20_B32", 128, 4)])
+def test_bf16_storage_mode(cuda_device, name, d, T):
+    """build_network(d, float_dtype=torch.bfloat16): BASELINE config 5's "bf16 embeddings with fp32 accumulate".
+    Against the oracle restating the same rounding points (a handful of bf16 ulps: the two sides can land on
+    different sides of a rounding boundary), and against the fp32 path (bf16 storage is an approximation of it)."""
+    t = pack_tuple(name)
+    params = P.init_params(d, seed=11, perturb=True)
+    model = tspgnn.build_network(d, float_dtype=torch.bfloat16)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    EV, W, C, route_exists, n_vertices, n_edges = t
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    pred, last, loss = sess.run([model["predictions"], model["last_states"], model["loss"]], feed_dict=feed)
+    batch = {"ev_uv": t[0].uv, "W": t[1], "C": t[2], "route_exists": t[3], "n_vertices": t[4], "n_edges": t[5]}
+    ref = TO.forward(TO.to_torch(params, torch.float64), batch, T, bf16=True)
+    full = TO.forward(TO.to_torch(params, torch.float64), batch, T)
+    e_h = rel_err(last["E"].h, ref["last_states"]["E"][0].numpy())
+    e_c = rel_err(last["V"].c, ref["last_states"]["V"][1].numpy())
+    e_p = rel_err(pred, ref["predictions"].numpy())
+    a_h = rel_err(last["E"].h, full["last_states"]["E"][0].numpy())
+    a_p = rel_err(pred, full["predictions"].numpy())
+    print("\n[%s d=%d T=%d bf16] vs bf16 oracle: E.h %.2e V.c %.2e pred %.2e | vs fp32 semantics: E.h %.2e pred %.2e"
+          % (name, d, T, e_h, e_c, e_p, a_h, a_p))
+    assert e_h < 3e-2 and e_c < 3e-2 and e_p < 1e-2
+    assert a_h < 1e-1 and a_p < 3e-2
+    assert abs(float(loss) - ref["loss"].item()) < 1e-2
+    with pytest.raises(NotImplementedError):
+        sess.run([model["train_step"]], feed_dict=feed)

@@ -89,11 +89,23 @@ class DeviceAdjacency(object):
         if y.shape[0] != rows_in:
             raise ValueError("matrix/embedding size mismatch: %d vs %d" % (rows_in, y.shape[0]))
         d = y.shape[1]
+        st = _lib.current_stream()
+        if y.dtype == torch.bfloat16:   # bf16 rows, fp32 sums, one rounding at the store (pattern matrices only)
+            if out is None:
+                out = torch.empty((rows_out, d), dtype=torch.bfloat16, device=y.device)
+            if not transpose and self.uv is not None:
+                _lib.call("tspgnn_gather2_sum_bf16", _lib.ptr(self.uv), _lib.ptr(y), _lib.ptr(out), R, C, d, st)
+                return out
+            rowptr, col, val = self.csr_t if transpose else self.csr
+            if val is not None:
+                raise NotImplementedError("bf16 aggregation of a valued matrix")
+            _lib.call("tspgnn_csr_rowsum_bf16", _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(y), _lib.ptr(out),
+                      rows_out, rows_in, d, st)
+            return out
         if d % 4 != 0:
             raise NotImplementedError("aggregation kernels need d %% 4 == 0 (got %d)" % d)
         if out is None:
             out = torch.empty((rows_out, d), dtype=torch.float32, device=y.device)
-        st = _lib.current_stream()
         if not transpose and self.uv is not None:
             _lib.call("tspgnn_gather2_sum_f32", _lib.ptr(self.uv), _lib.ptr(y), _lib.ptr(out), R, C, d, st)
             return out
@@ -204,6 +216,22 @@ class LayerNormBasicLSTMCell(object):
                       _lib.current_stream())
             return out
         return self.store.packed((key, self.base), build)
+
+    def _packed_bf16(self, key, rows_lo, rows_hi):
+        """Kernel rows [rows_lo, rows_hi) rounded to bf16 in MFMA fragment order: piece 0 of the bf16x3 packing."""
+        n = (rows_hi - rows_lo) * 4 * self.d
+        return self._packed_x3(key, rows_lo, rows_hi)[:2 * n]
+
+    def task_bf16(self, x, state, out):
+        """tspgnn_lstm_task_bf16: x, h, h_out bf16; c, c_out fp32."""
+        return _lib.LstmTaskB(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c),
+                              _lib.ptr(self._packed_bf16("lstm.x3", 0, self.dx + self.d)), _lib.ptr(self.ln()),
+                              _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None)
+
+    def gather_task_bf16(self, adj, zx, state, out):
+        return _lib.LstmTaskB(None, 0, _lib.ptr(state.h), _lib.ptr(state.c),
+                              _lib.ptr(self._packed_bf16("lstm.kh.x3", self.dx, self.dx + self.d)), _lib.ptr(self.ln()),
+                              _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], _lib.ptr(adj.uv), _lib.ptr(zx))
 
     def x3_ok(self):
         """The bf16x3 cell kernel covers this shape (tspgnn_lnlstm_fwd_multi_x3)."""
@@ -373,8 +401,9 @@ class GraphNN(object):
         self.Cell_activation = Cell_activation
         self.Msg_activation = Msg_activation
         self.Msg_last_activation = Msg_last_activation
-        if float_dtype != torch.float32:
-            raise NotImplementedError("GraphNN: the HIP path computes in fp32")
+        if float_dtype not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError("GraphNN: float_dtype must be torch.float32 or torch.bfloat16 (bf16 storage of the "
+                                      "embeddings with fp32 accumulation, inference only)")
         self.float_dtype = float_dtype
         self.store = store if store is not None else V.get_default_store()
         self.fold_adjacency = True   # (EV y) Kx = EV (y Kx) fast path; False = op-for-op reference order
@@ -524,10 +553,12 @@ class GraphNN(object):
                     dense_mats[m] = torch.as_tensor(a, dtype=torch.float32).to(device).contiguous()
         states = {}
         for v, init in initial_embeddings.items():
-            h0 = init.to(torch.float32).contiguous()
-            c0 = torch.zeros_like(h0) if v not in LSTM_initial_states \
+            h0 = init.to(self.float_dtype).contiguous()      # embeddings in the storage type; the cell state stays fp32
+            c0 = torch.zeros(h0.shape, dtype=torch.float32, device=h0.device) if v not in LSTM_initial_states \
                 else LSTM_initial_states[v].to(torch.float32).contiguous()
             states[v] = LSTMStateTuple(c=c0, h=h0)
+        if self.float_dtype == torch.bfloat16:
+            return self._run_bf16(states, mats, dense_mats, int(time_steps))
         folded = {v: self._folded(v, mats) for v in self.var}
         T = int(time_steps)
         if T > 0:
@@ -542,6 +573,98 @@ class GraphNN(object):
         for _ in range(T):
             states = self._step(states, mats, dense_mats, folded)
         return states
+
+    def _run_bf16(self, states, mats, dense_mats, T):
+        """bf16-storage forward (float_dtype=torch.bfloat16; BASELINE config 5): h, messages, aggregates and the
+        projected messages Zx are bf16 in HBM, GEMMs are bf16 MFMA with fp32 accumulation, the cell state, LayerNorm
+        and gate arithmetic fp32.  Three launches per step over ping-pong state buffers: message MLPs (vertex task
+        with its Kx projection), adjacency products, cells (edge cell in gather-init mode)."""
+        if dense_mats:
+            raise NotImplementedError("bf16 storage: dense matrices appended as cell inputs")
+        bf = dict(dtype=torch.bfloat16, device=self.store.theta.device)
+        for v in self.var:
+            if self.var[v] not in (32, 64, 128) or self._RNN_cells[v].dx % 32 != 0:
+                raise NotImplementedError("bf16 storage needs widths 32/64/128 and cell inputs in multiples of 32")
+            for u in self.loop[v]:
+                if "var" not in u or "fun" in u:
+                    raise NotImplementedError("bf16 storage supports loop entries made of var / msg / mat only")
+                if "msg" in u:
+                    m = self._msg_MLPs[u["msg"]]
+                    if m._plan[0] != "square" or m._plan[3] or not (1 <= m.n_square <= 4) or m.input_size != m.sizes[-1]:
+                        raise NotImplementedError("bf16 storage needs square message MLPs of at most 4 layers")
+        if T == 0:
+            return states
+        buf = [{v: LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) for v, st in states.items()},
+               {v: LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h)) for v, st in states.items()}]
+
+        def folds(v):   # single gather over a two-ones-per-row matrix behind a message MLP: Zx = msg(y) Kx on source rows
+            if not self.fold_adjacency or len(self.loop[v]) != 1:
+                return None
+            u = self.loop[v][0]
+            if "mat" not in u or "msg" not in u or u.get("transpose?", False) or mats[u["mat"]].uv is None:
+                return None
+            return u if self._RNN_cells[v].dx == self._msg_MLPs[u["msg"]].sizes[-1] == self.var[v] else None
+        folded = {v: folds(v) for v in self.var}
+        runs, keep = [], [buf]
+        for p in (0, 1):
+            src, dst = buf[p], buf[1 - p]
+            mlp_tasks, lstm_tasks, mid, msg_out, zxs = {}, {}, [], {}, {}
+            for v in self.var:
+                for i, u in enumerate(self.loop[v]):
+                    y = src[u["var"]].h
+                    if "msg" in u:
+                        mlp = self._msg_MLPs[u["msg"]]
+                        d = mlp.sizes[-1]
+                        out = torch.empty((y.shape[0], d), **bf)
+                        pw = po = None
+                        if folded[v] is not None:
+                            cv = self._RNN_cells[v]
+                            zxs[v] = torch.empty((y.shape[0], 4 * self.var[v]), **bf)
+                            pw, po = cv._packed_bf16("lstm.kx.x3", 0, cv.dx), zxs[v]
+                        n = mlp.n_square
+                        mlp_tasks.setdefault(d, []).append(_lib.MlpTaskB(
+                            _lib.ptr(y), _lib.ptr(mlp.wb_packed_bf16(0, n - 1, d)), _lib.ptr(out), y.shape[0], n,
+                            mlp.relu_mask(0, n), _lib.ptr(pw), _lib.ptr(po)))
+                        y = out
+                    msg_out[(v, i)] = y
+            for v, d in self.var.items():
+                cell, st = self._RNN_cells[v], src[v]
+                out = (dst[v].h, dst[v].c)
+                if folded[v] is not None:
+                    lstm_tasks.setdefault(d, []).append(cell.gather_task_bf16(mats[folded[v]["mat"]], zxs[v], st, out))
+                    continue
+                inputs = []
+                for i, u in enumerate(self.loop[v]):
+                    y = msg_out[(v, i)]
+                    if "mat" in u:
+                        adj, tr = mats[u["mat"]], u.get("transpose?", False)
+                        o = torch.empty((adj.shape[1] if tr else adj.shape[0], y.shape[1]), **bf)
+                        mid.append((adj.matmul, (y, tr, o)))
+                        y = o
+                    inputs.append(y)
+                if len(inputs) == 1:
+                    x = inputs[0]
+                else:
+                    x = torch.empty((st.h.shape[0], cell.dx), **bf)
+                    mid.append((lambda ins, o: torch.cat(ins, dim=1, out=o), (inputs, x)))
+                if x.shape[0] != st.h.shape[0] or x.shape[1] != cell.dx:
+                    raise ValueError("cell input must be [%d,%d], got %s" % (st.h.shape[0], cell.dx, tuple(x.shape)))
+                lstm_tasks.setdefault(d, []).append(cell.task_bf16(x, st, out))
+                keep.append(x)
+            keep += [msg_out, zxs]
+            mlp_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in mlp_tasks.items() for k in range(0, len(ts), 4)]
+            lstm_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in lstm_tasks.items() for k in range(0, len(ts), 4)]
+            runs.append((mlp_calls, mid, lstm_calls))
+        self._plan_keep = keep
+        for t in range(T):
+            mlp_calls, mid, lstm_calls = runs[t & 1]
+            for arr, d in mlp_calls:
+                _lib.call_multi("tspgnn_mlp_fwd_multi_bf16", arr, d)
+            for fn, args in mid:
+                fn(*args)
+            for arr, d in lstm_calls:
+                _lib.call_multi("tspgnn_lnlstm_fwd_multi_bf16", arr, d)
+        return buf[T & 1]
 
     def _x3_ok(self, n_rows=None):
         """The bf16x3 kernels cover this network (widths 32/64, cell inputs in multiples of 32) and, when the row
@@ -845,6 +968,8 @@ class GraphNN(object):
         variable's weight gradient is ONE reduction over all time steps (sized for 288 GB of HBM:
         ~10 GB at n=40, batch 128, T=32).  Returns (states, tape)."""
         T = int(time_steps)
+        if self.float_dtype != torch.float32:
+            raise NotImplementedError("training runs with float_dtype=torch.float32 (bf16 storage is inference only)")
         self.check_run(adjacency_matrices, initial_embeddings, T, {})
         device = next(iter(initial_embeddings.values())).device
         f32 = dict(dtype=torch.float32, device=device)

@@ -120,6 +120,20 @@ class Mlp(object):
             return out
         return self.store.packed(("mlp.x3", self.name, first, last), build)
 
+    def wb_packed_bf16(self, first, last, d):
+        """Byte tensor of {bf16 pack(W) [d*d*2 B] (weights rounded to bf16, fragment order), b [d*4 B]} per square
+        layer first..last for the bf16-storage kernels, cached until the variables change."""
+        def build(out):
+            src = self.wb_packed_x3(first, last, d)
+            per3, per = 6 * d * d + 4 * d, 2 * d * d + 4 * d
+            if out is None:
+                out = torch.empty((last - first + 1) * per, dtype=torch.uint8, device=src.device)
+            for j in range(last - first + 1):
+                out[j * per:j * per + 2 * d * d].copy_(src[j * per3:j * per3 + 2 * d * d])            # piece 0
+                out[j * per + 2 * d * d:(j + 1) * per].copy_(src[j * per3 + 6 * d * d:(j + 1) * per3])  # bias
+            return out
+        return self.store.packed(("mlp.bf16", self.name, first, last), build)
+
     def wt_packed(self, first, last, d):
         """pack(W_l^T) for square layers first..last back to back (data-gradient kernels)."""
         def build(out):

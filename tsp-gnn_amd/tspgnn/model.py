@@ -65,11 +65,14 @@ class Network(dict):
     """The dict build_network returns, plus the objects Session needs."""
 
 
-def build_network(d, store=None):
+def build_network(d, store=None, float_dtype=torch.float32):
+    """model.py:9-170.  ``float_dtype=torch.bfloat16`` (the reference GraphNN's own float_dtype argument,
+    graphnn.py:18) stores the embeddings as bf16 with fp32 accumulation (BASELINE config 5, inference only)."""
     d = int(d)
     store = store if store is not None else V.reset_default_store()
     GNN = Network()
     GNN.d = d
+    GNN.float_dtype = float_dtype
     GNN.store = store
     # placeholders (model.py:18-29)
     GNN["route_exists"] = Placeholder("route_exists", np.float32, 1)
@@ -103,6 +106,7 @@ def build_network(d, store=None):
             "E": [{"mat": "EV", "msg": "V_msg_E", "var": "V"}],
         },
         name="TSP",
+        float_dtype=float_dtype,
         store=store,
     )
     # model.py:107-115
@@ -224,7 +228,7 @@ class Session(object):
         _lib.call("tspgnn_tile_rows_f32", _lib.ptr(self.store.view("V_init")), 1.0 / math.sqrt(float(d)),
                   _lib.ptr(V0), b.N, d, st)
         last = m["gnn"]({"EV": b.adj}, {"V": V0, "E": E0}, b.T)               # model.py:118-122
-        vote = m.E_vote_MLP(last["E"].h).view(-1)                             # model.py:128
+        vote = m.E_vote_MLP(last["E"].h.to(torch.float32)).view(-1)           # model.py:128 (bf16 storage: widened once)
         logits = torch.empty(b.B, dtype=torch.float32, device=self.device)
         _lib.call("tspgnn_segment_mean_f32", _lib.ptr(vote), _lib.ptr(b.seg), _lib.ptr(logits), b.B, st)
         pred = torch.empty(b.B, dtype=torch.float32, device=self.device)
@@ -291,7 +295,7 @@ class Session(object):
             if f.name == "predictions":
                 results.append(out["predictions"].cpu().numpy())
             elif f.name == "last_states":
-                results.append({v: LSTMStateTuple(c=s.c.cpu().numpy(), h=s.h.cpu().numpy())
+                results.append({v: LSTMStateTuple(c=s.c.cpu().numpy(), h=s.h.to(torch.float32).cpu().numpy())
                                 for v, s in out["last_states"].items()})
             else:
                 idx = {"loss": 0, "acc": 1, "TP": 2, "FP": 3, "TN": 4, "FN": 5}[f.name]
