@@ -38,6 +38,15 @@ for tag, dtype in (("bf16", torch.bfloat16), ("f32", torch.float32)):
     out[tag] = {"ms_per_forward": round(ms, 3), "mp_steps_per_s": round(T / (ms * 1e-3), 1),
                 "us_per_mp_step": round(1e3 * ms / T, 1), "loss": float(o["stats"][0].item()),
                 "predictions_head": [round(float(x), 5) for x in o["predictions"][:4]]}
+    from tspgnn import _lib
+    _lib.TIMELINE = []
+    sess.forward_device(b)
+    torch.cuda.synchronize()
+    per = {}
+    for name, e0, e1 in _lib.TIMELINE:
+        per.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)
+    _lib.TIMELINE = None
+    out[tag]["kernels_us"] = {k: round(sum(v) / len(v), 1) for k, v in per.items() if len(v) >= T}
     del replay, sess, model
     torch.cuda.empty_cache()
 print(json.dumps(out))

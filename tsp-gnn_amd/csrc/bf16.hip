@@ -83,7 +83,11 @@ template <int LPR>
 __global__ __launch_bounds__(256) void csr_rowsum_bf16_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
                                                               const uint4* __restrict__ X, uint4* __restrict__ Y, int N) {
     constexpr int RPW = kWave / LPR;
-    const int v = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    // XCD-aware vertex order (workgroup b runs on XCD b % 8): each XCD owns a contiguous eighth of the vertices, so
+    // the two reads of every edge row (one per endpoint) meet in one L2 -- see csr_rowsum_body in aggregate.hip
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const unsigned vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;  // bijective for any nb
+    const int v = (int)(((long long)vb * blockDim.x + threadIdx.x) >> 6);
     if (v >= N) return;  // wave-uniform
     const int lane = threadIdx.x & 63, sub = lane / LPR, c = lane % LPR;
     const int beg = rowptr[v], end = rowptr[v + 1];
