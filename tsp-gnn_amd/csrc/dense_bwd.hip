@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X,
     float cs[BV];
 #pragma unroll
     for (int n = 0; n < BV; ++n) cs[n] = 0.f;
-    constexpr int UN = 4;  // k-steps (of 4 rows) in flight
+    constexpr int UN = 8;  // k-steps (of 4 rows) in flight
     for (long long r0 = r_beg; r0 < r_end; r0 += 4 * UN) {
         float a[UN][AV], b[UN][BV];
 #pragma unroll
@@ -581,7 +581,7 @@ static int pick_vec(int width) { return width % 64 == 0 ? 4 : (width % 32 == 0 ?
 static void wgrad_plan(long long rows, int kin, int nout, int* n_chunks, long long* chunk_rows) {
     const int av = pick_vec(kin), bv = pick_vec(nout);
     const int nob = (kin / (16 * av)) * (nout / (16 * bv));
-    long long target = (long long)n_cus() * 4 / nob;  // ~4 wavefronts per CU in total
+    long long target = (long long)n_cus() * 8 / nob;  // ~8 wavefronts per CU in total (HBM-bound: loads in flight)
     if (target < 1) target = 1;
     long long by_rows = (rows + 255) / 256;             // at least 256 rows per chunk
     long long nc = target < by_rows ? target : by_rows;
