@@ -287,6 +287,8 @@ typedef struct tspgnn_lstm_bwd_task {
     const float* dh_out; const float* dc_out; float* dz; float* dc_in; float* ln_grad; float* workspace;
     int rows;
     const int32_t* uv; const float* Zx;   /* gather-init mode when uv != NULL: dx == 0, K = Kh */
+    const float* KT; float* dxh;          /* optional (d == 64, gather-init mode): dxh[rows,d] = dz Kh^T in the same launch,
+                                             KT = tspgnn_pack_weights_f32(Kh, 4d, d, transposed=1); dz is not re-read */
 } tspgnn_lstm_bwd_task;   /* fields as the arguments of tspgnn_lnlstm_bwd_f32 / tspgnn_lnlstm_gather_bwd_f32 */
 
 typedef struct tspgnn_mlp_bwd_task {

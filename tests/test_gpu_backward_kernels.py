@@ -121,6 +121,39 @@ def test_lnlstm_backward_chain(cuda_device, d, dx, rows, null_grads):
     assert rel_err(ln_grad.cpu().numpy().reshape(5, 2, d), gln.numpy()) < TOL
 
 
+@pytest.mark.parametrize("rows", [1, 333, 9000])
+def test_lnlstm_gather_backward_fused_dh(cuda_device, rows):
+    """tspgnn_lstm_bwd_task.KT / .dxh (d = 64, gather-init mode): dh = dz Kh^T formed in the cell launch equals the
+    separate tspgnn_linear_f32 on the stored dz, and the other outputs do not change."""
+    d, N = 64, 257
+    rng = np.random.RandomState(rows)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    uv = np.stack([rng.randint(0, N, rows), rng.randint(0, N, rows)], 1).astype(np.int32)
+    Zx, h, c = f32(rng.randn(N, 4 * d)), f32(rng.randn(rows, d)), f32(rng.randn(rows, d))
+    Kh = f32(rng.randn(d, 4 * d) / np.sqrt(d))
+    ln = f32(np.stack([np.stack([1 + 0.2 * rng.randn(d), 0.2 * rng.randn(d)]) for _ in range(5)]))
+    dh_o, dc_o = f32(rng.randn(rows, d)), f32(rng.randn(rows, d))
+    args = dict(uv=dev(uv, cuda_device, np.int32), Zx=dev(Zx, cuda_device), h=dev(h, cuda_device), c=dev(c, cuda_device),
+                K=packed(Kh, cuda_device), KT=packed(Kh, cuda_device, transposed=1), ln=dev(ln, cuda_device),
+                dh=dev(dh_o, cuda_device), dc=dev(dc_o, cuda_device))
+    outs = []
+    for fused in (False, True):
+        dz, dc_in, dh_in = empty((rows, 4 * d), cuda_device), empty((rows, d), cuda_device), empty((rows, d), cuda_device)
+        ln_grad = empty((10 * d,), cuda_device, 0.0)
+        wsl = ws("tspgnn_lnlstm_bwd_workspace_floats", d, device=cuda_device)
+        task = _lib.LstmBwdTask(None, 0, _lib.ptr(args["h"]), _lib.ptr(args["c"]), _lib.ptr(args["K"]), _lib.ptr(args["ln"]),
+                                _lib.ptr(args["dh"]), _lib.ptr(args["dc"]), _lib.ptr(dz), _lib.ptr(dc_in), _lib.ptr(ln_grad),
+                                _lib.ptr(wsl), rows, _lib.ptr(args["uv"]), _lib.ptr(args["Zx"]),
+                                _lib.ptr(args["KT"]) if fused else None, _lib.ptr(dh_in) if fused else None)
+        _lib.call_multi("tspgnn_lnlstm_bwd_multi_f32", [task], d)
+        if not fused:
+            _lib.call("tspgnn_linear_f32", _lib.ptr(dz), 4 * d, _lib.ptr(args["KT"]), None, 0, _lib.ptr(dh_in), d, 0, rows, None)
+        torch.cuda.synchronize()
+        outs.append([t.cpu().numpy() for t in (dz, dc_in, dh_in, ln_grad)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)      # same arithmetic in the same order, from registers instead of from HBM
+
+
 @pytest.mark.parametrize("d,L,mask,rows", [(64, 4, 0b0111, 500), (64, 3, 0b111, 333), (32, 4, 0b0111, 40), (32, 2, 0b01, 17),
                                            (128, 2, 0b11, 100), (64, 1, 0, 64)])
 def test_mlp_backward_and_wgrad(cuda_device, d, L, mask, rows):

@@ -239,7 +239,7 @@ __device__ __forceinline__ void lstm_tile_backward(f32x4 (&acc)[D / 4], const fl
     }
 }
 
-// LDS: [K chunk or all of K] [ln 10*D] [NW slabs of 10*D].
+// LDS: [K chunk or all of K] [K^T (optional)] [ln 10*D] [NW slabs of 10*D].
 constexpr int kMaxTasks = 4;
 
 struct LstmBwdTaskTable {
@@ -271,6 +271,8 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const LstmBwdTaskTa
     const int qc = tt.qc[k];
     const int2* __restrict__ uv = reinterpret_cast<const int2*>(tt.task[k].uv);
     const float* __restrict__ Zx = tt.task[k].Zx;
+    const float* __restrict__ KT = tt.task[k].KT;
+    float* __restrict__ dxh = tt.task[k].dxh;
     constexpr int NT4 = D / 4, TPG = D / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int QX = dx >> 4, QT = QX + TPG;
@@ -278,7 +280,8 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const LstmBwdTaskTa
     const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4, wave = tid >> 6;
     const int nw = blockDim.x >> 6;
     float* lds_k = lds;
-    float* lds_ln = lds + (size_t)(resident ? QT : qc) * 16 * 4 * D;
+    float* lds_kt = lds + (size_t)(resident ? QT : qc) * 16 * 4 * D;   // K^T for the fused data gradient (optional)
+    float* lds_ln = lds_kt + (KT != nullptr ? (size_t)4 * D * (dx + D) : 0);
     float* slabs = lds_ln + 10 * D;
     float* slab = slabs + wave * 10 * D;
     for (int i = tid; i < 10 * D; i += blockDim.x) lds_ln[i] = ln[i];
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const LstmBwdTaskTa
 
     if (resident) {
         copy_to_lds(lds_k, K, (dx + D) * 4 * D, tid, blockDim.x);
+        if (KT != nullptr) copy_to_lds(lds_kt, KT, 4 * D * (dx + D), tid, blockDim.x);
         const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
         const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
         __syncthreads();
@@ -323,6 +327,27 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const LstmBwdTaskTa
             }
             gemm_kloop<NT4>(acc, lds_k, 0, 0, QT, x + rc * dx + g * 4, h + rc * D + g * 4, QX, g, rl);
             finish(acc, rc, valid);
+            if constexpr (D == 64) {
+                if (KT != nullptr) {
+                    // dh = dz Kh^T while dz is still in registers (gather-init mode, dx == 0): the D layout of dz is
+                    // the B operand of the transposed-chaining GEMM, as between two MLP layers; saves a launch and a
+                    // [rows,4D] read.  sched_barrier: dz (acc) is dead after the last k-step, keep it that way.
+                    f32x4 out[TPG];
+#pragma unroll
+                    for (int t = 0; t < TPG; ++t) out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < NT4; q += 4) {
+                        float b[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) b[i] = acc[q + (i >> 2)][i & 3];
+                        ksteps<TPG, 16>(out, lds_kt + frag_off<TPG>(q * 4, g, rl), b);
+                    }
+                    if (valid) {
+#pragma unroll
+                        for (int t = 0; t < TPG; ++t) st4(dxh + rc * D + t * 16 + g * 4, out[t]);
+                    }
+                }
+            }
         }
     } else {
         __syncthreads();
@@ -653,7 +678,13 @@ static int launch_lnlstm_bwd(const tspgnn_lstm_bwd_task* tasks, int n, hipStream
             any_chunked = true;
         }
         tt.qc[k] = qc;
-        if ((size_t)qc * per_q > lds_k) lds_k = (size_t)qc * per_q;
+        size_t need = (size_t)qc * per_q;
+        if (tasks[k].KT != nullptr) {
+            need += (size_t)4 * D * (tasks[k].dx + D) * sizeof(float);
+            if (D != 64 || tasks[k].dx != 0 || qc < QT || need + extra(NWMAX) > 160 * 1024)
+                return fail(TSPGNN_EUNSUPPORTED, "lnlstm_bwd: the fused data gradient needs d=64, dx=0 and K, K^T resident in LDS");
+        }
+        if (need > lds_k) lds_k = need;
         const long long tiles = ((long long)tasks[k].rows + 15) / 16;
         cost[k] = tiles * (QT + 8);  // k-blocks + ~8 blocks' worth of elementwise backward
         tiles_all += tiles;

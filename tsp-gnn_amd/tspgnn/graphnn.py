@@ -318,10 +318,13 @@ class LayerNormBasicLSTMCell(object):
                                 _lib.ptr(self.ln()), _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in),
                                 _lib.ptr(self.ln_grad()), _lib.ptr(ws), h.shape[0], None, None)
 
-    def gather_backward_task(self, adj, zx, h, c, dh_out, dc_out, dz, dc_in, ws):
+    def gather_backward_task(self, adj, zx, h, c, dh_out, dc_out, dz, dc_in, ws, dh_in=None):
+        """``dh_in`` given (d == 64): dh_in = dz Kh^T is formed in the same launch, from dz in registers."""
+        fuse = dh_in is not None and self.d == 64
         return _lib.LstmBwdTask(None, 0, _lib.ptr(h), _lib.ptr(c), _lib.ptr(self.kh_packed()), _lib.ptr(self.ln()),
                                 _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in),
-                                _lib.ptr(self.ln_grad()), _lib.ptr(ws), h.shape[0], _lib.ptr(adj.uv), _lib.ptr(zx))
+                                _lib.ptr(self.ln_grad()), _lib.ptr(ws), h.shape[0], _lib.ptr(adj.uv), _lib.ptr(zx),
+                                _lib.ptr(self.kh_t_packed()) if fuse else None, _lib.ptr(dh_in) if fuse else None)
 
     def backward_data(self, dz, dx_out, dh_in):
         """[dx | dh] = dz K^T."""
@@ -329,10 +332,11 @@ class LayerNormBasicLSTMCell(object):
                   self.dx, _lib.ptr(dh_in), self.d, 0, dz.shape[0], _lib.current_stream())
 
     def gather_backward_data(self, adj, dz, dh_in, dzx, dy):
-        """dh = dz Kh^T, dZx = EV^T dz, dy = dZx Kx^T (folded cell)."""
+        """dh = dz Kh^T (unless the cell launch already formed it: dh_in None), dZx = EV^T dz, dy = dZx Kx^T."""
         st = _lib.current_stream()
-        _lib.call("tspgnn_linear_f32", _lib.ptr(dz), 4 * self.d, _lib.ptr(self.kh_t_packed()), None, 0, _lib.ptr(dh_in),
-                  self.d, 0, dz.shape[0], st)
+        if dh_in is not None:
+            _lib.call("tspgnn_linear_f32", _lib.ptr(dz), 4 * self.d, _lib.ptr(self.kh_t_packed()), None, 0, _lib.ptr(dh_in),
+                      self.d, 0, dz.shape[0], st)
         adj.matmul(dz, transpose=True, out=dzx)
         _lib.call("tspgnn_linear_f32", _lib.ptr(dzx), 4 * self.d, _lib.ptr(self.kx_t_packed()), None, 0, _lib.ptr(dy),
                   self.dx, 0, dzx.shape[0], st)
@@ -1104,7 +1108,7 @@ class GraphNN(object):
                 cell = self._RNN_cells[v]
                 if folded[v] is not None:
                     task = cell.gather_backward_task(mats[folded[v]["mat"]], tape.ZX[v][t], tape.H[v][t], tape.C[v][t],
-                                                     dH[v], dC[v], DZ[v][t], ndC[v], ws[v])
+                                                     dH[v], dC[v], DZ[v][t], ndC[v], ws[v], dh_in=ndH[v])
                 else:
                     task = cell.backward_task(tape.X[v][t], tape.H[v][t], tape.C[v][t], dH[v], dC[v], DZ[v][t], ndC[v],
                                               ws[v])
@@ -1116,7 +1120,8 @@ class GraphNN(object):
             for v in self.var:
                 cell = self._RNN_cells[v]
                 if folded[v] is not None:   # dX[v] becomes the gradient w.r.t. the message y (source rows)
-                    cell.gather_backward_data(mats[folded[v]["mat"]], DZ[v][t], ndH[v], DZX[v][t], dX[v])
+                    cell.gather_backward_data(mats[folded[v]["mat"]], DZ[v][t], None if cell.d == 64 else ndH[v],
+                                              DZX[v][t], dX[v])   # (d == 64: dh was formed by the cell launch)
                 else:
                     cell.backward_data(DZ[v][t], dX[v], ndH[v])
             # ---- 3: adjoint adjacency products, then every message MLP's data gradient in one launch
