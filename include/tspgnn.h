@@ -289,6 +289,10 @@ typedef struct tspgnn_lstm_bwd_task {
     const int32_t* uv; const float* Zx;   /* gather-init mode when uv != NULL: dx == 0, K = Kh */
     const float* KT; float* dxh;          /* optional (d == 64, gather-init mode): dxh[rows,d] = dz Kh^T in the same launch,
                                              KT = tspgnn_pack_weights_f32(Kh, 4d, d, transposed=1); dz is not re-read */
+    int defer_reduce;                     /* != 0: ADD the workgroups' LayerNorm-gradient partials to `workspace` (zeroed by
+                                             the caller before the first launch) and leave ln_grad alone; one
+                                             tspgnn_lnlstm_bwd_finish_f32 after the last time step folds them -- one
+                                             reduction per cell instead of one per time step */
 } tspgnn_lstm_bwd_task;   /* fields as the arguments of tspgnn_lnlstm_bwd_f32 / tspgnn_lnlstm_gather_bwd_f32 */
 
 typedef struct tspgnn_mlp_bwd_task {
@@ -297,6 +301,8 @@ typedef struct tspgnn_mlp_bwd_task {
 } tspgnn_mlp_bwd_task;    /* fields as the arguments of tspgnn_mlp_bwd_f32 */
 
 int tspgnn_lnlstm_bwd_multi_f32(const tspgnn_lstm_bwd_task* tasks, int n_tasks, int d, void* stream);
+/* ln_grad[10d] += fixed-order sum of the deferred partials in `workspace` (tspgnn_lnlstm_bwd_workspace_floats(d)). */
+int tspgnn_lnlstm_bwd_finish_f32(const float* workspace, float* ln_grad, int d, void* stream);
 int tspgnn_mlp_bwd_multi_f32(const tspgnn_mlp_bwd_task* tasks, int n_tasks, int d, void* stream);
 
 /* Workspace (floats) tspgnn_wgrad_f32 needs. */

@@ -376,7 +376,8 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const LstmBwdTaskTa
     for (int i = tid; i < 10 * D; i += blockDim.x) {
         float s = 0.f;
         for (int w = 0; w < nw; ++w) s += slabs[w * 10 * D + i];
-        ln_partial[(size_t)my_blk * 10 * D + i] = s;
+        float* dst = ln_partial + (size_t)my_blk * 10 * D + i;
+        *dst = tt.task[k].defer_reduce ? *dst + s : s;   // (this workgroup owns the row; launches are stream-ordered)
     }
 }
 
@@ -704,6 +705,7 @@ static int launch_lnlstm_bwd(const tspgnn_lstm_bwd_task* tasks, int n, hipStream
     int rc = launched("tspgnn_lnlstm_bwd_f32");
     if (rc) return rc;
     for (int k = 0; k < n; ++k) {
+        if (tasks[k].defer_reduce) continue;
         const int nblk = tt.blk_end[k] - (k ? tt.blk_end[k - 1] : 0);
         reduce_partials(tasks[k].workspace, nblk, 10 * D, tasks[k].ln_grad, 10 * D, 1.0f, 1, st);
         if ((rc = launched("tspgnn_lnlstm_bwd_f32(reduce)"))) return rc;
@@ -793,6 +795,13 @@ extern "C" int tspgnn_lnlstm_bwd_multi_f32(const tspgnn_lstm_bwd_task* tasks, in
         case 64: return launch_lnlstm_bwd<64>(live, n, st);
         default: return launch_lnlstm_bwd<128>(live, n, st);
     }
+}
+
+extern "C" int tspgnn_lnlstm_bwd_finish_f32(const float* workspace, float* ln_grad, int d, void* stream) {
+    TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "lnlstm_bwd_finish: d=%d must be 32, 64 or 128", d);
+    TSPGNN_REQUIRE(workspace && ln_grad, "lnlstm_bwd_finish: null pointer");
+    reduce_partials(workspace, n_cus() + 8, 10 * d, ln_grad, 10 * d, 1.0f, 1, as_stream(stream));
+    return launched("tspgnn_lnlstm_bwd_finish_f32");
 }
 
 extern "C" int tspgnn_lnlstm_bwd_f32(const float* x, int dx, const float* h, const float* c, const float* K,

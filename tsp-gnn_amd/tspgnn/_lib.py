@@ -38,6 +38,7 @@ SIGNATURES = {
     "tspgnn_lnlstm_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_mlp_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_lnlstm_bwd_finish_f32": [c_void_p, c_void_p, c_int, c_void_p],
     "tspgnn_mlp_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_gather_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_void_p],
@@ -114,7 +115,7 @@ class LstmBwdTask(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("dx", c_int), ("h", c_void_p), ("c", c_void_p), ("K", c_void_p), ("ln", c_void_p),
                 ("dh_out", c_void_p), ("dc_out", c_void_p), ("dz", c_void_p), ("dc_in", c_void_p), ("ln_grad", c_void_p),
                 ("workspace", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p),
-                ("KT", c_void_p), ("dxh", c_void_p)]
+                ("KT", c_void_p), ("dxh", c_void_p), ("defer_reduce", c_int)]
 
 
 class MlpBwdTask(ctypes.Structure):

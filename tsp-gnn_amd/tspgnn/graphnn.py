@@ -313,18 +313,25 @@ class LayerNormBasicLSTMCell(object):
                   self.d, _lib.current_stream())
         return h_out, LSTMStateTuple(c=c_out, h=h_out)
 
-    def backward_task(self, x, h, c, dh_out, dc_out, dz, dc_in, ws):
+    def backward_task(self, x, h, c, dh_out, dc_out, dz, dc_in, ws, defer=False):
         return _lib.LstmBwdTask(_lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(self.kernel_packed()),
                                 _lib.ptr(self.ln()), _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in),
-                                _lib.ptr(self.ln_grad()), _lib.ptr(ws), h.shape[0], None, None)
+                                _lib.ptr(self.ln_grad()), _lib.ptr(ws), h.shape[0], None, None, None, None,
+                                1 if defer else 0)
 
-    def gather_backward_task(self, adj, zx, h, c, dh_out, dc_out, dz, dc_in, ws, dh_in=None):
-        """``dh_in`` given (d == 64): dh_in = dz Kh^T is formed in the same launch, from dz in registers."""
+    def gather_backward_task(self, adj, zx, h, c, dh_out, dc_out, dz, dc_in, ws, dh_in=None, defer=False):
+        """``dh_in`` given (d == 64): dh_in = dz Kh^T is formed in the same launch, from dz in registers.
+        ``defer``: LayerNorm-gradient partials accumulate in ``ws`` (see backward_finish)."""
         fuse = dh_in is not None and self.d == 64
         return _lib.LstmBwdTask(None, 0, _lib.ptr(h), _lib.ptr(c), _lib.ptr(self.kh_packed()), _lib.ptr(self.ln()),
                                 _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in),
                                 _lib.ptr(self.ln_grad()), _lib.ptr(ws), h.shape[0], _lib.ptr(adj.uv), _lib.ptr(zx),
-                                _lib.ptr(self.kh_t_packed()) if fuse else None, _lib.ptr(dh_in) if fuse else None)
+                                _lib.ptr(self.kh_t_packed()) if fuse else None, _lib.ptr(dh_in) if fuse else None,
+                                1 if defer else 0)
+
+    def backward_finish(self, ws):
+        """Fold the LayerNorm-gradient partials that the deferred backward launches of all time steps left in ws."""
+        _lib.call("tspgnn_lnlstm_bwd_finish_f32", _lib.ptr(ws), _lib.ptr(self.ln_grad()), self.d, _lib.current_stream())
 
     def backward_data(self, dz, dx_out, dh_in):
         """[dx | dh] = dz K^T."""
@@ -1093,7 +1100,8 @@ class GraphNN(object):
             u = self.loop[v][i]
             mlp = self._msg_MLPs[u["msg"]]
             DPRE[(v, i)] = torch.empty((mlp.n_square, T, n[u["var"]], self.var[u["var"]]), **f32)
-        ws = {v: _lib.workspace("tspgnn_lnlstm_bwd_workspace_floats", d, device=device) for v, d in self.var.items()}
+        # LayerNorm-gradient partials of all T steps accumulate here (zeroed); one fold per cell after the loop
+        ws = {v: _lib.workspace("tspgnn_lnlstm_bwd_workspace_floats", d, device=device).zero_() for v, d in self.var.items()}
         folded = tape.folded
         DZX = {v: torch.empty_like(tape.ZX[v]) for v in self.var if folded[v] is not None}
         dH = {v: (dstates.get(v, (None, None))[0]) for v in self.var}
@@ -1108,10 +1116,10 @@ class GraphNN(object):
                 cell = self._RNN_cells[v]
                 if folded[v] is not None:
                     task = cell.gather_backward_task(mats[folded[v]["mat"]], tape.ZX[v][t], tape.H[v][t], tape.C[v][t],
-                                                     dH[v], dC[v], DZ[v][t], ndC[v], ws[v], dh_in=ndH[v])
+                                                     dH[v], dC[v], DZ[v][t], ndC[v], ws[v], dh_in=ndH[v], defer=True)
                 else:
                     task = cell.backward_task(tape.X[v][t], tape.H[v][t], tape.C[v][t], dH[v], dC[v], DZ[v][t], ndC[v],
-                                              ws[v])
+                                              ws[v], defer=True)
                 tasks.setdefault(d, []).append(task)
             for d, ts in tasks.items():
                 for k in range(0, len(ts), 4):
@@ -1158,6 +1166,7 @@ class GraphNN(object):
         # weight gradients: one reduction per variable over all T steps
         for v, d in self.var.items():
             cell = self._RNN_cells[v]
+            cell.backward_finish(ws[v])      # LayerNorm parameters: the deferred per-step partials
             if folded[v] is not None:
                 rows_src = T * tape.X[v].shape[1]
                 cell.backward_weights_folded(tape.X[v].view(-1, cell.dx), DZX[v].view(-1, 4 * d), rows_src,
