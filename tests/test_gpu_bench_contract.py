@@ -1,0 +1,35 @@
+"""bench.py keeps the driver's contract: one JSON line with the agreed keys, measured on this GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_contract(cuda_device):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--cpu-seconds", "2", "--train-steps", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines            # exactly ONE line on stdout
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["higher_is_better"] is True
+    assert r["vs_baseline"] is None and r["scaling"] == "weak" and r["data"] == "synthetic"
+    assert "workload" in r["config"] and "n=40" in r["config"]["workload"]
+    assert r["value"] > 0 and abs(r["value"] - 32 * 1e3 / r["ms_per_step"]) / r["value"] < 1e-3
+    roof = r["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    cpu = r["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1
+    assert "error" not in (r.get("train") or {})
