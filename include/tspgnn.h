@@ -374,6 +374,13 @@ double tspgnn_host_route_cost(const double* Mw, int n, const int64_t* route, int
 /* CSR of EV^T (rowptr:[N+1], eid:[2M], ascending edge ids per vertex) from the endpoint list; HOST pointers.
  * 0 = OK, -2 = endpoint out of range. */
 int tspgnn_host_csr_by_vertex(const int32_t* uv, long long M, int N, int32_t* rowptr, int32_t* eid);
+/*
+ * Parser of the reference's ".graph" instance files (dataset.py:145-187 / instance_loader.py:95-127).  Call with
+ * Ma == Mw == NULL to get n and the tour length, then with Ma[n*n] (int64 0/1), Mw[n*n] (double), route[len].
+ * Returns 0, or <0: -1 bad arguments, -2 cannot open, -3 no/invalid DIMENSION, -4 missing section, -5 edge out of
+ * range, -6 malformed weight matrix.
+ */
+int tspgnn_host_read_graph(const char* path, int* n_out, int* route_len_out, int64_t* Ma, double* Mw, int64_t* route);
 
 #ifdef __cplusplus
 }

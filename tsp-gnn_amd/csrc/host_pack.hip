@@ -2,6 +2,11 @@
 // InstanceLoader.create_batch inner loops (instance_loader.py:56-73) and of the CSR-by-vertex build,
 // so that packing a batch costs ~1 ms instead of the reference's O(M) Python loop + O(M*N) dense matrix.
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
 
 #include "tspgnn.h"
 
@@ -71,5 +76,96 @@ extern "C" int tspgnn_host_csr_by_vertex(const int32_t* uv, long long M, int N, 
     }
     for (int v = N; v > 0; --v) rowptr[v] = rowptr[v - 1];  // undo the cursor advance
     rowptr[0] = 0;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- .graph files
+// The reference's TSPLIB-like text format (written by dataset.py:145-187, parsed by instance_loader.py:95-127 with
+// Python string splitting): DIMENSION, EDGE_DATA_SECTION (pairs "i j" until a line with -1), EDGE_WEIGHT_SECTION
+// (full n x n matrix), TOUR_SECTION (one line of vertex ids).  Two calls: the first (Ma == NULL) returns n and the
+// tour length, the second fills Ma[n*n] (0/1, int64 like the reference's np.zeros(dtype=int)), Mw[n*n], route.
+namespace {
+
+bool slurp(const char* path, std::string* out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    char buf[1 << 16];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, got);
+    fclose(f);
+    return true;
+}
+
+// pointer to the first character after the line that contains `key` (searching from `from`), or NULL
+const char* after_line_with(const char* from, const char* key) {
+    const char* p = strstr(from, key);
+    if (!p) return nullptr;
+    const char* nl = strchr(p, '\n');
+    return nl ? nl + 1 : p + strlen(p);
+}
+
+}  // namespace
+
+extern "C" int tspgnn_host_read_graph(const char* path, int* n_out, int* route_len_out, int64_t* Ma, double* Mw,
+                                      int64_t* route) {
+    if (!path || !n_out || !route_len_out) return -1;
+    std::string text;
+    if (!slurp(path, &text)) return -2;
+    const char* t = text.c_str();
+    const char* dim = strstr(t, "DIMENSION");
+    if (!dim) return -3;
+    const char* colon = dim + strlen("DIMENSION");
+    while (*colon == ':' || *colon == ' ' || *colon == '\t') ++colon;
+    const long n = strtol(colon, nullptr, 10);
+    if (n <= 0 || n > (1 << 20)) return -3;
+    const char* edges = after_line_with(dim, "EDGE_DATA_SECTION");
+    const char* weights = edges ? after_line_with(edges, "EDGE_WEIGHT_SECTION") : nullptr;
+    const char* tour = weights ? after_line_with(weights, "TOUR_SECTION") : nullptr;
+    if (!edges || !weights || !tour) return -4;
+    // tour: integers on the line after TOUR_SECTION
+    int len = 0;
+    {
+        const char* p = tour;
+        for (;;) {
+            while (*p == ' ' || *p == '\t') ++p;
+            if (*p == '\n' || *p == '\r' || *p == 0) break;
+            char* end;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            if (route) route[len] = v;
+            ++len;
+            p = end;
+        }
+    }
+    *n_out = (int)n;
+    *route_len_out = len;
+    if (!Ma && !Mw) return 0;  // size query
+    if (!Ma || !Mw) return -1;
+    memset(Ma, 0, sizeof(int64_t) * n * n);
+    {   // pairs until the line that contains -1 (the reference tests `"-1" in line`)
+        const char* p = edges;
+        while (p < weights) {
+            const char* nl = strchr(p, '\n');
+            const char* e = nl ? nl : p + strlen(p);
+            if (memmem(p, e - p, "-1", 2) != nullptr) break;
+            char* q;
+            const long i = strtol(p, &q, 10);
+            if (q == p) break;
+            const long j = strtol(q, nullptr, 10);
+            if (i < 0 || j < 0 || i >= n || j >= n) return -5;
+            Ma[i * n + j] = 1;
+            if (!nl) break;
+            p = nl + 1;
+        }
+    }
+    {
+        const char* p = weights;
+        for (long k = 0; k < n * n; ++k) {
+            char* q;
+            Mw[k] = strtod(p, &q);
+            if (q == p) return -6;
+            p = q;
+        }
+    }
     return 0;
 }

@@ -67,7 +67,8 @@ SIGNATURES = {
                                   c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 
-HOST_FUNCTIONS = ("tspgnn_host_pack_instance", "tspgnn_host_route_cost", "tspgnn_host_csr_by_vertex")
+HOST_FUNCTIONS = ("tspgnn_host_pack_instance", "tspgnn_host_route_cost", "tspgnn_host_csr_by_vertex",
+                  "tspgnn_host_read_graph")
 
 # size queries: name -> argtypes; these return long long (floats of workspace)
 SIZE_QUERIES = {
@@ -160,6 +161,8 @@ def _load():
     lib.tspgnn_host_route_cost.argtypes = [c_void_p, c_int, c_void_p, c_int]
     lib.tspgnn_host_csr_by_vertex.restype = c_int
     lib.tspgnn_host_csr_by_vertex.argtypes = [c_void_p, c_longlong, c_int, c_void_p, c_void_p]
+    lib.tspgnn_host_read_graph.restype = c_int
+    lib.tspgnn_host_read_graph.argtypes = [c_char_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     return lib
 
 
