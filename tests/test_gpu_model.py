@@ -490,3 +490,30 @@ def test_bf16_storage_mode(cuda_device, name, d, T):
     assert abs(float(loss) - ref["loss"].item()) < 1e-2
     with pytest.raises(NotImplementedError):
         sess.run([model["train_step"]], feed_dict=feed)
+
+
+def test_experiment_sweeps_on_graph_files(cuda_device, tmp_path):
+    """experiments.acceptance_curve / accuracy_by_size over InstanceLoader directories of .graph files: the values
+    are the plain means of per-batch fetches (cross-checked against direct sess.run calls)."""
+    from tspgnn import experiments as X
+    rng = np.random.RandomState(3)
+    dirs = {}
+    for n in (6, 9):
+        p = tmp_path / ("n=%d" % n)
+        p.mkdir()
+        for i in range(4):
+            Ma, Mw, route = tspgnn.random_instance(n, rng)
+            tspgnn.write_graph(Ma, Mw, str(p / ("%d.graph" % i)), route=route)
+        dirs[n] = str(p)
+    model = tspgnn.build_network(32)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer(seed=5))
+    loaders = {n: tspgnn.InstanceLoader(d) for n, d in dirs.items()}
+    devs = [-0.5, 0.0, 0.5]
+    curve = X.acceptance_curve(sess, model, loaders[6], 3, devs, batch_size=2, max_batches=2)
+    assert curve.shape == (3,) and np.all((curve > 0) & (curve < 1))
+    loaders[6].reset()
+    direct = np.mean(np.concatenate([X.get_predictions(sess, model, b, 3) for b in loaders[6].get_batches(2, 0.0)]))
+    assert abs(curve[1] - direct) < 1e-7
+    acc = X.accuracy_by_size(sess, model, loaders, 3, 0.02, batch_size=2, max_batches=2)
+    assert set(acc) == {6, 9} and all(0.0 <= a <= 1.0 for a in acc.values())

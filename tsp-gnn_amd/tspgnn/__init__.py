@@ -16,6 +16,7 @@ from .variables import VariableStore, get_default_store, reset_default_store
 from . import tf_checkpoint
 from .util import load_weights, save_weights
 from .train import run_batch, summarize_epoch
+from . import experiments
 
 __all__ = [
     "TspgnnError", "GraphNN", "LSTMStateTuple", "DeviceAdjacency", "LayerNormBasicLSTMCell", "InstanceLoader",
