@@ -237,6 +237,25 @@ class Mlp(object):
                       _lib.ptr(ws), st)
 
     # ------------------------------------------------------------------ forward
+    def forward_x3(self, x):
+        """Inference forward with the square layers on the bf16x3 kernel (fp32-class accuracy, see csrc/dense_x3.hip);
+        falls back to __call__ for shapes that kernel does not cover."""
+        kind, d, n_sq, head = self._plan
+        if kind != "square" or d not in (32, 64) or len(self._chunks()) != 1 or x.dtype != torch.float32 \
+                or not x.is_contiguous() or x.shape[1] != self.input_size:
+            return self(x)
+        out = torch.empty((x.shape[0], d), dtype=torch.float32, device=x.device)
+        task = _lib.MlpTask(_lib.ptr(x), _lib.ptr(self.wb_packed_x3(0, n_sq - 1, d)), _lib.ptr(out), None, 0, x.shape[0],
+                            n_sq, self.relu_mask(0, n_sq), None, None)
+        _lib.call_multi("tspgnn_mlp_fwd_multi_x3", [task], d)
+        if not head:
+            return out
+        y = torch.empty((x.shape[0], 1), dtype=torch.float32, device=x.device)
+        last = self.layer_names[-1]
+        _lib.call("tspgnn_rowdot_f32", _lib.ptr(out), _lib.ptr(self.store.view(last + "/kernel")),
+                  _lib.ptr(self.store.view(last + "/bias")), _lib.ptr(y), x.shape[0], d, _lib.current_stream())
+        return y
+
     def __call__(self, inputs, save=None):
         """inputs: fp32 device tensor [rows, input_size].  ``save`` (optional list) receives the
         tensors a later backward needs."""

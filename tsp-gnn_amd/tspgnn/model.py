@@ -228,7 +228,9 @@ class Session(object):
         _lib.call("tspgnn_tile_rows_f32", _lib.ptr(self.store.view("V_init")), 1.0 / math.sqrt(float(d)),
                   _lib.ptr(V0), b.N, d, st)
         last = m["gnn"]({"EV": b.adj}, {"V": V0, "E": E0}, b.T)               # model.py:118-122
-        vote = m.E_vote_MLP(last["E"].h.to(torch.float32)).view(-1)           # model.py:128 (bf16 storage: widened once)
+        Eh = last["E"].h.to(torch.float32)                                    # (bf16 storage: widened once)
+        vote_mlp = m.E_vote_MLP.forward_x3 if m["gnn"].gemm == "bf16x3" else m.E_vote_MLP
+        vote = vote_mlp(Eh).view(-1)                                          # model.py:128
         logits = torch.empty(b.B, dtype=torch.float32, device=self.device)
         _lib.call("tspgnn_segment_mean_f32", _lib.ptr(vote), _lib.ptr(b.seg), _lib.ptr(logits), b.B, st)
         pred = torch.empty(b.B, dtype=torch.float32, device=self.device)
