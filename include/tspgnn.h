@@ -374,6 +374,13 @@ double tspgnn_host_route_cost(const double* Mw, int n, const int64_t* route, int
 /* CSR of EV^T (rowptr:[N+1], eid:[2M], ascending edge ids per vertex) from the endpoint list; HOST pointers.
  * 0 = OK, -2 = endpoint out of range. */
 int tspgnn_host_csr_by_vertex(const int32_t* uv, long long M, int N, int32_t* rowptr, int32_t* eid);
+/* Whole-batch packing (one call instead of one per instance): per-instance host pointers / sizes in arrays.
+ * tspgnn_host_count_edges fills n_edges[B] (= count_nonzero(Ma)); tspgnn_host_pack_batch then fills uv[M,2], W[M]
+ * and C[M] (target_cost if use_target, else (1 -/+ dev) * tour cost for even / odd instances) and returns M. */
+int tspgnn_host_count_edges(const void* const* Ma, const int* ma_kind, const int* n, int B, int64_t* n_edges);
+long long tspgnn_host_pack_batch(const void* const* Ma, const int* ma_kind, const double* const* Mw, const int* n,
+                                 const int64_t* const* route, const int* route_len, int B, double dev, int use_target,
+                                 double target_cost, int32_t* uv, double* W, double* C);
 /*
  * Parser of the reference's ".graph" instance files (dataset.py:145-187 / instance_loader.py:95-127).  Call with
  * Ma == Mw == NULL to get n and the tour length, then with Ma[n*n] (int64 0/1), Mw[n*n] (double), route[len].

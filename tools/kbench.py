@@ -3,7 +3,6 @@
 entry point in a back-to-back loop between two HIP events.  Development aid (gpurun)."""
 import os
 import sys
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -44,6 +44,58 @@ extern "C" long long tspgnn_host_pack_instance(const void* Ma, int ma_kind, cons
     }
 }
 
+// Whole-batch variants: one call per batch instead of one per instance (the Python loop over 128 instances costs
+// more than the packing itself).  Arrays of per-instance pointers / sizes, all in host memory.
+template <typename T>
+static long count_nonzero(const T* Ma, long n2) {
+    long m = 0;
+    for (long k = 0; k < n2; ++k) m += Ma[k] != T(0);
+    return m;
+}
+
+extern "C" int tspgnn_host_count_edges(const void* const* Ma, const int* ma_kind, const int* n, int B, int64_t* n_edges) {
+    if (B < 0 || (B > 0 && (!Ma || !ma_kind || !n || !n_edges))) return -1;
+    for (int b = 0; b < B; ++b) {
+        const long n2 = (long)n[b] * n[b];
+        switch (ma_kind[b]) {
+            case 0: n_edges[b] = count_nonzero(static_cast<const int8_t*>(Ma[b]), n2); break;
+            case 1: n_edges[b] = count_nonzero(static_cast<const int32_t*>(Ma[b]), n2); break;
+            case 2: n_edges[b] = count_nonzero(static_cast<const int64_t*>(Ma[b]), n2); break;
+            case 3: n_edges[b] = count_nonzero(static_cast<const float*>(Ma[b]), n2); break;
+            case 4: n_edges[b] = count_nonzero(static_cast<const double*>(Ma[b]), n2); break;
+            default: return -1;
+        }
+    }
+    return 0;
+}
+
+extern "C" double tspgnn_host_route_cost(const double* Mw, int n, const int64_t* route, int len);
+
+// uv[M,2], W[M], C[M] of the block-diagonal batch (instance_loader.py:56-73).  C: target_cost if use_target != 0,
+// else (1 - dev) * cost for even instances and (1 + dev) * cost for odd ones, cost = tspgnn_host_route_cost.
+extern "C" long long tspgnn_host_pack_batch(const void* const* Ma, const int* ma_kind, const double* const* Mw,
+                                            const int* n, const int64_t* const* route, const int* route_len, int B,
+                                            double dev, int use_target, double target_cost, int32_t* uv, double* W,
+                                            double* C) {
+    if (B < 0 || (B > 0 && (!Ma || !ma_kind || !Mw || !n || !uv || !W || !C))) return -1;
+    if (!use_target && B > 0 && (!route || !route_len)) return -1;
+    long long m_acc = 0;
+    int v_off = 0;
+    for (int b = 0; b < B; ++b) {
+        const long long m = tspgnn_host_pack_instance(Ma[b], ma_kind[b], Mw[b], n[b], v_off, uv + 2 * m_acc, W + m_acc);
+        if (m < 0) return -1;
+        double c = target_cost;
+        if (!use_target) {
+            const double cost = tspgnn_host_route_cost(Mw[b], n[b], route[b], route_len[b]);
+            c = (b % 2 == 0) ? (1.0 - dev) * cost : (1.0 + dev) * cost;
+        }
+        for (long long k = 0; k < m; ++k) C[m_acc + k] = c;
+        m_acc += m;
+        v_off += n[b];
+    }
+    return m_acc;
+}
+
 // sum of Mw[min,max] over the pairs zip(route, route[1:] + route[1:]) divided by n -- including the
 // reference's closing-edge quirk (instance_loader.py:70): the last pair is (route[-1], route[1]).
 extern "C" double tspgnn_host_route_cost(const double* Mw, int n, const int64_t* route, int len) {
