@@ -347,8 +347,8 @@ def test_captured_training_step_matches_eager(cuda_device):
 
 
 def test_batch_prefetcher_feeds_identical_batches(cuda_device):
-    """parallel.BatchPrefetcher (background packing + pinned, side-stream upload) must deliver the same
-    device batches as Session.prepare, in order."""
+    """parallel.BatchPrefetcher (background packing, side-stream upload, pinned or pageable staging) must deliver
+    the same device batches as Session.prepare, in order."""
     rng = np.random.RandomState(3)
     host_batches = []
     for _ in range(4):
@@ -365,9 +365,24 @@ def test_batch_prefetcher_feeds_identical_batches(cuda_device):
         feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: 3, model["route_exists"]: r,
                 model["n_vertices"]: nv, model["n_edges"]: ne}
         want.append(sess.forward(feed)["predictions"].clone())
-    got = [sess.forward_device(b)["predictions"].clone() for b in tspgnn.BatchPrefetcher(sess, host_batches, 3)]
+    for pinned in (False, True):
+        got = [sess.forward_device(b)["predictions"].clone()
+               for b in tspgnn.BatchPrefetcher(sess, host_batches, 3, pinned=pinned)]
+        torch.cuda.synchronize()
+        assert len(got) == 4 and all(torch.equal(a, b) for a, b in zip(got, want))
+    # many batches without any synchronisation between them (batches are dropped while their kernels are still
+    # queued: the uploads' memory must not be recycled underneath them), and a failing producer is reported
+    stream = [host_batches[i % 4] for i in range(40)]
+    got = [sess.forward_device(b)["predictions"] for b in tspgnn.BatchPrefetcher(sess, stream, 3)]
     torch.cuda.synchronize()
-    assert len(got) == 4 and all(torch.equal(a, b) for a, b in zip(got, want))
+    assert all(torch.equal(g, want[i % 4]) for i, g in enumerate(got))
+
+    def broken():
+        yield host_batches[0]
+        raise KeyError("producer died")
+    with pytest.raises(RuntimeError):
+        for _ in tspgnn.BatchPrefetcher(sess, broken(), 3):
+            pass
 
 
 def test_save_and_load_weights_roundtrip_with_optimizer_state(cuda_device, tmp_path, capsys):

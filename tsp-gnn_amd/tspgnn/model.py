@@ -60,6 +60,16 @@ def global_variables_initializer(seed=0):
 class DeviceBatch(object):
     """One packed batch resident on the device (see Session.prepare)."""
 
+    def tensors(self):
+        """Every device tensor of the batch (for stream bookkeeping when it was uploaded on another stream)."""
+        out = [getattr(self, k, None) for k in ("WC", "labels", "seg")]
+        adj = getattr(self, "adj", None)
+        if adj is not None:
+            out.append(adj.uv)
+            for csr in (adj.csr, adj.csr_t):
+                out.extend(csr)
+        return [t for t in out if torch.is_tensor(t)]
+
 
 class Network(dict):
     """The dict build_network returns, plus the objects Session needs."""
