@@ -554,8 +554,7 @@ static int launch_cell_x3(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
         }
         if (need > lds_w) lds_w = need;
         const long long tiles = ((long long)c.rows + 15) / 16;
-        // a lock-step task is a latency chain (several LDS re-stagings per round): it gets workgroups for one round
-        cost[k] = tiles * (KBT * 4 + 2 * L + (tasks[k].proj_w ? 8 : 0) + 6) * (tt.kbc[k] < KBT ? 2 : 1);
+        cost[k] = tiles * (KBT * 4 + 2 * L + (tasks[k].proj_w ? 8 : 0) + 6);
         tiles_all += tiles;
     }
     tt.n = n;
@@ -564,7 +563,36 @@ static int launch_cell_x3(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
     const int nw = tiles_all <= (long long)grid * 4 ? 4 : (tiles_all <= (long long)grid * 8 ? 8 : 12);
     const long long max_grid = (tiles_all + nw - 1) / nw;
     if (grid > max_grid) grid = (int)max_grid;
-    grid = split_blocks_x3(cost, n, grid, tt.blk_end);
+    {
+        // A lock-step task is a latency chain (several LDS re-stagings per round) that the resident tasks of the
+        // launch hide: it gets exactly the workgroups of ONE round (more would idle, fewer would double the chain),
+        // capped at half the grid; the resident tasks share the rest in proportion to their cost.
+        int fixed[kMaxTasks], fixed_sum = 0, n_res = 0;
+        long long res_cost[kMaxTasks];
+        for (int k = 0; k < n; ++k) {
+            const bool lock = tt.kbc[k] < (tasks[k].cell.dx + D) / 32;
+            const long long tiles = ((long long)tasks[k].cell.rows + 15) / 16;
+            fixed[k] = lock ? (int)((tiles + nw - 1) / nw) : 0;
+            fixed_sum += fixed[k];
+            if (!lock) ++n_res;
+        }
+        if (n_res == 0 || fixed_sum == 0 || fixed_sum > grid / 2) {
+            grid = split_blocks_x3(cost, n, grid, tt.blk_end);
+        } else {
+            int res_end[kMaxTasks], j = 0;
+            for (int k = 0; k < n; ++k)
+                if (!fixed[k]) res_cost[j++] = cost[k];
+            split_blocks_x3(res_cost, n_res, grid - fixed_sum, res_end);
+            int used = 0;
+            j = 0;
+            for (int k = 0; k < n; ++k) {
+                used += fixed[k] ? fixed[k] : res_end[j] - (j ? res_end[j - 1] : 0);
+                if (!fixed[k]) ++j;
+                tt.blk_end[k] = used;
+            }
+            grid = used;
+        }
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlstm_mlp_fwd_x3_kernel<D>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute(%d B): %s", what, (int)lds_bytes, hipGetErrorString(e));
