@@ -122,11 +122,21 @@ __device__ __forceinline__ void dense_layer_x3(f32x4 (&a)[D / 16], const __bf16*
     }
 }
 
-// bytes -> LDS with 16-byte lanes (packed weights are already in fragment order)
+// bytes -> LDS, 16 bytes per lane, straight from global memory (global_load_lds_dwordx4: no VGPR round trip, so
+// every request of the stage is in flight at once).  The LDS address of a lane is the wavefront's base + lane*16:
+// the base passed to the builtin must be the one of lane 0.  Callers follow up with stage_wait() + a barrier.
 __device__ __forceinline__ void copy_bytes_to_lds(void* dst, const void* __restrict__ src, int nbytes, int tid,
                                                   int nthreads) {
-    copy_to_lds(reinterpret_cast<float*>(dst), reinterpret_cast<const float*>(src), nbytes >> 2, tid, nthreads);
+    const int lane = tid & 63, n16 = nbytes >> 4;
+    const char* s = reinterpret_cast<const char*>(src);
+    char* d = reinterpret_cast<char*>(dst);
+    for (int idx = tid; idx - lane < n16; idx += nthreads) {
+        if (idx < n16)
+            __builtin_amdgcn_global_load_lds(s + (size_t)idx * 16,
+                                             (__attribute__((address_space(3))) void*)(d + (size_t)(idx - lane) * 16), 16, 0, 0);
+    }
 }
+__device__ __forceinline__ void stage_wait() { __builtin_amdgcn_s_waitcnt(0); }
 
 constexpr int kMaxTasks = 4;
 
@@ -167,6 +177,7 @@ __global__ __launch_bounds__(1024) void mlp_fwd_x3_kernel(const MlpTaskTableX3 t
     const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
     const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
     if (tid == 0) *ticket = t_beg;
+    stage_wait();
     __syncthreads();
 
     const int lane = tid & 63, rl = lane & 15, g = lane >> 4;
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(1024) void mlp_fwd_x3_kernel(const MlpTaskTableX3 t
         __syncthreads();
         copy_bytes_to_lds(lds, proj_w, 3 * D * 4 * D * 2, tid, blockDim.x);
         if (tid == 0) *ticket = t_beg;
+        stage_wait();
         __syncthreads();
         const __bf16* wp = reinterpret_cast<const __bf16*>(lds);
         for (;;) {
@@ -384,6 +396,7 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_x3_kernel(const CellTaskTa
         const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
         const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
         if (tid == 0) *ticket = t_beg;
+        stage_wait();
         __syncthreads();
         for (;;) {
             int tile = 0;
@@ -438,6 +451,7 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_x3_kernel(const CellTaskTa
                     const int kb1 = min(KBT, kb0 + kbc);
                     __syncthreads();
                     stage(kb0, kb1);
+                    stage_wait();
                     __syncthreads();
                     if (live) kloop(acc, rc, kb0, kb0, kb1);
                 }
@@ -446,6 +460,7 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_x3_kernel(const CellTaskTa
             if (n_layers > 0) {
                 __syncthreads();
                 copy_bytes_to_lds(lds_wb, mlp_wb, n_layers * LAYER_BYTES, tid, blockDim.x);
+                stage_wait();
                 __syncthreads();
                 for (int l = 0; l < n_layers; ++l) {
                     const __bf16* wh = reinterpret_cast<const __bf16*>(lds_wb + (size_t)l * LAYER_BYTES);
@@ -459,6 +474,7 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_x3_kernel(const CellTaskTa
                 if (proj_w != nullptr) {  // proj_out = mlp(h') P, P packed [D, 4D]
                     __syncthreads();
                     copy_bytes_to_lds(lds_wb, proj_w, 3 * D * 4 * D * 2, tid, blockDim.x);
+                    stage_wait();
                     __syncthreads();
                     f32x4 acc[NT4];
 #pragma unroll

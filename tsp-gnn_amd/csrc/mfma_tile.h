@@ -11,26 +11,21 @@ namespace tspgnn {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-// Straight float4 copy global -> LDS with 8 loads in flight per thread (the weights are already in
-// fragment order, so staging is a pure, fully coalesced stream).
+// global -> LDS, 16 bytes per lane, with gfx950's direct loads (global_load_lds_dwordx4: no VGPR round trip, so every
+// request of the stage is in flight at once; the weights are already in fragment order, the copy is a pure stream).
+// The LDS address of a lane is the wavefront's base + lane*16, so the base handed to the builtin is lane 0's.  Returns
+// after the data has landed in LDS for THIS wavefront (s_waitcnt); callers still need their barrier.
 __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int nfloats, int tid,
                                             int nthreads) {
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-    const int n4 = nfloats >> 2;
-    for (int base = tid; base < n4; base += nthreads * 8) {
-        f32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * nthreads;
-            if (idx < n4) v[u] = s4[idx];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * nthreads;
-            if (idx < n4) d4[idx] = v[u];
-        }
+    const int lane = tid & 63, n16 = nfloats >> 2;
+    const char* s = reinterpret_cast<const char*>(src);
+    char* d = reinterpret_cast<char*>(dst);
+    for (int idx = tid; idx - lane < n16; idx += nthreads) {
+        if (idx < n16)
+            __builtin_amdgcn_global_load_lds(s + (size_t)idx * 16,
+                                             (__attribute__((address_space(3))) void*)(d + (size_t)(idx - lane) * 16), 16, 0, 0);
     }
+    __builtin_amdgcn_s_waitcnt(0);
 }
 
 // acc[t] (t in [0,NT)) += W_frag(step s, tile t) * bval for all output tiles of one k-step.
