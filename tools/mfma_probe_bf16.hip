@@ -2,7 +2,8 @@
 //   mode 0: 4 waves, MFMA only           mode 1: 4 waves, VALU only
 //   mode 2: 8 waves, 4 MFMA + 4 VALU     mode 3: 4 waves, each interleaving both streams (same wave)
 //   mode 4: 8 waves, all interleaving (two mixed waves per SIMD)
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_probe_bf16.hip -o /tmp/probe_bf16
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DSCALAR_VALU] tools/mfma_probe_bf16.hip -o /tmp/probe_bf16
+// (plain -O3 turns the fmaf chain into v_pk_fma_f32; -DSCALAR_VALU pins it to v_fma_f32)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -22,7 +23,13 @@ __device__ __forceinline__ void body(f32x4 (&acc)[8], float (&v)[16], bf16x8 a, 
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = fmaf(v[i], fa, fc);
+                    for (int i = 0; i < 16; ++i) {
+#ifdef SCALAR_VALU   // keep hipcc from SLP-packing the chain into v_pk_fma_f32
+                        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(fa), "v"(fc));
+#else
+                        v[i] = fmaf(v[i], fa, fc);
+#endif
+                    }
             }
         }
     }
