@@ -82,11 +82,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; (ranks wrap around the visible devices only so that the N>1 path can be exercised with the
+    # gloo backend on a single-GPU box: TSPGNN_DIST_BACKEND=gloo, see tests/test_gpu_bench_contract.py)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("TSPGNN_DIST_BACKEND", "nccl")      # "nccl" = RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     sizes, d, T = WORKLOADS[args.workload]
     t_pack0 = time.perf_counter()

@@ -33,3 +33,22 @@ def test_bench_json_contract(cuda_device):
         assert key in cpu, key
     assert cpu["kind"] == "port" and cpu["cores"] >= 1
     assert "error" not in (r.get("train") or {})
+
+
+def test_bench_two_ranks_gloo_on_one_gpu(cuda_device):
+    """The N > 1 path of bench.py (rendezvous, barriers, max-over-ranks timing, the training all-reduce, rank 0
+    printing alone) launched the way the driver launches it; gloo instead of RCCL so that two ranks can share
+    this box's single GPU."""
+    env = dict(os.environ, TSPGNN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--train-steps", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["cpu_baseline"] is None
+    assert r["config"]["global_batch"] == 2 * r["config"]["per_gpu_batch"]
+    assert abs(r["value"] - 2 * 32 * 1e3 / r["ms_per_step"]) / r["value"] < 1e-3      # whole-job aggregate
+    assert "error" not in r["train"] and "world 2" in r["train"]["what"]
