@@ -663,7 +663,12 @@ class GraphNN(object):
                 lstm_tasks.setdefault(d, []).append(cell.task_bf16(x, st, out))
                 keep.append(x)
             keep += [msg_out, zxs]
-            mlp_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in mlp_tasks.items() for k in range(0, len(ts), 4)]
+            # tasks with a projection go to their own launch: without them the MLP kernel needs a third of the
+            # registers (the projection's 4d accumulators) and the big edge task runs at twice the occupancy
+            mlp_calls = []
+            for d, ts in mlp_tasks.items():
+                for group in ([t for t in ts if not t.proj_w], [t for t in ts if t.proj_w]):
+                    mlp_calls += [(_lib.task_array(group[k:k + 4]), d) for k in range(0, len(group), 4)]
             lstm_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in lstm_tasks.items() for k in range(0, len(ts), 4)]
             runs.append((mlp_calls, mid, lstm_calls))
         self._plan_keep = keep
