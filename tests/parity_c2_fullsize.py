@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (lives under tests/: it uses the oracle)
 sys.path.insert(0, os.path.join(ROOT, "tsp-gnn_amd"))
 sys.path.insert(0, ROOT)
 import tspgnn  # noqa: E402
