@@ -385,6 +385,31 @@ def test_batch_prefetcher_feeds_identical_batches(cuda_device):
             pass
 
 
+def test_captured_graph_serves_other_batches_of_the_same_shape(cuda_device):
+    """DeviceBatch.copy_from: one captured forward graph replayed over a stream of same-shaped batches."""
+    rng = np.random.RandomState(11)
+    params = P.init_params(32, seed=1)
+    model = tspgnn.build_network(32)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+
+    def feed_of(t):
+        EV, W, C, r, nv, ne = t
+        return {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: 3, model["route_exists"]: r,
+                model["n_vertices"]: nv, model["n_edges"]: ne}
+    batches = [tspgnn.InstanceLoader.create_batch([tspgnn.random_instance(9, rng) for _ in range(4)], dev=0.02) for _ in range(3)]
+    static = sess.prepare(feed_of(batches[0]))
+    replay = sess.capture_forward(static)
+    for t in batches:
+        want = sess.forward(feed_of(t))["predictions"].clone()
+        static.copy_from(sess.prepare(feed_of(t)))
+        assert torch.equal(replay()["predictions"], want)
+    other = tspgnn.InstanceLoader.create_batch([tspgnn.random_instance(8, rng) for _ in range(4)], dev=0.02)
+    with pytest.raises(ValueError):
+        static.copy_from(sess.prepare(feed_of(other)))
+
+
 def test_save_and_load_weights_roundtrip_with_optimizer_state(cuda_device, tmp_path, capsys):
     """util.save_weights / load_weights (reference util.py:5-37): TensorFlow-bundle files keyed by TF variable names;
     a restored session continues training on exactly the trajectory of the one that saved."""

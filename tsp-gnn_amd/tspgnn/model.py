@@ -60,6 +60,17 @@ def global_variables_initializer(seed=0):
 class DeviceBatch(object):
     """One packed batch resident on the device (see Session.prepare)."""
 
+    def copy_from(self, other):
+        """Overwrite this batch's device tensors with ``other``'s (same shapes: same numbers of graphs, vertices and
+        edges) -- lets a captured forward graph, which is bound to THIS batch's buffers, serve a stream of batches."""
+        mine, theirs = self.tensors(), other.tensors()
+        if (self.M, self.N, self.B, self.T) != (other.M, other.N, other.B, other.T) or len(mine) != len(theirs) \
+                or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(mine, theirs)):
+            raise ValueError("copy_from: the batches differ in shape")
+        for a, b in zip(mine, theirs):
+            a.copy_(b, non_blocking=True)
+        return self
+
     def tensors(self):
         """Every device tensor of the batch (for stream bookkeeping when it was uploaded on another stream)."""
         out = [getattr(self, k, None) for k in ("WC", "labels", "seg")]
