@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""Randomised parity sweep (a script, not collected by pytest): random batch shapes -- 1..12 graphs of 3..45
+vertices, complete or sparse, d in {32, 64}, T in 0..6 -- through the HIP path and the float64 oracle; forward for
+both GEMM arithmetics, gradients on every third case.  Prints one line per case and the worst errors; exits
+non-zero on the first violation of the 1e-5 bar.  `tests/test_gpu_model.py::test_random_shapes_parity` runs a
+fixed, short prefix of the same sequence in the suite.
+
+    python tests/fuzz_parity.py [n_cases] [seed]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(os.path.dirname(HERE), "tsp-gnn_amd"), os.path.dirname(HERE), HERE]
+
+import tspgnn  # noqa: E402
+from oracle import params as P  # noqa: E402
+from oracle import torch_oracle as TO  # noqa: E402
+
+REL_TOL = 1e-5
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def draw_case(rng):
+    B = int(rng.randint(1, 13))
+    sizes = [int(x) for x in rng.randint(3, 46, size=B)]
+    conn = float(rng.choice([1.0, 1.0, 0.7, 0.4]))
+    d = int(rng.choice([32, 64, 64]))
+    T = int(rng.randint(0, 7))
+    return sizes, conn, d, T, int(rng.randint(0, 1 << 30))
+
+
+def feed_of(model, t, T):
+    EV, W, C, route_exists, n_vertices, n_edges = t
+    return {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+
+
+def run_case(idx, case, with_grads):
+    """-> dict of errors; raises AssertionError past the bar."""
+    sizes, conn, d, T, seed = case
+    t = tspgnn.synthetic_batch(sizes, seed=seed, connectivity=conn)
+    params = P.init_params(d, seed=seed % 9973, perturb=True)
+    batch = {"ev_uv": t[0].uv, "W": t[1], "C": t[2], "route_exists": t[3], "n_vertices": t[4], "n_edges": t[5]}
+    ref = TO.forward(TO.to_torch(params, torch.float64), batch, T)
+    errs = {}
+    for gemm in ("bf16x3", "f32"):
+        model = tspgnn.build_network(d)
+        model["gnn"].gemm = gemm
+        sess = tspgnn.Session(model)
+        sess.run(tspgnn.global_variables_initializer())
+        model.store.load(params)
+        pred, loss, last = sess.run([model["predictions"], model["loss"], model["last_states"]], feed_dict=feed_of(model, t, T))
+        e = max(rel_err(pred, ref["predictions"].numpy()),
+                rel_err(last["E"].h, ref["last_states"]["E"][0].numpy()), rel_err(last["E"].c, ref["last_states"]["E"][1].numpy()),
+                rel_err(last["V"].h, ref["last_states"]["V"][0].numpy()), rel_err(last["V"].c, ref["last_states"]["V"][1].numpy()))
+        errs[gemm] = e
+        assert e < REL_TOL, ("forward", gemm, case, e)
+        assert abs(float(loss) - ref["loss"].item()) < REL_TOL, ("loss", gemm, case)
+        if gemm == "bf16x3" and with_grads:
+            out = sess.loss_and_grads(feed_of(model, t, T))
+            torch.cuda.synchronize()
+            g = model.store.grad_dict()
+            _, ref_g = TO.loss_and_grads(params, batch, T, dtype=torch.float64)
+            _, f32_g = TO.loss_and_grads(params, batch, T, dtype=torch.float32, dense=True)
+            l2 = {k: TO.L2NORM_SCALING * params[k] for k in params}
+            gscale = max(np.abs(ref_g[k] - l2[k]).max() for k in ref_g)
+            worst = 0.0
+            for k in ref_g:
+                r = ref_g[k] - l2[k]
+                scale = max(np.abs(r).max(), 1e-3 * gscale)
+                err = np.abs(g[k] - r).max() / scale
+                err32 = np.abs(f32_g[k] - ref_g[k]).max() / scale
+                worst = max(worst, err)
+                assert err < max(2e-5, 3 * err32), ("grad", k, case, err, err32)
+            errs["grad"] = worst
+    return errs
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+    worst = {}
+    for i in range(n_cases):
+        case = draw_case(rng)
+        errs = run_case(i, case, with_grads=(i % 3 == 0))
+        for k, v in errs.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+        print("case %3d  B=%2d n=%s conn=%.1f d=%d T=%d  %s" % (
+            i, len(case[0]), "%d..%d" % (min(case[0]), max(case[0])), case[1], case[2], case[3],
+            "  ".join("%s %.2e" % kv for kv in sorted(errs.items()))), flush=True)
+    print("worst over %d cases: %s" % (n_cases, "  ".join("%s %.2e" % kv for kv in sorted(worst.items()))))
+
+
+if __name__ == "__main__":
+    main()

@@ -557,3 +557,13 @@ def test_experiment_sweeps_on_graph_files(cuda_device, tmp_path):
     assert abs(curve[1] - direct) < 1e-7
     acc = X.accuracy_by_size(sess, model, loaders, 3, 0.02, batch_size=2, max_batches=2)
     assert set(acc) == {6, 9} and all(0.0 <= a <= 1.0 for a in acc.values())
+
+
+def test_random_shapes_parity(cuda_device):
+    """A fixed prefix of tests/fuzz_parity.py's random sequence: batch size, graph sizes (3..45), sparsity, d and T
+    drawn at random; forward parity for both GEMM arithmetics, gradients on every third case.  (The full sweep,
+    60 cases: forward <= 1.9e-6, run with `python tests/fuzz_parity.py 60`.)"""
+    import fuzz_parity
+    rng = np.random.RandomState(2024)
+    for i in range(10):
+        fuzz_parity.run_case(i, fuzz_parity.draw_case(rng), with_grads=(i % 3 == 0))
