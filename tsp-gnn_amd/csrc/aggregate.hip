@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void gather2_sum_kernel(const int2* __restrict
 // in ascending order, the groups are then combined with wavefront shuffles in a fixed
 // order (deterministic result).  Edge ids of the row are fetched with one coalesced load
 // per 64 edges and broadcast by shuffle instead of one dependent scalar load per edge.
-template <int LPR, bool VALUED>
+// CB > 1: rows wider than 16 float4 are split into CB column blocks of LPR float4, one wavefront each (adjacent
+// wavefronts of a workgroup): four times the wavefronts and RPW rows in flight per load instead of one 1 KiB row at a
+// time -- a wide row-sum is otherwise bound by the latency of its ~n dependent-in-order batches of loads.
+template <int LPR, bool VALUED, int CB = 1>
 __device__ __forceinline__ void csr_rowsum_body(const int* __restrict__ rowptr, const int* __restrict__ eid,
                                                 const float* __restrict__ val, const float4* __restrict__ X,
                                                 float4* __restrict__ Y, int N, unsigned blk, unsigned nblk) {
@@ -51,11 +54,12 @@ __device__ __forceinline__ void csr_rowsum_body(const int* __restrict__ rowptr, 
     // every edge row of that graph TWICE (once per endpoint) -- share one L2 and the second read hits.
     const unsigned nb = nblk, q = nb >> 3, r = nb & 7, xcd = blk & 7, slot = blk >> 3;
     const unsigned vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;  // bijective for any nb
-    const int v = (int)(((long long)vb * blockDim.x + threadIdx.x) >> 6);
+    const int wv = (int)(((long long)vb * blockDim.x + threadIdx.x) >> 6);
+    const int v = wv / CB;
     if (v >= N) return;  // wave-uniform
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
-    const int c = lane % LPR;
+    const int c = (wv % CB) * LPR + lane % LPR;   // float4 column within the LPR*CB-wide row
     const int beg = rowptr[v], end = rowptr[v + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = beg; base < end; base += kWave) {
@@ -70,7 +74,7 @@ __device__ __forceinline__ void csr_rowsum_body(const int* __restrict__ rowptr, 
             const int e = __shfl(my_e, src);
             const float w = VALUED ? __shfl(my_w, src) : 1.0f;
             if (k < cnt) {
-                const float4 x = X[(long long)e * LPR + c];
+                const float4 x = X[(long long)e * (LPR * CB) + c];
                 if (VALUED) {
                     acc.x = fmaf(w, x.x, acc.x);
                     acc.y = fmaf(w, x.y, acc.y);
@@ -92,14 +96,14 @@ __device__ __forceinline__ void csr_rowsum_body(const int* __restrict__ rowptr, 
         acc.z += __shfl_xor(acc.z, off);
         acc.w += __shfl_xor(acc.w, off);
     }
-    if (sub == 0) Y[(long long)v * LPR + c] = acc;
+    if (sub == 0) Y[(long long)v * (LPR * CB) + c] = acc;
 }
 
-template <int LPR, bool VALUED>
+template <int LPR, bool VALUED, int CB = 1>
 __global__ __launch_bounds__(256) void csr_rowsum_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
                                                          const float* __restrict__ val, const float4* __restrict__ X,
                                                          float4* __restrict__ Y, int N) {
-    csr_rowsum_body<LPR, VALUED>(rowptr, eid, val, X, Y, N, blockIdx.x, gridDim.x);
+    csr_rowsum_body<LPR, VALUED, CB>(rowptr, eid, val, X, Y, N, blockIdx.x, gridDim.x);
 }
 
 // Both directions of one message-passing step's aggregation in ONE launch: E <- V gather and V <- E
@@ -107,15 +111,15 @@ __global__ __launch_bounds__(256) void csr_rowsum_kernel(const int* __restrict__
 // graphnn.py:143), so their workgroups can share the chip and the HBM pipe instead of paying two
 // launch latencies for ~5 us of streaming each.  Workgroups [0, nb_rowsum) run the row-sum (a multiple
 // of 8 keeps its XCD-contiguous vertex order), the rest the gather.
-template <int LPR>
+template <int LPR, int CB = 1>
 __global__ __launch_bounds__(256) void spmm_pair_kernel(const int2* __restrict__ uv, const float4* __restrict__ Xv,
                                                         float4* __restrict__ Ye, int M, const int* __restrict__ rowptr,
                                                         const int* __restrict__ eid, const float4* __restrict__ Xe,
                                                         float4* __restrict__ Yv, int N, unsigned nb_rowsum) {
     if (blockIdx.x < nb_rowsum)
-        csr_rowsum_body<LPR, false>(rowptr, eid, nullptr, Xe, Yv, N, blockIdx.x, nb_rowsum);
+        csr_rowsum_body<LPR, false, CB>(rowptr, eid, nullptr, Xe, Yv, N, blockIdx.x, nb_rowsum);
     else
-        gather2_sum_body(uv, Xv, Ye, M, LPR, blockIdx.x - nb_rowsum, gridDim.x - nb_rowsum);
+        gather2_sum_body(uv, Xv, Ye, M, LPR * CB, blockIdx.x - nb_rowsum, gridDim.x - nb_rowsum);
 }
 
 // Any d that is a multiple of 4 but not 32/64/128/256: one thread per (row, float4 column).
@@ -147,11 +151,12 @@ static int launch_csr(const int32_t* rowptr, const int32_t* idx, const float* va
     float4* Y4 = reinterpret_cast<float4*>(Y);
     const int d4 = d / 4;
     const unsigned grid = (unsigned)(((long long)R * kWave + 255) / 256);
+    auto grid_cb = [&](int cb) { return (unsigned)(((long long)R * cb * kWave + 255) / 256); };
     switch (d4) {
         case 8: csr_rowsum_kernel<8, VALUED><<<grid, 256, 0, st>>>(rowptr, idx, val, X4, Y4, R); break;
         case 16: csr_rowsum_kernel<16, VALUED><<<grid, 256, 0, st>>>(rowptr, idx, val, X4, Y4, R); break;
-        case 32: csr_rowsum_kernel<32, VALUED><<<grid, 256, 0, st>>>(rowptr, idx, val, X4, Y4, R); break;
-        case 64: csr_rowsum_kernel<64, VALUED><<<grid, 256, 0, st>>>(rowptr, idx, val, X4, Y4, R); break;
+        case 32: csr_rowsum_kernel<16, VALUED, 2><<<grid_cb(2), 256, 0, st>>>(rowptr, idx, val, X4, Y4, R); break;
+        case 64: csr_rowsum_kernel<16, VALUED, 4><<<grid_cb(4), 256, 0, st>>>(rowptr, idx, val, X4, Y4, R); break;
         default: {
             const unsigned g2 = (unsigned)(((long long)R * d4 + 255) / 256);
             csr_rowsum_generic_kernel<VALUED><<<g2, 256, 0, st>>>(rowptr, idx, val, X4, Y4, R, d4);
@@ -190,7 +195,8 @@ extern "C" int tspgnn_spmm_pair_f32(const int32_t* uv, const float* Xv, float* Y
     }
     TSPGNN_REQUIRE(uv && Xv && Ye && rowptr && eid && Xe && Yv, "spmm_pair: null pointer");
     const int d4 = d / 4;
-    unsigned nb_rowsum = (unsigned)(((long long)N * kWave + 255) / 256);
+    const int cb = d4 > 16 ? d4 / 16 : 1;   // column blocks of the row-sum (see csr_rowsum_body)
+    unsigned nb_rowsum = (unsigned)(((long long)N * cb * kWave + 255) / 256);
     long long nb_gather = ((long long)M * d4 + 255) / 256;
     if (nb_gather > 256 * 16) nb_gather = 256 * 16;
     const unsigned grid = nb_rowsum + (unsigned)nb_gather;
@@ -203,8 +209,8 @@ extern "C" int tspgnn_spmm_pair_f32(const int32_t* uv, const float* Xv, float* Y
     switch (d4) {
         case 8: spmm_pair_kernel<8><<<grid, 256, 0, st>>>(uv2, Xv4, Ye4, M, rowptr, eid, Xe4, Yv4, N, nb_rowsum); break;
         case 16: spmm_pair_kernel<16><<<grid, 256, 0, st>>>(uv2, Xv4, Ye4, M, rowptr, eid, Xe4, Yv4, N, nb_rowsum); break;
-        case 32: spmm_pair_kernel<32><<<grid, 256, 0, st>>>(uv2, Xv4, Ye4, M, rowptr, eid, Xe4, Yv4, N, nb_rowsum); break;
-        default: spmm_pair_kernel<64><<<grid, 256, 0, st>>>(uv2, Xv4, Ye4, M, rowptr, eid, Xe4, Yv4, N, nb_rowsum); break;
+        case 32: spmm_pair_kernel<16, 2><<<grid, 256, 0, st>>>(uv2, Xv4, Ye4, M, rowptr, eid, Xe4, Yv4, N, nb_rowsum); break;
+        default: spmm_pair_kernel<16, 4><<<grid, 256, 0, st>>>(uv2, Xv4, Ye4, M, rowptr, eid, Xe4, Yv4, N, nb_rowsum); break;
     }
     return launched("tspgnn_spmm_pair_f32");
 }
