@@ -86,6 +86,72 @@ __global__ __launch_bounds__(512) void linear_kernel(const float* __restrict__ X
     }
 }
 
+// Few rows (the vertex side: a few hundred 16-row tiles on 256 CUs): one wavefront per tile would run the whole
+// kin/4 * NT chain of MFMAs alone (512 at kin=256, NT=8: ~8 us) with most of the chip idle.  Here the NT output tiles
+// of a row tile are split over four wavefronts (NT/4 each), two row tiles per workgroup; W resident in LDS.
+template <int NT, int PART>
+__device__ __forceinline__ void linear_split_part(const float* lds_w, const float* xr, int QT, int g, int rl,
+                                                  f32x4 (&acc)[NT / 4]) {
+    constexpr int TW = NT / 4, U = (PART * TW) / 4, C0 = (PART * TW) % 4;
+    for (int q0 = 0; q0 < QT; q0 += 8) {
+        f32x4 xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[i] = ld4(xr + (q0 + i < QT ? q0 + i : QT - 1) * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (q0 + i < QT) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x4 aw = ld4(lds_w + frag_off<NT>((q0 + i) * 4 + p, g, rl) + U * 64);
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) acc[t] = MFMA16(aw[C0 + t], xv[i][p], acc[t]);
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void linear_split_kernel(const float* __restrict__ X, int kin,
+                                                           const float* __restrict__ Wp, float* __restrict__ Y1, int n1,
+                                                           float* __restrict__ Y2, int n2, int acc2, int rows,
+                                                           int tiles_total) {
+    static_assert(NT % 4 == 0, "four column parts");
+    constexpr int TW = NT / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int QT = kin >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4, wave = tid >> 6;
+    copy_to_lds(lds, Wp, kin * NT * 16, tid, blockDim.x);
+    __syncthreads();
+    const int tile = blockIdx.x * 2 + (wave >> 2), part = wave & 3;
+    if (tile >= tiles_total) return;  // wave-uniform, after the only barrier
+    const int row = tile * 16 + rl;
+    const bool valid = row < rows;
+    const size_t rc = (size_t)(valid ? row : rows - 1);
+    const float* xr = X + rc * kin + g * 4;
+    f32x4 acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    switch (part) {
+        case 0: linear_split_part<NT, 0>(lds, xr, QT, g, rl, acc); break;
+        case 1: linear_split_part<NT, 1>(lds, xr, QT, g, rl, acc); break;
+        case 2: linear_split_part<NT, 2>(lds, xr, QT, g, rl, acc); break;
+        default: linear_split_part<NT, 3>(lds, xr, QT, g, rl, acc); break;
+    }
+    if (valid) {
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            const int col = (part * TW + t) * 16;
+            if (col < n1) {
+                st4(Y1 + rc * n1 + col + g * 4, acc[t]);
+            } else {
+                float* p = Y2 + rc * n2 + (col - n1) + g * 4;
+                st4(p, acc2 ? ld4(p) + acc[t] : acc[t]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ LN-LSTM backward
 // LayerNorm forward statistics of one gate held in the D-layout (TPG tiles x 4 regs per lane, the rest
 // of the row in the lanes l^16, l^32, l^48): v <- xhat = (v - mean) * rstd, returns rstd.
@@ -635,6 +701,15 @@ static int launch_linear(const float* X, int kin, const float* Wp, float* Y1, in
     if (e != hipSuccess) return fail((int)e, "linear: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
     int grid = n_cus() * per_cu;
+    if constexpr (NT % 4 == 0) {
+        if (qc >= QT && tiles <= n_cus() * 4) {   // few tiles: split each tile's columns over four wavefronts
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_split_kernel<NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return fail((int)e, "linear: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            linear_split_kernel<NT><<<(tiles + 1) / 2, 512, lds_bytes, st>>>(X, kin, Wp, Y1, n1, Y2, n2, acc2, rows, tiles);
+            return launched("tspgnn_linear_f32");
+        }
+    }
     const int nw = (qc >= QT && tiles <= grid * 4) ? 4 : 8;
     const int max_grid = (tiles + nw - 1) / nw;
     if (grid > max_grid) grid = max_grid;
