@@ -454,19 +454,23 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const LstmBwdTaskTa
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n_chunks,
                                                               long long stride, float* __restrict__ out, int n,
                                                               float scale, int accumulate) {
-    __shared__ float red[256];
+    // The chunk partials are folded in float64: a gradient that is a small difference of large per-graph
+    // contributions (labels 0/1 pull in opposite directions) would otherwise lose its digits HERE, in the one
+    // place where thousands of fp32 partials of either sign meet; n_chunks * n adds, free on this chip.
+    __shared__ double red[256];
     const int S = blockDim.y;  // slices; blockDim.x * S == 256
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float s = 0.f;
+    double s = 0.0;
     if (i < n) {
-        for (int c = threadIdx.y; c < n_chunks; c += S) s += partial[(size_t)c * stride + i];
+        for (int c = threadIdx.y; c < n_chunks; c += S) s += (double)partial[(size_t)c * stride + i];
     }
     red[threadIdx.y * blockDim.x + threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.y == 0 && i < n) {
-        float t = red[threadIdx.x];
+        double t = red[threadIdx.x];
         for (int k = 1; k < S; ++k) t += red[k * blockDim.x + threadIdx.x];
-        out[i] = accumulate ? fmaf(scale, t, out[i]) : scale * t;
+        t *= (double)scale;
+        out[i] = (float)(accumulate ? t + (double)out[i] : t);
     }
 }
 
