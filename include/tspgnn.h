@@ -298,7 +298,10 @@ typedef struct tspgnn_lstm_bwd_task {
 typedef struct tspgnn_mlp_bwd_task {
     const float* dY; const float* wt; const float* acts; long long acts_stride; const float* Yout;
     float* dpre; long long dpre_stride; float* dX; int accumulate_dx; int rows; int n_layers; unsigned relu_mask;
-} tspgnn_mlp_bwd_task;    /* fields as the arguments of tspgnn_mlp_bwd_f32 */
+    const int32_t* uv;                    /* optional, [rows,2]: gather-init mode -- dY is an [n_src,d] array and the chain
+                                             starts from dY[uv[r][0]] + dY[uv[r][1]], i.e. the adjoint of the V<-E row-sum
+                                             (EV x dY, graphnn.py:156-160 with adjoint_a) without materialising it */
+} tspgnn_mlp_bwd_task;    /* fields as the arguments of tspgnn_mlp_bwd_f32 (uv = NULL there) */
 
 int tspgnn_lnlstm_bwd_multi_f32(const tspgnn_lstm_bwd_task* tasks, int n_tasks, int d, void* stream);
 /* ln_grad[10d] += fixed-order sum of the deferred partials in `workspace` (tspgnn_lnlstm_bwd_workspace_floats(d)). */

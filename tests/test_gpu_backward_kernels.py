@@ -291,3 +291,29 @@ def test_adam_clip_step(cuda_device):
     torch.cuda.synchronize()
     assert int(cnt.item()) == step
     assert np.abs(td2.cpu().numpy() - p["a"]).max() < 2e-6 * np.abs(p["a"]).max()
+
+
+@pytest.mark.parametrize("d,rows,n_src", [(64, 700, 41), (32, 33, 9)])
+def test_mlp_backward_gather_init_equals_explicit_gather(cuda_device, d, rows, n_src):
+    """tspgnn_mlp_bwd_task.uv: the chain starts from dY[u] + dY[v] -- bit-identical to gather2_sum followed by the
+    plain chain (same additions in the same order)."""
+    rng = np.random.RandomState(rows)
+    L, mask = 3, 0b011
+    Ws = [(rng.randn(d, d) / np.sqrt(d)).astype(np.float32) for _ in range(L)]
+    wt = torch.cat([packed(w, cuda_device, transposed=1).view(-1) for w in Ws])
+    uv = np.stack([rng.randint(0, n_src, rows), rng.randint(0, n_src, rows)], 1).astype(np.int32)
+    src = dev(rng.randn(n_src, d).astype(np.float32), cuda_device)
+    acts = dev(rng.randn(L - 1, rows, d).astype(np.float32), cuda_device)
+    uvd = dev(uv, cuda_device, np.int32)
+    gathered = empty((rows, d), cuda_device)
+    _lib.call("tspgnn_gather2_sum_f32", _lib.ptr(uvd), _lib.ptr(src), _lib.ptr(gathered), rows, n_src, d, None)
+    outs = []
+    for dY, uvp in ((gathered, None), (src, uvd)):
+        dpre = empty((L, rows, d), cuda_device)
+        dX = empty((rows, d), cuda_device)
+        task = _lib.MlpBwdTask(_lib.ptr(dY), _lib.ptr(wt), _lib.ptr(acts), 0, None, _lib.ptr(dpre), 0, _lib.ptr(dX), 0, rows, L, mask,
+                               _lib.ptr(uvp))
+        _lib.call_multi("tspgnn_mlp_bwd_multi_f32", [task], d)
+        torch.cuda.synchronize()
+        outs.append((dpre.cpu().numpy(), dX.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

@@ -509,6 +509,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdTaskTable tt) 
     const int acc_dx = tt.task[k].accumulate_dx;
     const int rows = tt.task[k].rows, n_layers = tt.task[k].n_layers;
     const unsigned relu_mask = tt.task[k].relu_mask;
+    const int2* __restrict__ uv = reinterpret_cast<const int2*>(tt.task[k].uv);
     const int tiles_total = (rows + 15) / 16;
     constexpr int NT = D / 16;
     __shared__ __attribute__((aligned(16))) float lds[MAXL * D * D + 4];
@@ -529,8 +530,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdTaskTable tt) 
         const bool valid = row < rows;
         const size_t rbase = (size_t)(valid ? row : rows - 1) * D + g * 4;
         f32x4 a[NT];
+        if (uv != nullptr) {  // gather-init mode: the adjoint of the row-sum aggregation, formed on the fly
+            const int2 ends = uv[valid ? row : rows - 1];
+            const float* pu = dY + (size_t)ends.x * D + g * 4;
+            const float* pv = dY + (size_t)ends.y * D + g * 4;
 #pragma unroll
-        for (int q = 0; q < NT; ++q) a[q] = ld4(dY + rbase + q * 16);
+            for (int q = 0; q < NT; ++q) a[q] = ld4(pu + q * 16) + ld4(pv + q * 16);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NT; ++q) a[q] = ld4(dY + rbase + q * 16);
+        }
         for (int l = n_layers - 1; l >= 0; --l) {
             if ((relu_mask >> l) & 1u) {
                 const float* A = (l == n_layers - 1) ? Yout : acts + (size_t)l * acts_stride;
@@ -930,7 +939,7 @@ extern "C" int tspgnn_mlp_bwd_f32(const float* dY, const float* wt, const float*
                                   const float* Yout, float* dpre, long long dpre_stride, float* dX, int accumulate_dx,
                                   int rows, int d, int n_layers, unsigned relu_mask, void* stream) {
     const tspgnn_mlp_bwd_task t = {dY, wt, acts, acts_stride, Yout, dpre, dpre_stride, dX, accumulate_dx, rows, n_layers,
-                                   relu_mask};
+                                   relu_mask, nullptr};
     return tspgnn_mlp_bwd_multi_f32(&t, 1, d, stream);
 }
 

@@ -123,7 +123,7 @@ class MlpBwdTask(ctypes.Structure):
     """tspgnn_mlp_bwd_task (include/tspgnn.h)."""
     _fields_ = [("dY", c_void_p), ("wt", c_void_p), ("acts", c_void_p), ("acts_stride", c_longlong), ("Yout", c_void_p),
                 ("dpre", c_void_p), ("dpre_stride", c_longlong), ("dX", c_void_p), ("accumulate_dx", c_int),
-                ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint)]
+                ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint), ("uv", c_void_p)]
 
 
 class TspgnnError(RuntimeError):

@@ -1146,13 +1146,19 @@ class GraphNN(object):
                     dy = dX[v] if len(self.loop[v]) == 1 else dX[v][:, off:off + w].contiguous()
                     off += w
                     src = u["var"]
+                    gather_uv = None
                     if "mat" in u and folded[v] is None:   # adjoint of mat (x) y is mat^T (x) dy and vice versa
-                        dy = mats[u["mat"]].matmul(dy, transpose=not u.get("transpose?", False))
+                        adj = mats[u["mat"]]
+                        if u.get("transpose?", False) and adj.uv is not None and "msg" in u and src not in targets \
+                                and self._msg_MLPs[u["msg"]].backward_task_fuses_gather(dy):
+                            gather_uv = adj.uv     # the adjoint of the row-sum is a two-row gather: the MLP launch forms it
+                        else:
+                            dy = adj.matmul(dy, transpose=not u.get("transpose?", False))
                     if "msg" in u:
                         mlp = self._msg_MLPs[u["msg"]]
                         acts, dpre = tape.acts[(v, i)], DPRE[(v, i)]
                         task = mlp.backward_task(dy, acts[:, t], acts.stride(0), None, dpre[:, t], dpre.stride(0),
-                                                 ndH[src], True)
+                                                 ndH[src], True, gather_uv=gather_uv)
                         if task is None or src in targets:   # several kernels, or a second writer of ndH[src]
                             mlp.backward_data(dy, acts[:, t], acts.stride(0), None, dpre[:, t], dpre.stride(0), ndH[src],
                                               accumulate=True)

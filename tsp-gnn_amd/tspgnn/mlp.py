@@ -215,14 +215,20 @@ class Mlp(object):
                       _lib.ptr(dst), 1 if (accumulate and first) else 0, rows, d, n, self.relu_mask(l0, n), st)
             g = dst
 
-    def backward_task(self, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate):
-        """An _lib.MlpBwdTask for a single-kernel chain (None if several kernels are needed)."""
+    def backward_task(self, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, gather_uv=None):
+        """An _lib.MlpBwdTask for a single-kernel chain (None if several kernels are needed).
+        ``gather_uv`` (int32 [rows,2]): dY holds SOURCE rows and the chain starts from dY[u] + dY[v] per row."""
         kind, d, n_sq, head = self._plan
         if len(self._chunks()) != 1:
             return None
         return _lib.MlpBwdTask(_lib.ptr(dY), _lib.ptr(self.wt_packed(0, n_sq - 1, d)), _lib.ptr(acts), acts_stride,
                                _lib.ptr(y_out), _lib.ptr(dpre), dpre_stride, _lib.ptr(dX), 1 if accumulate else 0,
-                               dY.shape[0], n_sq, self.relu_mask(0, n_sq))
+                               dY.shape[0] if gather_uv is None else gather_uv.shape[0], n_sq, self.relu_mask(0, n_sq),
+                               _lib.ptr(gather_uv))
+
+    def backward_task_fuses_gather(self, dY):
+        """backward_task(..., gather_uv=...) is available: one kernel covers the chain and dY is a plain fp32 array."""
+        return len(self._chunks()) == 1 and dY.dtype == torch.float32 and dY.is_contiguous()
 
     def backward_weights(self, layer_inputs, layer_dpre, rows):
         """dW_l += X_l^T dPre_l, db_l += colsum(dPre_l) for the square layers; ``rows`` may span all
