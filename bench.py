@@ -264,6 +264,10 @@ def main():
                                "csr_rowsum": round(rowsum_b / t_rowsum / 1e3, 1)},
             "spmm_steps_per_s": round(1e6 / t_pair, 1),
             "incidences_per_s": round(4 * M * 1e6 / t_pair, 1),
+            "note": "north_star's target kernel, measured back to back on the benchmark batch (HIP events on the launch "
+                    "stream, 300 launches).  In the timed forward the V<-E direction is this row-sum kernel "
+                    "(kernels_us.tspgnn_csr_rowsum_f32) and the E<-V gather is folded into the edge cell's operand "
+                    "load (Zx[u] + Zx[v] inside lnlstm_mlp_fwd_multi_x3, whose figures are in roofline_dense).",
         }
         dense_names = ("tspgnn_mlp_fwd_f32", "tspgnn_mlp_fwd_multi_f32", "tspgnn_lnlstm_fwd_f32",
                        "tspgnn_lnlstm_fwd_multi_f32", "tspgnn_lnlstm_gather_fwd_f32", "tspgnn_linear_f32",
