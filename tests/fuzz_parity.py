@@ -8,6 +8,7 @@ shown next to the fp32 restatement's own error.  `tests/test_gpu_model.py::test_
 fixed, short prefix of the same sequence in the suite.
 
     python tests/fuzz_parity.py [n_cases] [seed]
+    BF16=1 python tests/fuzz_parity.py [n_cases] [seed]     # the bf16-storage mode against the bf16-rounding oracle
 """
 import os
 import sys
@@ -95,13 +96,34 @@ def run_case(idx, case, with_grads, strict=True):
     return errs
 
 
+def run_case_bf16(case):
+    """The bf16-storage mode (BASELINE config 5) on the same random shapes, d in {64, 128}: against the oracle
+    that rounds at the same points (a handful of bf16 ulps) -- the suite's bars (tests/test_gpu_model.py)."""
+    sizes, conn, d, T, seed = case
+    d = 128 if d == 32 else d
+    t = tspgnn.synthetic_batch(sizes, seed=seed, connectivity=conn)
+    params = P.init_params(d, seed=seed % 9973, perturb=True)
+    batch = {"ev_uv": t[0].uv, "W": t[1], "C": t[2], "route_exists": t[3], "n_vertices": t[4], "n_edges": t[5]}
+    ref = TO.forward(TO.to_torch(params, torch.float64), batch, T, bf16=True)
+    model = tspgnn.build_network(d, float_dtype=torch.bfloat16)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    pred, last = sess.run([model["predictions"], model["last_states"]], feed_dict=feed_of(model, t, T))
+    e_h = rel_err(last["E"].h, ref["last_states"]["E"][0].numpy())
+    e_c = rel_err(last["V"].c, ref["last_states"]["V"][1].numpy())
+    e_p = rel_err(pred, ref["predictions"].numpy())
+    assert e_h < 3e-2 and e_c < 3e-2 and e_p < 1e-2, ("bf16", case, e_h, e_c, e_p)
+    return {"bf16_h": e_h, "bf16_c": e_c, "bf16_pred": e_p}
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
     worst = {}
     for i in range(n_cases):
         case = draw_case(rng)
-        errs = run_case(i, case, with_grads=(i % 3 == 0), strict=False)
+        errs = run_case_bf16(case) if os.environ.get("BF16") else run_case(i, case, with_grads=(i % 3 == 0), strict=False)
         for k, v in errs.items():
             worst[k] = max(worst.get(k, 0.0), v)
         print("case %3d  B=%2d n=%s conn=%.1f d=%d T=%d  %s" % (
