@@ -9,6 +9,7 @@ fixed, short prefix of the same sequence in the suite.
 
     python tests/fuzz_parity.py [n_cases] [seed]
     BF16=1 python tests/fuzz_parity.py [n_cases] [seed]     # the bf16-storage mode against the bf16-rounding oracle
+    DET=1 python tests/fuzz_parity.py [n_cases] [seed]      # eager vs captured training steps, bit for bit
 """
 import os
 import sys
@@ -117,13 +118,44 @@ def run_case_bf16(case):
     return {"bf16_h": e_h, "bf16_c": e_c, "bf16_pred": e_p}
 
 
+def run_case_determinism(case):
+    """Eager train_step vs the captured one (two HIP graphs), three steps each, on the same random shape: losses and
+    final weights must be identical bit for bit, and a captured forward must replay bit-identically."""
+    sizes, conn, d, T, seed = case
+    t = tspgnn.synthetic_batch(sizes, seed=seed, connectivity=conn)
+    params = P.init_params(d, seed=seed % 9973, perturb=True)
+    finals = []
+    for captured in (False, True):
+        model = tspgnn.build_network(d)
+        sess = tspgnn.Session(model)
+        sess.run(tspgnn.global_variables_initializer())
+        model.store.load(params)
+        b = sess.prepare(feed_of(model, t, T))
+        if captured:
+            fwd = sess.capture_forward(b)
+            p0 = fwd()["predictions"].clone()
+            assert torch.equal(fwd()["predictions"], p0) and torch.equal(sess.forward_device(b)["predictions"], p0), ("replay", case)
+        step = sess.capture_train_step(b) if captured else (lambda: sess.train_step(b))
+        losses = [float(step()["stats"][0].item()) for _ in range(3)]
+        torch.cuda.synchronize()
+        finals.append((model.store.theta.clone(), losses))
+    assert finals[0][1] == finals[1][1], ("losses", case, finals[0][1], finals[1][1])
+    assert torch.equal(finals[0][0], finals[1][0]), ("weights", case)
+    return {"det_ok": 1.0}
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
     worst = {}
     for i in range(n_cases):
         case = draw_case(rng)
-        errs = run_case_bf16(case) if os.environ.get("BF16") else run_case(i, case, with_grads=(i % 3 == 0), strict=False)
+        if os.environ.get("BF16"):
+            errs = run_case_bf16(case)
+        elif os.environ.get("DET"):
+            errs = run_case_determinism(case)
+        else:
+            errs = run_case(i, case, with_grads=(i % 3 == 0), strict=False)
         for k, v in errs.items():
             worst[k] = max(worst.get(k, 0.0), v)
         print("case %3d  B=%2d n=%s conn=%.1f d=%d T=%d  %s" % (
