@@ -70,19 +70,27 @@ template <int NT>
 __device__ __forceinline__ void kblock_p3(f32x4 (&acc)[NT], const __bf16* wh, const __bf16* wm, const __bf16* wl, int kb,
                                           int g, int jl, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
     const int off = ((kb * 4 + g) * NT * 16 + jl) * 8;
+    // The weight fragments of tile t+1 are fetched while the six (dependent) MFMAs of tile t run: hi and mid into a
+    // second register set, lo -- used by the first MFMA only -- back into its own register right after that MFMA.
+    bf16x8 ah = ldw(wh + off), am = ldw(wm + off), al = ldw(wl + off);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const bf16x8 ah = ldw(wh + off + t * 128);
-        const bf16x8 am = ldw(wm + off + t * 128);
-        const bf16x8 al = ldw(wl + off + t * 128);
+        bf16x8 nah = ah, nam = am;
+        if (t + 1 < NT) {
+            nah = ldw(wh + off + (t + 1) * 128);
+            nam = ldw(wm + off + (t + 1) * 128);
+        }
         f32x4 c = acc[t];
         c = MFMA_BF16(al, bh, c);  // smallest terms first
+        if (t + 1 < NT) al = ldw(wl + off + (t + 1) * 128);
         c = MFMA_BF16(am, bm, c);
         c = MFMA_BF16(ah, bl, c);
         c = MFMA_BF16(am, bh, c);
         c = MFMA_BF16(ah, bm, c);
         c = MFMA_BF16(ah, bh, c);
         acc[t] = c;
+        ah = nah;
+        am = nam;
     }
 }
 
