@@ -567,3 +567,29 @@ def test_random_shapes_parity(cuda_device):
     rng = np.random.RandomState(2024)
     for i in range(10):
         fuzz_parity.run_case(i, fuzz_parity.draw_case(rng), with_grads=(i % 3 == 0))
+
+
+@pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
+def test_edge_order_within_a_problem_is_free(cuda_device, gemm):
+    """The reference orders a problem's edges as np.nonzero walks the upper triangle (instance_loader.py:60-66); the
+    kernels must not depend on it: edges shuffled within each problem (and the endpoints of half of them swapped)
+    give the same predictions, and states that are the same rows in the new order -- against the oracle on the
+    shuffled batch, and against the unshuffled HIP run."""
+    t = pack_tuple("ragged_B6", 2)
+    EV, W, C, r, nv, ne = t
+    rng = np.random.RandomState(4)
+    eo = np.concatenate([[0], np.cumsum(ne)])
+    perm = np.concatenate([eo[i] + rng.permutation(int(ne[i])) for i in range(len(ne))])
+    uv = EV.uv[perm].copy()
+    swap = rng.rand(len(uv)) < 0.5
+    uv[swap] = uv[swap][:, ::-1]
+    t2 = (tspgnn.SparseEV(uv, EV.shape[1]), W[perm], C[perm], r, nv, ne)
+    params = P.init_params(64, seed=5, perturb=True)
+    a = run_hip(64, params, t, 5, fetch=("predictions", "last_states"), gemm=gemm)
+    b = run_hip(64, params, t2, 5, fetch=("predictions", "last_states"), gemm=gemm)
+    ref = TO.forward(TO.to_torch(params, torch.float64), batch_from_tuple(t2), 5)
+    assert rel_err(b["predictions"], ref["predictions"].numpy()) < REL_TOL
+    assert rel_err(b["last_states"]["E"].h, ref["last_states"]["E"][0].numpy()) < REL_TOL
+    assert rel_err(b["predictions"], a["predictions"]) < 2e-6
+    assert rel_err(b["last_states"]["E"].h, a["last_states"]["E"].h[perm]) < 5e-6
+    assert rel_err(b["last_states"]["V"].c, a["last_states"]["V"].c) < 5e-6
