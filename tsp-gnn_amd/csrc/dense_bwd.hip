@@ -680,6 +680,109 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X,
     }
 }
 
+// The same reduction on the bf16 matrix cores with fp32-class accuracy (bf16x3, see dense_x3.hip) for the hot shape
+// class kin % 64 == 0, nout % 64 == 0: 32 rows per step -- lane (f, g) loads the float4 of rows r0 + 8g .. 8g+7, eight
+// consecutive contraction indices of v_mfma_f32_16x16x32_bf16 -- 96 MFMAs of 16 cycles instead of 128 of 32 per 32 rows,
+// which turns the cell's [T*M,64]^T [T*M,256] product from MFMA-bound into HBM-bound.  Output layout as wgrad_kernel<4,4>.
+typedef __bf16 bf16x8_w __attribute__((ext_vector_type(8)));
+#define MFMA_BF16_W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void split3_w(const float (&x)[8], bf16x8_w& hi, bf16x8_w& mid, bf16x8_w& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        const float r1 = x[i] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        hi[i] = h;
+        mid[i] = m;
+        lo[i] = (__bf16)(r1 - (float)m);
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                       long long rows, int kin, int nout, float* __restrict__ P,
+                                                       float* __restrict__ Pb, int n_chunks, long long chunk_rows) {
+    const int lane = threadIdx.x & 63, fl = lane & 15, g = lane >> 4;
+    const int nbi = kin / 64, nbj = nout / 64, nob = nbi * nbj;
+    const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= (long long)n_chunks * nob) return;  // wave-uniform
+    const int c = (int)(w / nob), ob = (int)(w % nob), ib = ob / nbj, jb = ob % nbj;
+    const long long r_beg = c * chunk_rows, r_end = min(rows, r_beg + chunk_rows);
+    const float* xp = X + (size_t)ib * 64 + fl * 4;
+    const float* yp = dY + (size_t)jb * 64 + fl * 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long r0 = r_beg; r0 < r_end; r0 += 32) {
+        f32x4 a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long r = r0 + 8 * g + j;
+            const bool ok = r < r_end;
+            const long long rr = ok ? r : r_beg;
+            a[j] = ld4(xp + rr * kin);
+            b[j] = ld4(yp + rr * nout);
+            if (!ok) {
+                a[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                b[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        bf16x8_w ah[4], am[4], al[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = a[j][m];
+            split3_w(v, ah[m], am[m], al[m]);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = b[j][n];
+                cs[n] += v[j];
+            }
+            bf16x8_w bh, bm, bl;
+            split3_w(v, bh, bm, bl);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 d = acc[m][n];
+                d = MFMA_BF16_W(al[m], bh, d);  // smallest terms first
+                d = MFMA_BF16_W(am[m], bm, d);
+                d = MFMA_BF16_W(ah[m], bl, d);
+                d = MFMA_BF16_W(am[m], bh, d);
+                d = MFMA_BF16_W(ah[m], bm, d);
+                d = MFMA_BF16_W(ah[m], bh, d);
+                acc[m][n] = d;
+            }
+        }
+    }
+    float* Pc = P + (size_t)c * kin * nout;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xf = ib * 64 + (4 * g + r) * 4 + m;
+                const int yf = jb * 64 + fl * 4 + n;
+                Pc[(size_t)xf * nout + yf] = acc[m][n][r];
+            }
+    if (Pb != nullptr && ib == 0) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float s = cs[n];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (g == 0) Pb[(size_t)c * nout + jb * 64 + fl * 4 + n] = s;
+        }
+    }
+}
+
 static int pick_vec(int width) { return width % 64 == 0 ? 4 : (width % 32 == 0 ? 2 : 1); }
 
 // Split of the row range used by tspgnn_wgrad_f32 (and its workspace size).
@@ -967,7 +1070,12 @@ extern "C" int tspgnn_wgrad_f32(const float* X, const float* dY, long long rows,
     const int av = pick_vec(kin), bv = pick_vec(nout);
     int rc;
 #define TSPGNN_WG(A, B) rc = launch_wgrad<A, B>(X, dY, rows, kin, nout, P, Pb, nc, cr, st)
-    if (av == 4 && bv == 4) TSPGNN_WG(4, 4);
+    if (av == 4 && bv == 4 && rows >= 4096) {   // the big reductions over T*rows: bf16 matrix cores, fp32-class accuracy
+        const int nob = (kin / 64) * (nout / 64);
+        const unsigned grid = (unsigned)(((long long)nc * nob + 3) / 4);
+        wgrad_x3_kernel<<<grid, 256, 0, st>>>(X, dY, rows, kin, nout, P, Pb, nc, cr);
+        rc = launched("tspgnn_wgrad_f32");
+    } else if (av == 4 && bv == 4) TSPGNN_WG(4, 4);
     else if (av == 4 && bv == 2) TSPGNN_WG(4, 2);
     else if (av == 4 && bv == 1) TSPGNN_WG(4, 1);
     else if (av == 2 && bv == 4) TSPGNN_WG(2, 4);
