@@ -1,7 +1,9 @@
-"""Data-parallel path: instances sharded over ranks, ONE all-reduce of the flat
-gradient bucket, weighted by B_r/B.  Runs on CPU with the gloo backend, world_size 2 (and 3 with
-unequal shards); the per-rank gradients come from the oracle, the all-reduce / weighting logic is
-the product's Session.allreduce_grads.  RCCL itself only exists on the GPU box."""
+"""Data-parallel path: instances sharded over ranks, ONE all-reduce of the bucket
+[flat gradient | batch size, statistics], weighted by B_r/B.  Runs on CPU with the gloo backend, world_size 2
+(and 3 with unequal shards); the per-rank gradients and statistics come from the oracle, the bucket packing,
+the collective and the division by the reduced batch size are the product's Session.allreduce_grads
+(tensor ops only, so they run here).  The same logic with the HIP backward producing the gradients is covered
+on the GPU box by tests/test_gpu_dp.py; RCCL itself only exists there."""
 import os
 import socket
 
@@ -42,7 +44,7 @@ def _worker(rank, world, port, bounds, q):
     g = load_pack("ragged_B6", 0)
     params = P.init_params(d, seed=3, perturb=True)
     lo, hi = bounds[rank], bounds[rank + 1]
-    _, local = TO.loss_and_grads(params, _shard(g, lo, hi), T)
+    out, local = TO.loss_and_grads(params, _shard(g, lo, hi), T)
     model = tspgnn.build_network(d)
     sess = tspgnn.Session(model, device="cpu")          # plumbing only: no kernel is launched on CPU
     store = model.store
@@ -50,9 +52,16 @@ def _worker(rank, world, port, bounds, q):
     for name in store.names():
         # the oracle's gradient includes the L2 term, which the product adds AFTER the all-reduce
         store.grad_view(name).copy_(torch.from_numpy(local[name] - TO.L2NORM_SCALING * params[name]).float())
-    w = sess.allreduce_grads(hi - lo)
-    if rank == 0:
-        q.put((w, store.grad_dict()))
+    stats = torch.tensor([float(out[k]) for k in ("loss", "acc", "TP", "FP", "TN", "FN")], dtype=torch.float32)
+    assert sess.world_size == world
+    sess.allreduce_grads(hi - lo, stats)
+    theta0 = store.theta.clone()
+    if rank != 0:
+        store.theta.add_(1.0)          # a replica that drifted: the broadcast restores rank 0's variables
+    sess.broadcast_variables(0)
+    means = sess.allreduce_host_sums(np.array([float(hi - lo), 1.0]))
+    if rank == world - 1:
+        q.put((store.grad_dict(), stats.numpy().copy(), bool(torch.equal(store.theta, theta0)), means))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,14 +77,17 @@ def test_sharded_gradient_equals_global_batch_gradient(bounds):
     procs = [ctx.Process(target=_worker, args=(r, world, port, bounds, q)) for r in range(world)]
     for p in procs:
         p.start()
-    w0, got = q.get(timeout=180)
+    got, stats, same_theta, means = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     g = load_pack("ragged_B6", 0)
     params = P.init_params(32, seed=3, perturb=True)
-    _, ref = TO.loss_and_grads(params, _shard(g, 0, 6), 2)
-    assert abs(w0 - (bounds[1] - bounds[0]) / 6.0) < 1e-12
+    out, ref = TO.loss_and_grads(params, _shard(g, 0, 6), 2)
+    assert same_theta and means.tolist() == [6.0, float(world)]
+    # statistics of the GLOBAL batch (model.py:150-157): B-weighted means of loss / acc, sums of TP..FN
+    for i, k in enumerate(("loss", "acc", "TP", "FP", "TN", "FN")):
+        assert abs(stats[i] - float(out[k].detach())) < 2e-6, (k, stats[i])
     for k in ref:
         want = ref[k] - TO.L2NORM_SCALING * params[k]
         scale = max(np.abs(want).max(), 1e-12)
@@ -88,4 +100,23 @@ def test_allreduce_is_noop_without_process_group():
     sess = tspgnn.Session(model, device="cpu")
     model.store.zero_grad()
     model.store.grad.fill_(2.0)
-    assert sess.allreduce_grads(8) == 1.0 and float(model.store.grad[0]) == 2.0
+    stats = torch.arange(6, dtype=torch.float32)
+    sess.allreduce_grads(8, stats)
+    assert sess.world_size == 1 and float(model.store.grad[0]) == 2.0 and stats.tolist() == [0, 1, 2, 3, 4, 5]
+
+
+def test_cpu_session_is_plumbing_only():
+    """no CPU compute path -- a fetch on a device='cpu' session raises instead of running anything."""
+    import tspgnn
+    from conftest import load_pack as lp
+    model = tspgnn.build_network(32)
+    sess = tspgnn.Session(model, device="cpu")
+    sess.run(tspgnn.global_variables_initializer())
+    g = lp("n5_B2", 0)
+    feed = {model["EV"]: tspgnn.SparseEV(g["ev_uv"], int(g["n_vertices"].sum())), model["W"]: g["W"], model["C"]: g["C"],
+            model["time_steps"]: 1, model["route_exists"]: g["route_exists"], model["n_vertices"]: g["n_vertices"],
+            model["n_edges"]: g["n_edges"]}
+    with pytest.raises(RuntimeError, match="plumbing only"):
+        sess.run(model["predictions"], feed_dict=feed)
+    with pytest.raises(RuntimeError, match="plumbing only"):
+        sess.run(model["train_step"], feed_dict=feed)

@@ -86,6 +86,9 @@ extern "C" long long tspgnn_host_pack_batch(const void* const* Ma, const int* ma
         if (m < 0) return -1;
         double c = target_cost;
         if (!use_target) {
+            if (route_len[b] > 0 && !route[b]) return -1;
+            for (int k = 0; k < route_len[b]; ++k)  // the reference's Mw[x, y] raises IndexError here
+                if (route[b][k] < 0 || route[b][k] >= n[b]) return -2;
             const double cost = tspgnn_host_route_cost(Mw[b], n[b], route[b], route_len[b]);
             c = (b % 2 == 0) ? (1.0 - dev) * cost : (1.0 + dev) * cost;
         }
@@ -98,11 +101,14 @@ extern "C" long long tspgnn_host_pack_batch(const void* const* Ma, const int* ma
 
 // sum of Mw[min,max] over the pairs zip(route, route[1:] + route[1:]) divided by n -- including the
 // reference's closing-edge quirk (instance_loader.py:70): the last pair is (route[-1], route[1]).
+// A vertex id outside [0, n) yields NaN instead of an out-of-bounds read (the reference raises IndexError).
 extern "C" double tspgnn_host_route_cost(const double* Mw, int n, const int64_t* route, int len) {
     double s = 0.0;
+    if (!Mw || n <= 0 || (len > 0 && !route)) return __builtin_nan("");
     for (int k = 0; k < len; ++k) {
         const int64_t x = route[k];
         const int64_t y = (k + 1 < len) ? route[k + 1] : (len > 1 ? route[1] : route[0]);
+        if (x < 0 || x >= n || y < 0 || y >= n) return __builtin_nan("");
         const int64_t lo = x < y ? x : y, hi = x < y ? y : x;
         s += Mw[lo * n + hi];
     }
@@ -184,6 +190,7 @@ extern "C" int tspgnn_host_read_graph(const char* path, int* n_out, int* route_l
             char* end;
             const long v = strtol(p, &end, 10);
             if (end == p) break;
+            if (v < 0 || v >= n) return -7;  // a tour names vertices of this graph
             if (route) route[len] = v;
             ++len;
             p = end;

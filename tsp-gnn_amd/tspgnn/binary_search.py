@@ -13,11 +13,17 @@ from .instance_loader import InstanceLoader
 
 
 def cost_bounds(Mw, n):
-    """Loose bounds of the per-vertex tour cost: the n lightest / heaviest entries of the weight
-    matrix's triangles (binary_search.py:21-33)."""
-    wmin = np.minimum(np.sum(np.sort(np.triu(Mw).flatten())[:n]), np.sum(np.sort(np.tril(Mw).flatten())[:n]))
-    wmax = np.maximum(np.sum(np.sort(np.triu(Mw).flatten())[-n:]), np.sum(np.sort(np.tril(Mw).flatten())[-n:]))
-    return wmin / n, wmax / n
+    """Bracket of the per-vertex tour cost the search starts from, as the reference forms it
+    (experiments/binary_search.py:21-33): each triangle of the weight matrix is laid out as a full n x n array
+    (the other triangle zero-filled -- the zeros take part in the ranking, so for non-negative weights the lower
+    end of the bracket is 0), its n smallest and n largest entries are summed, and the looser of the two
+    triangles wins on either side.  Returned per vertex (divided by n)."""
+    lows, highs = [], []
+    for triangle in (np.triu(Mw), np.tril(Mw)):
+        ranked = np.sort(triangle, axis=None)
+        lows.append(ranked[:n].sum())
+        highs.append(ranked[ranked.size - n:].sum())
+    return min(lows) / n, max(highs) / n
 
 
 def get_cost(sess, model, instance, time_steps, threshold=0.5, stopping_delta=0.01, parallel=1):

@@ -15,6 +15,8 @@ form; it must be a 0/1 matrix with two ones per row, which is what create_batch 
 ``SparseEV`` that never materialises the dense matrix.
 """
 import math
+import threading
+import zlib
 
 import numpy as np
 import torch
@@ -155,7 +157,16 @@ class Session(object):
     """Executes fetches of a network built by build_network on one MI355X.
 
     ``Session(model=None, device='cuda:0')``: without ``model`` it binds to the most recently
-    built network (the TF default-graph behaviour train.py:202-206 relies on)."""
+    built network (the TF default-graph behaviour train.py:202-206 relies on).
+
+    There is no CPU compute path.  ``device='cpu'`` is accepted for PLUMBING ONLY -- the variable store, feed
+    validation and the data-parallel collectives (which is how the gloo tests exercise them without a GPU); every
+    fetch that would launch a kernel raises.
+
+    Data parallelism: when ``torch.distributed`` is initialised (or ``process_group`` is given) with
+    more than one rank, ``train_step`` all-reduces ONE bucket -- the flat gradient plus the batch statistics --
+    and the fetched loss / acc / TP / FP / TN / FN are those of the global batch; replicas are made identical by a
+    broadcast of the variables from rank 0 before the first training step."""
 
     def __init__(self, model=None, device=None, process_group=None):
         self.model = model if model is not None else build_network.last
@@ -169,9 +180,23 @@ class Session(object):
         self.store = self.model.store
         if not self.store.finalized:
             self.store.finalize(self.device)
-        self._adj_cache = (None, None)
+        self._adj_cache = threading.local()   # per thread: BatchPrefetcher prepares batches on a worker thread
         self._adam = None
         self.process_group = process_group
+        self._replicas_synced = False
+
+    @property
+    def world_size(self):
+        """Ranks of the data-parallel group (1 without an initialised torch.distributed)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.process_group)
+
+    def _require_gpu(self, what):
+        if self.device.type != "cuda":
+            raise RuntimeError("tspgnn.Session(device=%r) is plumbing only: %s launches HIP kernels and needs an MI355X; "
+                               "there is no CPU path" % (str(self.device), what))
 
     def __enter__(self):
         return self
@@ -190,20 +215,25 @@ class Session(object):
         return t.to(self.device)
 
     def _adjacency(self, EV):
+        """Device adjacency of a feed.  A ``DeviceAdjacency`` is used as is; a ``SparseEV`` is uploaded (CSR built)
+        and remembered under a fingerprint of its CONTENT -- shape + CRC of the endpoint array, ~0.3 ms at C2 --
+        so a caller that re-feeds the same edges (get_cost's probe loop) pays once while one that refills the
+        array in place gets the new graph, as TF re-reads every feed; a dense matrix is converted every time."""
         from .graphnn import DeviceAdjacency
-        key, cached = self._adj_cache
-        if key is EV:
-            return cached
         if isinstance(EV, DeviceAdjacency):
-            adj = EV
-        elif isinstance(EV, SparseEV):
-            adj = DeviceAdjacency.from_sparse_ev(EV, self.device)
-        else:
+            return EV
+        if not isinstance(EV, SparseEV):
             try:
-                adj = DeviceAdjacency.from_sparse_ev(SparseEV.fromdense(EV), self.device)
+                return DeviceAdjacency.from_sparse_ev(SparseEV.fromdense(EV), self.device)
             except ValueError as e:
                 raise ValueError("feed for model['EV']: %s" % e)
-        self._adj_cache = (EV, adj)
+        uv = np.ascontiguousarray(EV.uv)
+        key = (tuple(EV.shape), uv.shape, zlib.crc32(uv.view(np.uint8).reshape(-1)))
+        cache = self._adj_cache
+        if getattr(cache, "key", None) == key:
+            return cache.adj
+        adj = DeviceAdjacency.from_sparse_ev(EV, self.device)
+        cache.key, cache.adj = key, adj
         return adj
 
     # ------------------------------------------------------------------ forward
@@ -238,10 +268,16 @@ class Session(object):
         return b
 
     def forward(self, feed):
-        """Runs model.py:33-157 on the device; returns a dict of device tensors."""
-        return self.forward_device(feed if isinstance(feed, DeviceBatch) else self.prepare(feed))
+        """Runs model.py:33-157 on the device; returns a dict of device tensors.  In a data-parallel session the
+        statistics are reduced over the ranks (8 floats, one all-reduce); ``forward_device`` stays rank-local."""
+        b = feed if isinstance(feed, DeviceBatch) else self.prepare(feed)
+        out = self.forward_device(b)
+        if self.world_size > 1:
+            self._reduce_stats_only(out["stats"], b.B)
+        return out
 
     def forward_device(self, b):
+        self._require_gpu("a forward pass")
         m, d = self.model, self.model.d
         st = _lib.current_stream()
         E0 = m.edge_init_MLP(b.WC)                                            # model.py:43
@@ -294,6 +330,7 @@ class Session(object):
         for f in flist:
             if isinstance(f, _InitOp):
                 self.store.initialize(seed=f.seed)
+                self._reset_optimizer_slots()   # tf.global_variables_initializer also resets <var>/Adam, beta powers
         names = [f.name for f in flist if isinstance(f, Fetch) and not isinstance(f, _InitOp)]
         out = None
         if names:
@@ -329,6 +366,7 @@ class Session(object):
     def loss_and_grads(self, feed):
         """Forward + backward of ``loss`` (the L2 term is added by the optimiser kernel).  Leaves the
         gradient of the local mean loss in ``store.grad``; returns the forward outputs."""
+        self._require_gpu("a training step")
         m, d, st = self.model, self.model.d, _lib.current_stream()
         b = feed if isinstance(feed, DeviceBatch) else self.prepare(feed)
         store = self.store
@@ -384,19 +422,83 @@ class Session(object):
                       _lib.ptr(store.grad_view("V_init")), None, _lib.ptr(ws), st)
         return {"last_states": last, "E_vote": vote, "logits": logits, "predictions": pred, "stats": stats, "batch": b}
 
-    def allreduce_grads(self, local_batch):
-        """Data-parallel step: the loss is a mean over the GLOBAL batch, so each
-        rank's gradient of its local mean is weighted by B_r / B and summed with ONE all-reduce of the
-        flat gradient bucket (RCCL over xGMI when the backend is 'nccl').  No-op without a process group."""
+    # The data-parallel step.  The loss is a mean over the GLOBAL batch (model.py:157), so rank r's
+    # gradient of its local mean counts with weight B_r / B.  Everything that must cross ranks rides in ONE bucket:
+    #   bucket = [ B_r * grad_r | B_r, B_r*loss_r, B_r*acc_r, TP_r, FP_r, TN_r, FN_r, 0 ]     (VariableStore.bucket)
+    # one all-reduce(sum) of it (RCCL over xGMI with the 'nccl' backend; 462 KB at d=64), then every rank divides by the
+    # reduced B on the device: no host round trip, so the two HIP graphs of capture_train_step run back to back around
+    # the collective.  The L2 term, the clip by the GLOBAL norm and Adam follow on the reduced gradient, identically
+    # on every rank (model.py:163-167).  Tensor ops only (device-agnostic): the gloo tests run this on CPU.
+    def _pack_bucket(self, local_batch, stats, with_grad):
+        store = self.store
+        if store.grad is None:
+            store.zero_grad()
+        nb = float(local_batch)
+        tail = store.bucket[store.theta.numel():]
+        if with_grad:
+            store.grad.mul_(nb)
+        tail.zero_()
+        tail[0:1].fill_(nb)
+        if stats is not None:
+            tail[1:3].copy_(stats[0:2])
+            tail[1:3].mul_(nb)
+            tail[3:7].copy_(stats[2:6])
+        return tail
+
+    def _unpack_bucket(self, stats, with_grad):
+        store = self.store
+        tail = store.bucket[store.theta.numel():]
+        inv = torch.reciprocal(tail[0:1])
+        if with_grad:
+            store.grad.mul_(inv)
+        if stats is not None:
+            stats[0:2].copy_(tail[1:3] * inv)
+            stats[2:6].copy_(tail[3:7])
+
+    def allreduce_grads(self, local_batch, stats=None):
+        """One all-reduce of [gradient | batch size, statistics]; afterwards ``store.grad`` holds the gradient of
+        the global mean loss and ``stats`` (the 6-vector loss, acc, TP, FP, TN, FN of bce_metrics; optional) the
+        statistics of the global batch.  No-op with a single rank."""
+        if self.world_size == 1:
+            return
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.process_group) == 1:
-            return 1.0
-        tot = torch.tensor([float(local_batch)], dtype=torch.float64, device=self.store.grad.device)
-        dist.all_reduce(tot, group=self.process_group)
-        w = float(local_batch) / float(tot.item())
-        self.store.grad.mul_(w)
-        dist.all_reduce(self.store.grad, group=self.process_group)
-        return w
+        self._pack_bucket(local_batch, stats, True)
+        dist.all_reduce(self.store.bucket, group=self.process_group)
+        self._unpack_bucket(stats, True)
+
+    def _reduce_stats_only(self, stats, local_batch):
+        import torch.distributed as dist
+        tail = self._pack_bucket(local_batch, stats, False)
+        dist.all_reduce(tail, group=self.process_group)
+        self._unpack_bucket(stats, False)
+
+    def allreduce_host_sums(self, values):
+        """Sum of a small float64 host vector over the ranks (run_batch's label / prediction means)."""
+        v = np.asarray(values, dtype=np.float64)
+        if self.world_size == 1:
+            return v
+        import torch.distributed as dist
+        t = torch.from_numpy(v.copy()).to(self.device)
+        dist.all_reduce(t, group=self.process_group)
+        return t.cpu().numpy()
+
+    def broadcast_variables(self, src=0):
+        """Replicas start identical: theta (and the optimiser slots, if any) from rank ``src`` to every rank."""
+        if self.world_size == 1:
+            return
+        import torch.distributed as dist
+        group_src = src if self.process_group is None else dist.get_global_rank(self.process_group, src)
+        dist.broadcast(self.store.theta, src=group_src, group=self.process_group)
+        if self._adam is not None:
+            for k in ("m", "v", "t"):
+                dist.broadcast(self._adam[k], src=group_src, group=self.process_group)
+        self.store.touch()
+        self._replicas_synced = True
+
+    def _sync_replicas_once(self):
+        if not self._replicas_synced:
+            self.broadcast_variables(0)
+            self._replicas_synced = True
 
     def apply_gradients(self):
         """g += 1e-10*theta; clip_by_global_norm(0.65); Adam(lr=2e-5) -- one fused pass over theta."""
@@ -419,10 +521,19 @@ class Session(object):
                           "t": torch.zeros(1, dtype=torch.int32, device=self.device),
                           "ws": _lib.workspace("tspgnn_adam_workspace_floats", device=self.device)}
 
+    def _reset_optimizer_slots(self):
+        """Adam's m, v and step counter back to zero, in place (captured graphs keep pointing at the same tensors)."""
+        if self._adam is not None:
+            for k in ("m", "v", "t", "gnorm"):
+                self._adam[k].zero_()
+            self._adam["step"] = 0
+        self._replicas_synced = False
+
     def train_step(self, feed):
         """One ``sess.run(train_step)``: forward, backward, (all-reduce), L2 + clip + Adam."""
+        self._sync_replicas_once()
         out = self.loss_and_grads(feed)
-        self.allreduce_grads(out["batch"].B)
+        self.allreduce_grads(out["batch"].B, out["stats"])
         out["global_norm"] = self.apply_gradients()
         return out
 
@@ -433,6 +544,7 @@ class Session(object):
         launches per step stop costing host time.  Returns ``replay() -> outputs``."""
         b = batch if isinstance(batch, DeviceBatch) else self.prepare(batch)
         self._ensure_adam()
+        self._sync_replicas_once()
         self.loss_and_grads(b)                # warm-up outside the capture (allocator, caches)
         torch.cuda.synchronize()
         side = torch.cuda.Stream(device=self.device)
@@ -447,7 +559,7 @@ class Session(object):
 
         def replay():
             ga.replay()
-            self.allreduce_grads(b.B)
+            self.allreduce_grads(b.B, out["stats"])   # device-side only: no host sync between the two graphs
             gb.replay()
             self._adam["step"] += 1
             self.store.touch()

@@ -1,30 +1,71 @@
-"""The reference's per-batch driver (/root/reference/train.py:17-80) on the MI355X path: same arguments, same
-fetch list, same printed line, same 8-tuple -- a training script written against the reference keeps working
-with ``from tspgnn.train import run_batch, summarize_epoch``."""
+"""Per-batch driver of the MI355X path with the calling contract of the reference's ``run_batch`` /
+``summarize_epoch`` (/root/reference/train.py:17-76): same argument lists, and ``run_batch`` returns the
+8-tuple ``(loss, acc, mean label, mean prediction, TP, FP, TN, FN)`` a training script written against the
+reference unpacks.  Everything else -- how the feed is assembled, what is logged and how -- is this
+package's own.
+
+In a data-parallel session (``Session(..., process_group=...)``) the statistics that come back are the ones
+of the GLOBAL batch (``Session`` reduces them across ranks); the label / prediction means of
+the tuple are reduced here the same way, so every rank returns identical numbers.
+"""
+import sys
+
 import numpy as np
+
+_FEED_ORDER = ("EV", "W", "C", "route_exists", "n_vertices", "n_edges")
+_STAT_KEYS = ("loss", "acc", "predictions", "TP", "FP", "TN", "FN")
+
+
+def _feed_for(model, batch, time_steps):
+    """feed_dict of one ``InstanceLoader`` batch (a 6-tuple in ``_FEED_ORDER``)."""
+    if len(batch) != len(_FEED_ORDER):
+        raise ValueError("run_batch: a batch is the 6-tuple (%s), got %d items" % (", ".join(_FEED_ORDER), len(batch)))
+    feed = {model[key]: value for key, value in zip(_FEED_ORDER, batch)}
+    feed[model["time_steps"]] = time_steps
+    return feed
+
+
+def _batch_means(sess, labels, predictions):
+    """(mean label, mean prediction): of this batch, or -- in a data-parallel session -- of the global batch
+    (local sums and counts summed over the session's process group)."""
+    if getattr(sess, "world_size", 1) <= 1:
+        return np.mean(labels), np.mean(predictions)
+    sums = sess.allreduce_host_sums(np.array(
+        [np.sum(labels, dtype=np.float64), np.sum(predictions, dtype=np.float64), float(len(labels))]))
+    count = max(sums[2], 1.0)
+    return sums[0] / count, sums[1] / count
+
+
+def _log(kind, epoch_i, fields):
+    sys.stdout.write("[%s] epoch %d  %s\n" % (kind, epoch_i, "  ".join("%s=%s" % kv for kv in fields)))
+    sys.stdout.flush()
 
 
 def run_batch(sess, model, batch, batch_i, epoch_i, time_steps, train=False, verbose=True):
-    EV, W, C, route_exists, n_vertices, n_edges = batch
-    feed_dict = {
-        model['EV']: EV, model['W']: W, model['C']: C, model['time_steps']: time_steps,
-        model['route_exists']: route_exists, model['n_vertices']: n_vertices, model['n_edges']: n_edges,
-    }
-    outputs = [model['loss'], model['acc'], model['predictions'], model['TP'], model['FP'], model['TN'], model['FN']]
+    """One ``sess.run`` over ``batch``; with ``train`` the optimiser step is fetched first (train.py:36-42)."""
+    fetches = [model[key] for key in _STAT_KEYS]
     if train:
-        outputs = [model['train_step']] + outputs
-    loss, acc, predictions, TP, FP, TN, FN = sess.run(outputs, feed_dict=feed_dict)[-7:]
+        fetches.insert(0, model["train_step"])
+    values = sess.run(fetches, feed_dict=_feed_for(model, batch, time_steps))
+    stats = dict(zip(_STAT_KEYS, values[len(values) - len(_STAT_KEYS):]))
+    labels, n_vertices, n_edges = batch[3], batch[4], batch[5]
+    mean_label, mean_pred = _batch_means(sess, labels, stats["predictions"])
     if verbose:
-        print('{train_or_test} Epoch {epoch_i} Batch {batch_i}\t|\t(n,m,batch size)=({n},{m},{batch_size})\t|\t'
-              '(Loss,Acc)=({loss:.4f},{acc:.4f})\t|\tAvg. (Sat,Prediction)=({avg_sat:.4f},{avg_pred:.4f})'.format(
-                  train_or_test='Train' if train else 'Test', epoch_i=epoch_i, batch_i=batch_i, loss=loss, acc=acc,
-                  n=np.sum(n_vertices), m=np.sum(n_edges), batch_size=n_vertices.shape[0],
-                  avg_sat=np.mean(route_exists), avg_pred=np.mean(np.round(predictions))), flush=True)
-    return loss, acc, np.mean(route_exists), np.mean(predictions), TP, FP, TN, FN
+        _log("train" if train else "test", epoch_i, (
+            ("batch", batch_i),
+            ("vertices", int(np.sum(n_vertices))), ("edges", int(np.sum(n_edges))), ("graphs", len(n_vertices)),
+            ("loss", "%.4f" % stats["loss"]), ("acc", "%.4f" % stats["acc"]),
+            ("label_mean", "%.4f" % mean_label),
+            ("decided_yes", "%.4f" % float(np.mean(np.round(stats["predictions"])))),
+        ))
+    return (stats["loss"], stats["acc"], mean_label, mean_pred,
+            stats["TP"], stats["FP"], stats["TN"], stats["FN"])
 
 
 def summarize_epoch(epoch_i, loss, acc, sat, pred, train=False):
-    print('{train_or_test} Epoch {epoch_i} Average\t|\t(Loss,Acc)=({loss:.4f},{acc:.4f})\t|\t'
-          'Avg. (Sat,Pred)=({avg_sat:.4f},{avg_pred:.4f})'.format(
-              train_or_test='Train' if train else 'Test', epoch_i=epoch_i, loss=np.mean(loss), acc=np.mean(acc),
-              avg_sat=np.mean(sat), avg_pred=np.mean(pred)), flush=True)
+    """Epoch line: the means of the per-batch values ``run_batch`` returned (train.py:66-76)."""
+    _log("train" if train else "test", epoch_i, (
+        ("batches", len(loss)),
+        ("loss", "%.4f" % float(np.mean(loss))), ("acc", "%.4f" % float(np.mean(acc))),
+        ("label_mean", "%.4f" % float(np.mean(sat))), ("pred_mean", "%.4f" % float(np.mean(pred))),
+    ))

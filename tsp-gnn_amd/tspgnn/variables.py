@@ -124,11 +124,16 @@ class VariableStore(object):
         return self._offsets[name][0]
 
     # -- gradients (same flat layout as theta: one buffer to all-reduce, clip and apply) ----
+    # ``bucket`` = [grad (theta's layout) | BUCKET_TAIL floats]: the data-parallel step appends the local batch size
+    # and the batch statistics to the gradient so that ONE all-reduce carries everything (Session.allreduce_grads).
+    BUCKET_TAIL = 8
+
     def zero_grad(self):
         if self.grad is None:
-            self.grad = torch.zeros_like(self.theta)
+            self.bucket = torch.zeros(self.theta.numel() + self.BUCKET_TAIL, dtype=torch.float32, device=self.theta.device)
+            self.grad = self.bucket[:self.theta.numel()]
         else:
-            self.grad.zero_()
+            self.bucket.zero_()
         return self.grad
 
     def grad_view(self, name):
