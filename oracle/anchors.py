@@ -1,0 +1,39 @@
+"""Inputs of the full-size float64 anchors (TEST INFRASTRUCTURE): which batch and which weights
+``tests/golden/anchor_*.npz`` were computed on, and which rows of the state arrays they keep.  Shared by the
+generator (oracle/gen_golden.py, build container) and the GPU test that replays them (tests/test_gpu_anchors.py);
+touches nothing outside the repository."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+ANCHORS = {
+    # name: (sizes, T)  -- BASELINE.json configs[0], [1], [3]
+    "c1": (lambda: [20] * 32, 8),
+    "c2": (lambda: [40] * 128, 32),
+    "c4": (lambda: [int(x) for x in np.random.RandomState(0).randint(20, 81, size=512)], 2),
+}
+ANCHOR_ROWS = 512
+
+
+def anchor_inputs(name):
+    """The batch and the weights an anchor was computed on (also called by tests/test_gpu_anchors.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tsp-gnn_amd"))
+    import tspgnn
+    from oracle import params as P
+    import zlib
+    sizes, T = ANCHORS[name]
+    batch = tspgnn.synthetic_batch(sizes(), seed=1234)
+    params = P.init_params(64, seed=0)
+    EV, W, C = batch[0], batch[1], batch[2]
+    finger = np.array([float(EV.shape[0]), float(EV.shape[1]), float(zlib.crc32(np.ascontiguousarray(EV.uv).view(np.uint8).reshape(-1))),
+                       float(np.sum(W, dtype=np.float64)), float(np.sum(C, dtype=np.float64)),
+                       float(sum(np.sum(np.asarray(v, dtype=np.float64)) for v in params.values())),
+                       float(sum(np.sum(np.abs(np.asarray(v, dtype=np.float64))) for v in params.values()))])
+    return batch, params, T, finger
+
+
+def anchor_rows(n_rows):
+    return np.unique(np.linspace(0, n_rows - 1, ANCHOR_ROWS).astype(np.int64))

@@ -12,7 +12,16 @@
    those batches: regression anchors for the oracle itself (it has no reference vectors to
    pin against -- "parity unpinned", see oracle/__init__.py).
 
-Usage:  python oracle/gen_golden.py
+3. ``anchor_*.npz`` -- float64 oracle outputs at the FULL size of BASELINE.json's configs 0, 1 and 3 (C1: n=20,
+   B=32, T=8; C2: n=40, B=128, T=32; C4: ragged n in 20..80, B=512, T=2) for ``init_params(64, seed=0)`` on
+   ``tspgnn.synthetic_batch`` inputs: predictions, logits, loss, and for each of E.h, E.c, V.h, V.c the column sums
+   and 512 evenly spaced rows -- so that the GPU suite checks full-size parity in seconds without running the
+   oracle there (tests/test_gpu_anchors.py).  Input fingerprints are stored next to them: the test first checks
+   that it regenerated the same batch and the same weights.
+4. ``graph_*.npz`` -- ``.graph`` instance files (text) together with what the REFERENCE's own ``read_graph``
+   (/root/reference/instance_loader.py:95-127, imported here) parses out of them: pins the native reader.
+
+Usage:  python oracle/gen_golden.py [pack] [oracle] [anchors] [graph]      (default: all)
 """
 import os
 import sys
@@ -104,7 +113,75 @@ def gen_oracle():
         print("oracle", name, d, T, "loss", data["loss"])
 
 
+from oracle.anchors import ANCHORS, anchor_inputs, anchor_rows  # noqa: E402
+
+
+def gen_anchors():
+    import time
+    import torch
+    from oracle import torch_oracle as TO
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    for name in ANCHORS:
+        batch, params, T, finger = anchor_inputs(name)
+        EV, W, C, route_exists, n_vertices, n_edges = batch
+        ob = {"ev_uv": EV.uv, "W": W, "C": C, "route_exists": route_exists, "n_vertices": n_vertices, "n_edges": n_edges}
+        t0 = time.time()
+        with torch.no_grad():
+            ref = TO.forward(TO.to_torch(params, torch.float64), ob, T)
+        data = {"T": np.int64(T), "d": np.int64(64), "fingerprint": finger,
+                "predictions": ref["predictions"].numpy(), "logits": ref["logits"].numpy(),
+                "loss": np.float64(ref["loss"].item()), "acc": np.float64(ref["acc"].item())}
+        for var in ("E", "V"):
+            for k, part in enumerate(("h", "c")):
+                a = ref["last_states"][var][k].numpy()
+                rows = anchor_rows(a.shape[0])
+                data["%s%s_rows" % (var, part)] = a[rows]
+                data["%s%s_colsum" % (var, part)] = a.sum(0)
+                data["%s%s_absmax" % (var, part)] = np.float64(np.abs(a).max())
+        np.savez_compressed(os.path.join(OUT, "anchor_%s.npz" % name), **data)
+        print("anchor", name, "T", T, "M", EV.shape[0], "loss %.9f" % data["loss"], "%.1f s" % (time.time() - t0))
+
+
+def gen_graph():
+    """.graph texts parsed by the reference's read_graph.  The texts are written by this repository's writer
+    (tspgnn.write_graph: float weights, and dataset.py's integer-binned variant) plus one laid out by hand with the
+    format's freedoms: blank-separated header variants, a sparse graph, trailing blanks."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tsp-gnn_amd"))
+    import tspgnn
+    from instance_loader import read_graph  # the reference's parser
+
+    rng = np.random.RandomState(42)
+    texts = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, n, conn, int_w in (("full_n7", 7, 1.0, False), ("sparse_n12", 12, 0.35, False), ("binned_n6", 6, 1.0, True)):
+            Ma, Mw, route = make_instance(n, rng, conn)
+            path = os.path.join(tmp, name + ".graph")
+            tspgnn.write_graph(Ma, Mw, path, route=route, int_weights=int_w)
+            texts[name] = open(path).read()
+        texts["hand_n4"] = ("NAME : hand\nTYPE : TSP\nCOMMENT: laid out by hand\nDIMENSION: 4\nEDGE_DATA_FORMAT: EDGE_LIST\n"
+                            "EDGE_WEIGHT_TYPE: EXPLICIT\nEDGE_WEIGHT_FORMAT: FULL_MATRIX \nEDGE_DATA_SECTION:\n0 1\n0 3\n1 2\n"
+                            "2 3\n-1\nEDGE_WEIGHT_SECTION:\n0 0.5 0 0.25 \n0 0 1.5 0 \n0 0 0 2 \n0 0 0 0 \nTOUR_SECTION:\n"
+                            "0 1 2 3 \nEOF\n")
+        for name, text in texts.items():
+            path = os.path.join(tmp, name + ".graph")
+            with open(path, "w") as f:
+                f.write(text)
+            Ma, Mw, route = read_graph(path)
+            np.savez_compressed(os.path.join(OUT, "graph_%s.npz" % name), text=np.array(text), Ma=Ma, Mw=Mw,
+                                route=np.array(route, dtype=np.int64))
+            print("graph", name, Ma.shape, int(Ma.sum()), "edges, tour", route)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_pack()
-    gen_oracle()
+    what = sys.argv[1:] or ["pack", "oracle", "anchors", "graph"]
+    if "pack" in what:
+        gen_pack()
+    if "oracle" in what:
+        gen_oracle()
+    if "anchors" in what:
+        gen_anchors()
+    if "graph" in what:
+        gen_graph()

@@ -40,11 +40,13 @@ def layer_norm(x, gamma, beta):
     return x * inv + (beta - mean * inv)
 
 
-def lnlstm(x, h, c, K, ln, z0=None):
+def lnlstm(x, h, c, K, ln, z0=None, activation=relu):
     """LayerNormBasicLSTMCell.call as used at graphnn.py:168-170.
     ln: dict gate -> (gamma, beta) for gates input/transform/forget/output/state.
     z0: optional pre-activation offset (the part of [x,h] K a caller has already formed, e.g. an
-    aggregation pushed through Kx); None for the plain cell."""
+    aggregation pushed through Kx); None for the plain cell.
+    activation: the cell's constructor argument (relu on the hot path, graphnn.py:110; tanh is TF's default and
+    what TensorFlow's own unit test of the cell uses)."""
     d = h.shape[1]
     z = np.concatenate([x, h], axis=1) @ K
     if z0 is not None:
@@ -54,9 +56,9 @@ def lnlstm(x, h, c, K, ln, z0=None):
     j = layer_norm(j, *ln["transform"])
     f = layer_norm(f, *ln["forget"])
     o = layer_norm(o, *ln["output"])
-    new_c = c * sigmoid(f + x.dtype.type(FORGET_BIAS)) + sigmoid(i) * relu(j)
+    new_c = c * sigmoid(f + x.dtype.type(FORGET_BIAS)) + sigmoid(i) * activation(j)
     new_c = layer_norm(new_c, *ln["state"])
-    new_h = relu(new_c) * sigmoid(o)
+    new_h = activation(new_c) * sigmoid(o)
     return new_h, new_c
 
 

@@ -64,21 +64,24 @@ def layer_norm(x, gamma, beta):
     return x * inv + (beta - mean * inv)
 
 
-def lnlstm_cell(x, h, c, params, cell):
+def lnlstm_cell(x, h, c, params, cell, activation=torch.relu, base=None):
     """tf.contrib.rnn.LayerNormBasicLSTMCell.call with activation=relu (graphnn.py:110,168-170).
     args = concat([inputs, h]); no bias; gates i,j,f,o; forget bias added after LN;
-    the *normalised* new_c is both stored and fed to the output."""
-    base = "TSP/%s_cell/layer_norm_basic_lstm_cell" % cell
+    the *normalised* new_c is both stored and fed to the output.
+    ``activation`` (the cell's own constructor argument; the hot path always passes relu) exists so that the
+    cell can be checked against the one vector TensorFlow itself publishes for it, which uses the default tanh
+    (tests/test_oracle.py::test_lnlstm_cell_reproduces_tensorflow_unit_test_constants)."""
+    base = base if base is not None else "TSP/%s_cell/layer_norm_basic_lstm_cell" % cell
     z = torch.cat([x, h], dim=1) @ params[base + "/kernel"]
     i, j, f, o = torch.chunk(z, 4, dim=1)
     i = layer_norm(i, params[base + "/input/gamma"], params[base + "/input/beta"])
     j = layer_norm(j, params[base + "/transform/gamma"], params[base + "/transform/beta"])
     f = layer_norm(f, params[base + "/forget/gamma"], params[base + "/forget/beta"])
     o = layer_norm(o, params[base + "/output/gamma"], params[base + "/output/beta"])
-    g = torch.relu(j)
+    g = activation(j)
     new_c = c * torch.sigmoid(f + FORGET_BIAS) + torch.sigmoid(i) * g
     new_c = layer_norm(new_c, params[base + "/state/gamma"], params[base + "/state/beta"])
-    new_h = torch.relu(new_c) * torch.sigmoid(o)
+    new_h = activation(new_c) * torch.sigmoid(o)
     return new_h, new_c
 
 

@@ -291,6 +291,20 @@ def test_adam_clip_step(cuda_device):
     torch.cuda.synchronize()
     assert int(cnt.item()) == step
     assert np.abs(td2.cpu().numpy() - p["a"]).max() < 2e-6 * np.abs(p["a"]).max()
+    # The UPDATE itself, on exact inputs: with |theta| ~ 1e-3 one ulp of theta (1e-10) is far below the Adam step
+    # (<= lr = 2e-5), so theta' - theta exposes the kernel's arithmetic: every element's movement within 1e-5 of the
+    # largest movement (the model-level training tests cannot be this tight: there the gradients differ in rounding).
+    small = (1e-3 * theta).astype(np.float32)
+    td3, gd3, md3, vd3 = (dev(a, cuda_device) for a in (small, g, m, v))
+    _lib.call("tspgnn_adam_clip_step_f32", _lib.ptr(td3), _lib.ptr(gd3), _lib.ptr(md3), _lib.ptr(vd3), n, TO.L2NORM_SCALING, TO.CLIP_NORM,
+              float(lr_t), TO.ADAM_B1, TO.ADAM_B2, TO.ADAM_EPS, _lib.ptr(gn), _lib.ptr(wsz), None, None)
+    torch.cuda.synchronize()
+    g64 = g.astype(np.float64) + TO.L2NORM_SCALING * small
+    clipped, _ = TO.clip_by_global_norm({"a": g64})
+    p3, _, _ = TO.adam_step({"a": small.astype(np.float64)}, clipped, {"a": m.astype(np.float64)}, {"a": v.astype(np.float64)}, step)
+    moved_ref = p3["a"] - small.astype(np.float64)
+    moved = td3.cpu().numpy().astype(np.float64) - small.astype(np.float64)
+    assert np.abs(moved - moved_ref).max() < 1e-5 * np.abs(moved_ref).max()
 
 
 @pytest.mark.parametrize("d,rows,n_src", [(64, 700, 41), (32, 33, 9)])

@@ -161,3 +161,35 @@ def test_clip_and_adam_formulas():
     p, m, v = TO.adam_step({"a": np.zeros(2)}, {"a": np.array([1.0, -2.0])}, {"a": np.zeros(2)}, {"a": np.zeros(2)}, 1)
     # first Adam step moves by ~lr*sign(g)
     assert np.allclose(p["a"], [-2e-5, 2e-5], rtol=1e-6)
+
+
+def test_lnlstm_cell_reproduces_tensorflow_unit_test_constants():
+    """The one externally published vector for tf.contrib.rnn.LayerNormBasicLSTMCell: TensorFlow 1.x's own unit test
+    (tensorflow/contrib/rnn/python/kernel_tests/rnn_cell_test.py, LayerNormBasicLSTMCellTest.testBasicLSTMCell) runs
+    two stacked 2-unit cells (default tanh activation) with every kernel entry 0.5 (scope initialiser
+    constant_initializer(0.5); gamma = 1, beta = 0 keep their own initialisers), x = [[1, 1]],
+    (c0, h0, c1, h1) = 0.1 * ([0, 1], [2, 3], [4, 5], [6, 7]) and expects
+        h = state_h = [[-0.38079708, 0.38079708]],  state_c = [[-1, 1]]   for BOTH layers.
+    With a constant kernel the two units of every gate get the same pre-activation, so all four gate LayerNorms give
+    0, c' = LN(c * sigmoid(0 + forget_bias 1.0)) = -/+1 and h' = tanh(-/+1) * sigmoid(0).  Both oracle cells (torch
+    and NumPy restatement) must reproduce the constants; it pins the gate order's irrelevance here but, more to the
+    point, the forget bias placement, LN-of-the-state-before-the-output, and the epsilon."""
+    want_h = np.array([[-0.38079708, 0.38079708]])
+    want_c = np.array([[-1.0, 1.0]])
+    ones, zeros = np.ones(2), np.zeros(2)
+    base = "root/cell"
+    params = {base + "/kernel": np.full((4, 8), 0.5)}
+    for g in ("input", "transform", "forget", "output", "state"):
+        params[base + "/%s/gamma" % g], params[base + "/%s/beta" % g] = ones, zeros
+    tp = TO.to_torch(params, torch.float64)
+    ln = {g: (ones, zeros) for g in ("input", "transform", "forget", "output", "state")}
+    x = np.array([[1.0, 1.0]])
+    states = [(0.1 * np.array([[0.0, 1.0]]), 0.1 * np.array([[2.0, 3.0]])),
+              (0.1 * np.array([[4.0, 5.0]]), 0.1 * np.array([[6.0, 7.0]]))]
+    inp_t, inp_n = torch.tensor(x), x
+    for c, h in states:                           # MultiRNNCell: layer k feeds its h to layer k+1
+        h_t, c_t = TO.lnlstm_cell(inp_t, torch.tensor(h), torch.tensor(c), tp, None, activation=torch.tanh, base=base)
+        h_n, c_n = NO.lnlstm(inp_n, h, c, params[base + "/kernel"], ln, activation=np.tanh)
+        for got_h, got_c in ((h_t.numpy(), c_t.numpy()), (h_n, c_n)):
+            assert np.abs(got_h - want_h).max() < 5e-9 and np.abs(got_c - want_c).max() < 5e-9
+        inp_t, inp_n = h_t, h_n
