@@ -174,6 +174,27 @@ typedef struct tspgnn_cell_mlp_task {
 } tspgnn_cell_mlp_task;
 int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream);
 
+/*
+ * The same three launches on the fp16 matrix cores with fp32-class accuracy ("f16x2": every fp32 operand is split
+ * into two fp16 pieces hi + lo = x to 2^-24 relative, three piece products accumulate in fp32; see
+ * csrc/dense_h2.hip) -- half the matrix instructions and less than half the split arithmetic of bf16x3; the
+ * default arithmetic of the inference forward.  d in {32, 64}.  Operands as for the _x3 functions, except:
+ *   tspgnn_pack_weights_h2: W:[krows,ncols] -> P: 2*krows*ncols fp16, piece-major, the pieces of 2^s * W with
+ *     s = TSPGNN_H2_WEIGHT_SCALE_LOG2 (keeps the lo piece of a typical weight out of the fp16 subnormals;
+ *     |W| < 2^10 required);
+ *   mlp task:  wb = n_layers blocks of { packed[2*d*d] fp16, 2^s * bias[d] float }; Y comes back unscaled;
+ *              proj_out = 2^s * (Y P): it only ever feeds the z of an f16x2 cell (Zx of gather-init mode);
+ *   lstm task: K packed [dx+d, 4d]; Zx as written by an f16x2 projection (scaled by 2^s); zbias unscaled.
+ *     The cell normalises the scaled z with epsilon 2^2s * 1e-12, which reproduces the gates of the unscaled z
+ *     bit for bit (power-of-two scaling commutes with rounding).
+ */
+#define TSPGNN_H2_WEIGHT_SCALE_LOG2 6
+float tspgnn_h2_weight_scale(void);   /* 2^TSPGNN_H2_WEIGHT_SCALE_LOG2 */
+int tspgnn_pack_weights_h2(const float* W, void* P, int krows, int ncols, void* stream);
+int tspgnn_mlp_fwd_multi_h2(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream);
+int tspgnn_lnlstm_fwd_multi_h2(const tspgnn_lstm_task* tasks, int n_tasks, int d, void* stream);
+int tspgnn_lnlstm_mlp_fwd_multi_h2(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream);
+
 /* ------------------------------------------------------------------ bf16 storage, fp32 accumulate
  *
  * BASELINE config 5 ("bf16 embeddings with fp32 accumulate"): the same forward operators with

@@ -56,7 +56,7 @@ def run_case(idx, case, with_grads, strict=True):
     batch = {"ev_uv": t[0].uv, "W": t[1], "C": t[2], "route_exists": t[3], "n_vertices": t[4], "n_edges": t[5]}
     ref = TO.forward(TO.to_torch(params, torch.float64), batch, T)
     errs = {}
-    for gemm in ("bf16x3", "f32"):
+    for gemm in ("f16x2", "bf16x3", "f32"):
         model = tspgnn.build_network(d)
         model["gnn"].gemm = gemm
         sess = tspgnn.Session(model)
@@ -69,7 +69,7 @@ def run_case(idx, case, with_grads, strict=True):
         errs[gemm] = e
         assert e < REL_TOL, ("forward", gemm, case, e)
         assert abs(float(loss) - ref["loss"].item()) < REL_TOL, ("loss", gemm, case)
-        if gemm == "bf16x3" and with_grads:
+        if gemm == "f16x2" and with_grads:
             _, ref_g = TO.loss_and_grads(params, batch, T, dtype=torch.float64)
             _, f32_g = TO.loss_and_grads(params, batch, T, dtype=torch.float32, dense=True)
             l2 = {k: TO.L2NORM_SCALING * params[k] for k in params}

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 REL_TOL = 1e-5
 
 
-@pytest.mark.parametrize("gemm", ["default", "f32"])
+@pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "f32"])
 @pytest.mark.parametrize("name", ["c1", "c2", "c4"])
 def test_full_size_forward_matches_float64_anchor(cuda_device, name, gemm):
     import tspgnn
@@ -24,8 +24,7 @@ def test_full_size_forward_matches_float64_anchor(cuda_device, name, gemm):
     assert T == int(z["T"]) and np.array_equal(finger, z["fingerprint"]), "inputs differ from the anchor's"
     EV, W, C, route_exists, n_vertices, n_edges = batch
     model = tspgnn.build_network(64)
-    if gemm != "default":
-        model["gnn"].gemm = gemm
+    model["gnn"].gemm = gemm
     sess = tspgnn.Session(model)
     sess.run(tspgnn.global_variables_initializer())
     model.store.load(params)

@@ -39,10 +39,11 @@ def pack_tuple(name, seed=0, dense=False):
 
 @pytest.mark.parametrize("name,d,T", [("n5_B2", 32, 3), ("ragged_B6", 64, 4), ("sparse_B4", 64, 8),
                                       ("n20_B32", 64, 8), ("target_B4", 32, 2), ("n20_B32", 128, 2)])
-@pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
+@pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "f32"])
 def test_forward_parity_with_oracle(cuda_device, name, d, T, gemm):
-    """Both GEMM arithmetics of the inference forward (bf16 matrix cores on exact 3-way splits / fp32 MFMA)
-    meet the same 1e-5 budget; d=128 has no bf16x3 kernel and runs fp32 either way."""
+    """Every GEMM arithmetic of the inference forward (fp16 matrix cores on 2-way splits -- the default --, bf16
+    matrix cores on exact 3-way splits, fp32 MFMA) meets the same 1e-5 budget; d=128 has no split-operand kernel
+    and runs fp32 either way."""
     t = pack_tuple(name)
     params = P.init_params(d, seed=11, perturb=True)
     hip = run_hip(d, params, t, T, gemm=gemm)
@@ -426,7 +427,7 @@ def test_save_and_load_weights_roundtrip_with_optimizer_state(cuda_device, tmp_p
     model.store.load(params)
     for i in range(2):
         run_batch(sess, model, t, i, 0, 3, train=True, verbose=(i == 0))
-    assert "Train Epoch 0 Batch 0" in capsys.readouterr().out
+    assert "[train] epoch 0  batch=0" in capsys.readouterr().out
     path = str(tmp_path / "checkpoints" / "epoch=7")
     tspgnn.save_weights(sess, path)
     names = set(tspgnn.tf_checkpoint.read_bundle(path + "/model.ckpt"))
@@ -569,7 +570,7 @@ def test_random_shapes_parity(cuda_device):
         fuzz_parity.run_case(i, fuzz_parity.draw_case(rng), with_grads=(i % 3 == 0))
 
 
-@pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
+@pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "f32"])
 def test_edge_order_within_a_problem_is_free(cuda_device, gemm):
     """The reference orders a problem's edges as np.nonzero walks the upper triangle (instance_loader.py:60-66); the
     kernels must not depend on it: edges shuffled within each problem (and the endpoints of half of them swapped)

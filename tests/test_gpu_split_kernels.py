@@ -1,6 +1,10 @@
-"""bf16x3 (fp32-accurate, bf16 matrix cores) dense kernels vs the float64 numpy oracle, through the C ABI.
+"""The split-operand (fp32-accurate) dense kernels vs the float64 numpy oracle, through the C ABI, for both
+arithmetics: "h2" = two fp16 pieces per operand on the fp16 matrix cores (csrc/dense_h2.hip, the default of the
+inference forward) and "x3" = three bf16 pieces on the bf16 matrix cores (csrc/dense_x3.hip).
 
-The tolerance is the same as for the fp32 kernels: the split keeps every term down to 2^-24 relative."""
+The tolerance is the same as for the fp32 kernels: both splits keep every term down to 2^-24 relative.  The f16x2
+conventions the tests honour: weights packed as 2^s W, Dense biases stored as 2^s b, projected messages (proj_out /
+Zx) carrying the factor 2^s."""
 import numpy as np
 import pytest
 import torch
@@ -27,13 +31,26 @@ def _release_uploads():
     del _KEEP[:]
 
 
-def packed_x3(W, device):
-    """tspgnn_pack_weights_x3 -> uint8 tensor of 3*krows*ncols*2 bytes."""
+ARITHS = ["h2", "x3"]
+PIECES = {"x3": 3, "h2": 2}
+
+
+def zscale(arith):
+    """Factor carried by the weights / the z of a cell / the projected messages of this arithmetic."""
+    return float(_lib.lib.tspgnn_h2_weight_scale()) if arith == "h2" else 1.0
+
+
+def packed(arith, W, device):
+    """tspgnn_pack_weights_{x3,h2} -> uint8 tensor of pieces*krows*ncols*2 bytes."""
     src = dev(W, device)
-    out = torch.empty(3 * W.size * 2, dtype=torch.uint8, device=device)
+    out = torch.empty(PIECES[arith] * W.size * 2, dtype=torch.uint8, device=device)
     _KEEP.append(out)
-    _lib.call("tspgnn_pack_weights_x3", _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], None)
+    _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], None)
     return out
+
+
+def packed_x3(W, device):
+    return packed("x3", W, device)
 
 
 def bf16_to_f64(u16):
@@ -58,28 +75,48 @@ def test_pack_x3_pieces_sum_to_the_weight(cuda_device):
                               torch.from_numpy(W[0, :16].copy()).to(torch.bfloat16).to(torch.float32).numpy())
 
 
-def mlp_blocks(layers, device):
-    """{packed bf16x3, bias} per layer as one byte tensor."""
+def test_pack_h2_pieces_sum_to_the_scaled_weight(cuda_device):
+    sc = zscale("h2")
+    for kr, nc in ((64, 64), (32, 32), (64, 256), (128, 256)):
+        rng = np.random.RandomState(kr + nc)
+        W = (0.2 * rng.randn(kr, nc) * np.exp(0.5 * rng.randn(kr, nc))).astype(np.float32)
+        P = packed("h2", W, cuda_device).cpu().numpy().view(np.float16).reshape(2, kr // 32, 4, nc // 16, 16, 8)
+        pieces = P.astype(np.float64)
+        back = np.zeros((kr, nc))
+        for kb in range(kr // 32):
+            for g in range(4):
+                for j in range(8):
+                    k = 16 * (2 * kb + (j >> 2)) + 4 * g + (j & 3)
+                    back[k] = pieces[:, kb, g, :, :, j].sum(0).reshape(-1)
+        # two fp16 pieces: 2^-24 relative while the lo piece is a normal fp16 (|2^s w| >= 2^-2), 2^-25 absolute below
+        err = np.abs(back - sc * W.astype(np.float64))
+        assert np.all(err <= np.maximum(2.0 ** -23 * np.abs(sc * W), 2.0 ** -25))
+        assert np.array_equal(pieces[0, 0, 0, 0, :, 0], (sc * W[0, :16]).astype(np.float16).astype(np.float64))
+
+
+def mlp_blocks(arith, layers, device):
+    """{packed weights, bias (2^s b for h2)} per layer as one byte tensor."""
     parts = []
     for W, b in layers:
-        parts.append(packed_x3(W, device).cpu().numpy())
-        parts.append(np.ascontiguousarray(b, dtype=np.float32).view(np.uint8))
+        parts.append(packed(arith, W, device).cpu().numpy())
+        parts.append(np.ascontiguousarray(zscale(arith) * b, dtype=np.float32).view(np.uint8))
     return dev(np.concatenate(parts), device, np.uint8)
 
 
 @pytest.mark.parametrize("d,n_layers,mask", [(64, 4, 0b0111), (64, 3, 0b111), (32, 4, 0b0111), (32, 1, 0), (64, 2, 0b10)])
 @pytest.mark.parametrize("rows", [1, 16, 333, 70000])
-def test_mlp_fwd_x3(cuda_device, d, n_layers, mask, rows):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_mlp_fwd_split(cuda_device, arith, d, n_layers, mask, rows):
     rng = np.random.RandomState(rows + d)
     X = rng.randn(rows, d).astype(np.float32)
     layers = [((rng.randn(d, d) / np.sqrt(d)).astype(np.float32), (0.1 * rng.randn(d)).astype(np.float32))
               for _ in range(n_layers)]
-    wb = mlp_blocks(layers, cuda_device)
+    wb = mlp_blocks(arith, layers, cuda_device)
     Y = torch.empty((rows, d), dtype=torch.float32, device=cuda_device)
     acts = torch.empty((max(n_layers - 1, 1), rows, d), dtype=torch.float32, device=cuda_device)
     task = _lib.MlpTask(_lib.ptr(dev(X, cuda_device)), _lib.ptr(wb), _lib.ptr(Y), _lib.ptr(acts), 0, rows, n_layers, mask,
                         None, None)
-    _lib.call_multi("tspgnn_mlp_fwd_multi_x3", [task], d)
+    _lib.call_multi("tspgnn_mlp_fwd_multi_" + arith, [task], d)
     torch.cuda.synchronize()
     x = X.astype(np.float64)
     for l, (W, b) in enumerate(layers):
@@ -90,7 +127,8 @@ def test_mlp_fwd_x3(cuda_device, d, n_layers, mask, rows):
 
 
 @pytest.mark.parametrize("d", [32, 64])
-def test_mlp_x3_two_tasks_with_projection(cuda_device, d):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_mlp_two_tasks_with_projection(cuda_device, arith, d):
     rng = np.random.RandomState(d)
     rows_a, rows_b = 9000, 700
     Xa = rng.randn(rows_a, d).astype(np.float32)
@@ -101,11 +139,11 @@ def test_mlp_x3_two_tasks_with_projection(cuda_device, d):
     Ya = torch.empty((rows_a, d), dtype=torch.float32, device=cuda_device)
     Yb = torch.empty((rows_b, d), dtype=torch.float32, device=cuda_device)
     Zb = torch.empty((rows_b, 4 * d), dtype=torch.float32, device=cuda_device)
-    ta = _lib.MlpTask(_lib.ptr(dev(Xa, cuda_device)), _lib.ptr(mlp_blocks(la, cuda_device)), _lib.ptr(Ya), None, 0, rows_a, 3,
+    ta = _lib.MlpTask(_lib.ptr(dev(Xa, cuda_device)), _lib.ptr(mlp_blocks(arith, la, cuda_device)), _lib.ptr(Ya), None, 0, rows_a, 3,
                       0b111, None, None)
-    tb = _lib.MlpTask(_lib.ptr(dev(Xb, cuda_device)), _lib.ptr(mlp_blocks(lb, cuda_device)), _lib.ptr(Yb), None, 0, rows_b, 4,
-                      0b0111, _lib.ptr(packed_x3(P, cuda_device)), _lib.ptr(Zb))
-    _lib.call_multi("tspgnn_mlp_fwd_multi_x3", [ta, tb], d)
+    tb = _lib.MlpTask(_lib.ptr(dev(Xb, cuda_device)), _lib.ptr(mlp_blocks(arith, lb, cuda_device)), _lib.ptr(Yb), None, 0, rows_b, 4,
+                      0b0111, _lib.ptr(packed(arith, P, cuda_device)), _lib.ptr(Zb))
+    _lib.call_multi("tspgnn_mlp_fwd_multi_" + arith, [ta, tb], d)
     torch.cuda.synchronize()
     xa = Xa.astype(np.float64)
     for W, b in la:
@@ -115,7 +153,7 @@ def test_mlp_x3_two_tasks_with_projection(cuda_device, d):
         xb = NO.dense(xb, W.astype(np.float64), b.astype(np.float64), l < 3)
     assert rel_err(Ya.cpu().numpy(), xa) < 2e-6
     assert rel_err(Yb.cpu().numpy(), xb) < 2e-6
-    assert rel_err(Zb.cpu().numpy(), xb @ P.astype(np.float64)) < 2e-6
+    assert rel_err(Zb.cpu().numpy(), zscale(arith) * (xb @ P.astype(np.float64))) < 2e-6
 
 
 def ln_params(rng, d):
@@ -126,8 +164,10 @@ def ln_params(rng, d):
 
 @pytest.mark.parametrize("d,dx", [(64, 64), (32, 32), (32, 64), (64, 0), (64, 192), (64, 32)])
 @pytest.mark.parametrize("rows", [1, 17, 1000, 40000])
-def test_lnlstm_fwd_x3(cuda_device, d, dx, rows):
-    """dx+d = 128 at d=64 does not fit LDS in three pieces: the streamed (lock-step) mode is exercised too."""
+@pytest.mark.parametrize("arith", ARITHS)
+def test_lnlstm_fwd_split(cuda_device, arith, d, dx, rows):
+    """dx+d = 128 at d=64 does not fit LDS in three bf16 pieces, dx+d = 256 not in two fp16 pieces either: the
+    streamed (lock-step) mode is exercised too."""
     rng = np.random.RandomState(rows * 7 + d + dx)
     x = rng.randn(rows, dx).astype(np.float32)
     h = rng.randn(rows, d).astype(np.float32)
@@ -138,9 +178,9 @@ def test_lnlstm_fwd_x3(cuda_device, d, dx, rows):
     c_out = torch.empty((rows, d), dtype=torch.float32, device=cuda_device)
     xd = dev(x, cuda_device) if dx else None
     task = _lib.LstmTask(_lib.ptr(xd), dx, _lib.ptr(dev(h, cuda_device)), _lib.ptr(dev(c, cuda_device)),
-                         _lib.ptr(packed_x3(K, cuda_device)), _lib.ptr(dev(ln, cuda_device)), _lib.ptr(h_out), _lib.ptr(c_out),
+                         _lib.ptr(packed(arith, K, cuda_device)), _lib.ptr(dev(ln, cuda_device)), _lib.ptr(h_out), _lib.ptr(c_out),
                          rows, None, None, None, None)
-    _lib.call_multi("tspgnn_lnlstm_fwd_multi_x3", [task], d)
+    _lib.call_multi("tspgnn_lnlstm_fwd_multi_" + arith, [task], d)
     torch.cuda.synchronize()
     rh, rc = NO.lnlstm(x.astype(np.float64), h.astype(np.float64), c.astype(np.float64), K.astype(np.float64), lnd)
     assert rel_err(c_out.cpu().numpy(), rc) < 5e-6
@@ -148,7 +188,8 @@ def test_lnlstm_fwd_x3(cuda_device, d, dx, rows):
 
 
 @pytest.mark.parametrize("d", [32, 64])
-def test_lnlstm_x3_gather_init_and_zbias_tasks_in_one_launch(cuda_device, d):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_lnlstm_gather_init_and_zbias_tasks_in_one_launch(cuda_device, arith, d):
     rng = np.random.RandomState(d)
     N, M = 300, 5000
     uv = np.stack([rng.randint(0, N, M), rng.randint(0, N, M)], 1).astype(np.int32)
@@ -165,13 +206,13 @@ def test_lnlstm_x3_gather_init_and_zbias_tasks_in_one_launch(cuda_device, d):
     ln_v, lnd_v = ln_params(rng, d)
     he_o = torch.empty((M, d), dtype=torch.float32, device=cuda_device); ce_o = torch.empty_like(he_o)
     hv_o = torch.empty((N, d), dtype=torch.float32, device=cuda_device); cv_o = torch.empty_like(hv_o)
-    te = _lib.LstmTask(None, 0, _lib.ptr(dev(he, cuda_device)), _lib.ptr(dev(ce, cuda_device)), _lib.ptr(packed_x3(Kh, cuda_device)),
+    te = _lib.LstmTask(None, 0, _lib.ptr(dev(he, cuda_device)), _lib.ptr(dev(ce, cuda_device)), _lib.ptr(packed(arith, Kh, cuda_device)),
                        _lib.ptr(dev(ln_e, cuda_device)), _lib.ptr(he_o), _lib.ptr(ce_o), M,
-                       _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev(Zx, cuda_device)), None, None)
+                       _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev(zscale(arith) * Zx, cuda_device)), None, None)
     tv = _lib.LstmTask(_lib.ptr(dev(xv, cuda_device)), d, _lib.ptr(dev(hv, cuda_device)), _lib.ptr(dev(cv, cuda_device)),
-                       _lib.ptr(packed_x3(Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o), N,
+                       _lib.ptr(packed(arith, Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o), N,
                        None, None, _lib.ptr(dev(zb, cuda_device)), _lib.ptr(dev(deg, cuda_device)))
-    _lib.call_multi("tspgnn_lnlstm_fwd_multi_x3", [te, tv], d)
+    _lib.call_multi("tspgnn_lnlstm_fwd_multi_" + arith, [te, tv], d)
     torch.cuda.synchronize()
     z0 = Zx.astype(np.float64)[uv[:, 0]] + Zx.astype(np.float64)[uv[:, 1]]
     rh, rc = NO.lnlstm(np.zeros((M, 0)), he.astype(np.float64), ce.astype(np.float64), Kh.astype(np.float64), lnd_e, z0=z0)
@@ -184,8 +225,9 @@ def test_lnlstm_x3_gather_init_and_zbias_tasks_in_one_launch(cuda_device, d):
 
 
 @pytest.mark.parametrize("d", [32, 64])
-def test_cell_fused_with_next_step_mlp(cuda_device, d):
-    """tspgnn_lnlstm_mlp_fwd_multi_x3: edge cell (gather-init, resident) + 3-layer message MLP, and vertex cell
+@pytest.mark.parametrize("arith", ARITHS)
+def test_cell_fused_with_next_step_mlp(cuda_device, arith, d):
+    """tspgnn_lnlstm_mlp_fwd_multi_{h2,x3}: edge cell (gather-init, resident) + 3-layer message MLP, and vertex cell
     (bias-init, streamed) + 4-layer MLP + projection, one launch; both against the float64 oracle."""
     rng = np.random.RandomState(100 + d)
     N, M = 333, 7001
@@ -207,16 +249,16 @@ def test_cell_fused_with_next_step_mlp(cuda_device, d):
     he_o, ce_o, ae_o = torch.empty((M, d), **f32), torch.empty((M, d), **f32), torch.empty((M, d), **f32)
     hv_o, cv_o, yv_o = torch.empty((N, d), **f32), torch.empty((N, d), **f32), torch.empty((N, d), **f32)
     zv_o = torch.empty((N, 4 * d), **f32)
-    te = _lib.LstmTask(None, 0, _lib.ptr(dev(he, cuda_device)), _lib.ptr(dev(ce, cuda_device)), _lib.ptr(packed_x3(Kh, cuda_device)),
+    te = _lib.LstmTask(None, 0, _lib.ptr(dev(he, cuda_device)), _lib.ptr(dev(ce, cuda_device)), _lib.ptr(packed(arith, Kh, cuda_device)),
                        _lib.ptr(dev(ln_e, cuda_device)), _lib.ptr(he_o), _lib.ptr(ce_o), M,
-                       _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev(Zx, cuda_device)), None, None)
+                       _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev(zscale(arith) * Zx, cuda_device)), None, None)
     tv = _lib.LstmTask(_lib.ptr(dev(xv, cuda_device)), d, _lib.ptr(dev(hv, cuda_device)), _lib.ptr(dev(cv, cuda_device)),
-                       _lib.ptr(packed_x3(Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o), N,
+                       _lib.ptr(packed(arith, Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o), N,
                        None, None, _lib.ptr(dev(zb, cuda_device)), _lib.ptr(dev(deg, cuda_device)))
-    tasks = [_lib.CellMlpTask(te, _lib.ptr(mlp_blocks(le, cuda_device)), 3, 0b111, _lib.ptr(ae_o), None, None),
-             _lib.CellMlpTask(tv, _lib.ptr(mlp_blocks(lv, cuda_device)), 4, 0b0111, _lib.ptr(yv_o),
-                              _lib.ptr(packed_x3(P, cuda_device)), _lib.ptr(zv_o))]
-    _lib.call_multi("tspgnn_lnlstm_mlp_fwd_multi_x3", tasks, d)
+    tasks = [_lib.CellMlpTask(te, _lib.ptr(mlp_blocks(arith, le, cuda_device)), 3, 0b111, _lib.ptr(ae_o), None, None),
+             _lib.CellMlpTask(tv, _lib.ptr(mlp_blocks(arith, lv, cuda_device)), 4, 0b0111, _lib.ptr(yv_o),
+                              _lib.ptr(packed(arith, P, cuda_device)), _lib.ptr(zv_o))]
+    _lib.call_multi("tspgnn_lnlstm_mlp_fwd_multi_" + arith, tasks, d)
     torch.cuda.synchronize()
     z0 = Zx.astype(np.float64)[uv[:, 0]] + Zx.astype(np.float64)[uv[:, 1]]
     rh, rc = NO.lnlstm(np.zeros((M, 0)), he.astype(np.float64), ce.astype(np.float64), Kh.astype(np.float64), lnd_e, z0=z0)
@@ -232,10 +274,11 @@ def test_cell_fused_with_next_step_mlp(cuda_device, d):
     for l, (W, b) in enumerate(lv):
         y = NO.dense(y, W.astype(np.float64), b.astype(np.float64), l < 3)
     assert rel_err(yv_o.cpu().numpy(), y) < 5e-6
-    assert rel_err(zv_o.cpu().numpy(), y @ P.astype(np.float64)) < 5e-6
+    assert rel_err(zv_o.cpu().numpy(), zscale(arith) * (y @ P.astype(np.float64))) < 5e-6
 
 
-def test_x3_rejects_unsupported_width(cuda_device):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_split_kernels_reject_unsupported_width(cuda_device, arith):
     t = _lib.MlpTask(None, None, None, None, 0, 0, 1, 0, None, None)
     with pytest.raises(_lib.TspgnnError):
-        _lib.call_multi("tspgnn_mlp_fwd_multi_x3", [t], 128)
+        _lib.call_multi("tspgnn_mlp_fwd_multi_" + arith, [t], 128)

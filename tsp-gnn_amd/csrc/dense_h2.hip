@@ -1,0 +1,696 @@
+// fp32-accurate dense updates on the fp16 matrix cores ("f16x2").
+//
+// The dense work of a message-passing step (message MLPs, the cells' [x|h] K, the Kx projection) is too small per
+// row to be anything but issue-bound, so what counts is the number of matrix and vector instructions per row.
+// An fp16 carries 11 significand bits and rounding to nearest leaves an error <= 2^-12 relative, hence TWO fp16
+// pieces  x = hi + lo,  hi = rn16(x), lo = rn16(x - hi)  represent an fp32 value to 2^-24 relative -- half an fp32
+// ulp -- and the product needs three piece products,
+//     a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi        (dropped: a_lo*b_lo <= 2^-24 relative),
+// accumulated in fp32 inside v_mfma_f32_16x16x32_f16 (smallest terms first).  Against the three-piece bf16 split of
+// dense_x3.hip: 3 matrix instructions per product instead of 6, two vector instructions per split value
+// (v_cvt_pk_f16_f32 for a pair of hi, one v_fma_mix_f32 for x - hi, v_cvt_pk_f16_f32 for a pair of lo) instead of
+// ~5.5, and 4 instead of 6 bytes of LDS per weight -- a cell's Kh[64,256] and the three message layers are resident
+// in 112 KB with no piece left in L1.
+//
+// Range.  The lo piece of a value below 2^-2 is an fp16 subnormal (kept by the conversion and by the MFMA on gfx950 --
+// tools/f16_denorm_probe.hip), i.e. carries an ABSOLUTE error up to 2^-25.  For activations (O(1) rows) that is below
+// the fp32 rounding of the row's large entries; for weights (|w| ~ 0.1) it would cost a factor 2-4 in end-to-end
+// accuracy (tools/h2_numerics.py), so the WEIGHT operand is packed pre-multiplied by 2^6 and the scale is taken out
+// where that is free or nearly so:
+//   * cell: every term of z carries the factor (weights, the projected messages Zx, the folded bias), and the four gate
+//     LayerNorms run with epsilon 2^12 * 1e-12 -- a power-of-two scale commutes with every rounding, so the normalised
+//     gates are bit-identical to those of the unscaled z;
+//   * Dense layer: the bias block is stored pre-scaled and the output is multiplied by 2^-6 next to the relu.
+// Weights must stay below 2^10 in magnitude (fp16 overflow of the scaled hi piece); activations below 65504.
+//
+// Layout: the "transposed chaining" of dense.hip / dense_x3.hip (OUT^T = W^T IN^T, a wavefront owns 16 rows, the D
+// fragment of one layer is the next layer's B operand in the same lane).  A k-block covers 32 features: lane (rl, g)
+// supplies the 8 features 16*(2kb + (j>>2)) + 4g + (j&3), j = 0..7; the packed weights use the same permutation.
+#include "common.h"
+#include "mfma_tile.h"
+
+namespace tspgnn {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+constexpr int kH2ScaleLog2 = TSPGNN_H2_WEIGHT_SCALE_LOG2;
+constexpr float kH2Scale = (float)(1 << kH2ScaleLog2);
+constexpr float kH2InvScale = 1.0f / kH2Scale;
+constexpr float kH2GateEps = 1e-12f * kH2Scale * kH2Scale;  // LayerNorm epsilon of a z scaled by 2^s
+constexpr float kNegLog2e = -1.4426950408889634f;
+
+// x = hi + lo to 2^-24 relative: two v_cvt_pk_f16_f32 and two v_fma_mix_f32 (x - float(hi), the fp16 operand widened
+// inside the instruction) per pair of values.
+__device__ __forceinline__ void split2(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2 v = {x[i], x[i + 1]};
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x[i]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x[i + 1]));
+        const f32x2 r = {r0, r1};
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        hi[i] = h[0];
+        hi[i + 1] = h[1];
+        lo[i] = l[0];
+        lo[i + 1] = l[1];
+    }
+}
+
+// Packed weights of a [krows, ncols] matrix: P[piece][kb][g][t][jl][8] (fp16), piece 0 = hi, 1 = lo of 2^s * W,
+//   value = piece(2^s * W[16*(2kb + (j>>2)) + 4g + (j&3)][t*16 + jl]),   KB = krows/32, NT = ncols/16.
+// One ds_read_b128 per (piece, kb, t) and lane: 16 lanes x 16 B contiguous, lane groups a multiple of 256 B apart.
+__global__ __launch_bounds__(256) void pack_weights_h2_kernel(const float* __restrict__ W, _Float16* __restrict__ P,
+                                                              int krows, int ncols) {
+    const int NT = ncols >> 4;
+    const int total = krows * ncols;  // per piece
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i & 7, jl = (i >> 3) & 15;
+        int rest = i >> 7;
+        const int t = rest % NT;
+        rest /= NT;
+        const int g = rest & 3, kb = rest >> 2;
+        const int k = 16 * (2 * kb + (j >> 2)) + 4 * g + (j & 3);
+        const float x = kH2Scale * W[(size_t)k * ncols + t * 16 + jl];
+        const _Float16 h = (_Float16)x;
+        P[i] = h;
+        P[(size_t)total + i] = (_Float16)(x - (float)h);
+    }
+}
+
+__device__ __forceinline__ f16x8 ldw(const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); }
+
+// acc[t] += W-block(kb, all NT tiles) x B for one 32-feature k-block; wh / wl = the two pieces of the packed matrix
+// (LDS), (bh, bl) = split2 of the lane's eight B values.  The fragments of tile t+1 are fetched while the three
+// (dependent) MFMAs of tile t run.
+template <int NT>
+__device__ __forceinline__ void kblock_h2(f32x4 (&acc)[NT], const _Float16* wh, const _Float16* wl, int kb, int g, int jl,
+                                          const f16x8& bh, const f16x8& bl) {
+    const int off = ((kb * 4 + g) * NT * 16 + jl) * 8;
+    f16x8 ah = ldw(wh + off), al = ldw(wl + off);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f16x8 nah = ah, nal = al;
+        if (t + 1 < NT) {
+            nah = ldw(wh + off + (t + 1) * 128);
+            nal = ldw(wl + off + (t + 1) * 128);
+        }
+        f32x4 c = acc[t];
+        c = MFMA_F16(al, bh, c);  // smallest terms first
+        c = MFMA_F16(ah, bl, c);
+        c = MFMA_F16(ah, bh, c);
+        acc[t] = c;
+        ah = nah;
+        al = nal;
+    }
+}
+
+// One Dense(D) layer on the lane's part of a 16-row tile, activations chained in registers (D layout).  `bias` holds
+// 2^s * b; the output comes back at its true scale.
+template <int D>
+__device__ __forceinline__ void dense_layer_h2(f32x4 (&a)[D / 16], const _Float16* wh, const _Float16* wl, const float* bias,
+                                               bool relu, int g, int rl) {
+    constexpr int NT = D / 16, KB = D / 32;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = ld4(bias + t * 16 + g * 4);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = a[2 * kb + (j >> 2)][j & 3];
+        f16x8 bh, bl;
+        split2(x, bh, bl);
+        kblock_h2<NT>(acc, wh, wl, kb, g, rl, bh, bl);
+    }
+    const f32x2 inv = {kH2InvScale, kH2InvScale};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
+        }
+        a[t].lo = acc[t].lo * inv;
+        a[t].hi = acc[t].hi * inv;
+    }
+}
+
+// bytes -> LDS, 16 bytes per lane, straight from global memory (global_load_lds_dwordx4); the LDS address of a lane is
+// the wavefront's base + lane*16.  Callers follow up with h2_stage_wait() + a barrier.
+__device__ __forceinline__ void h2_copy_to_lds(void* dst, const void* __restrict__ src, int nbytes, int tid, int nthreads) {
+    const int lane = tid & 63, n16 = nbytes >> 4;
+    const char* s = reinterpret_cast<const char*>(src);
+    char* d = reinterpret_cast<char*>(dst);
+    for (int idx = tid; idx - lane < n16; idx += nthreads) {
+        if (idx < n16)
+            __builtin_amdgcn_global_load_lds(s + (size_t)idx * 16,
+                                             (__attribute__((address_space(3))) void*)(d + (size_t)(idx - lane) * 16), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void h2_stage_wait() { __builtin_amdgcn_s_waitcnt(0); }
+
+constexpr int kMaxTasksH2 = 4;
+
+// ---------------------------------------------------------------------------------- MLP (f16x2)
+// Task fields as tspgnn_mlp_task; wb points at n_layers blocks of { fp16 packed[2*D*D] , float bias[D] (= 2^s b) };
+// proj_w at an fp16 packed [2 * D * 4D] matrix; proj_out = 2^s * (Y P): it feeds the scaled z of an f16x2 cell.
+struct MlpTaskTableH2 {
+    tspgnn_mlp_task task[kMaxTasksH2];
+    int blk_end[kMaxTasksH2];
+    int n;
+};
+
+template <int D>
+__global__ __launch_bounds__(1024) void mlp_fwd_h2_kernel(const MlpTaskTableH2 tt) {
+    constexpr int NT = D / 16, KB = D / 32;
+    constexpr int LAYER_BYTES = 2 * D * D * 2 + D * 4;
+    constexpr int WBYTES = (4 * LAYER_BYTES > 2 * D * 4 * D * 2) ? 4 * LAYER_BYTES : 2 * D * 4 * D * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WBYTES + 16];
+    int* ticket = reinterpret_cast<int*>(lds + WBYTES);
+
+    int k = 0;
+    while (k + 1 < tt.n && (int)blockIdx.x >= tt.blk_end[k]) ++k;
+    const int blk0 = k ? tt.blk_end[k - 1] : 0;
+    const int my_blk = blockIdx.x - blk0, my_grid = tt.blk_end[k] - blk0;
+    const float* __restrict__ X = tt.task[k].X;
+    const unsigned char* __restrict__ wb = reinterpret_cast<const unsigned char*>(tt.task[k].wb);
+    float* __restrict__ Y = tt.task[k].Y;
+    float* __restrict__ acts = tt.task[k].acts;
+    const long long acts_stride = tt.task[k].acts_stride;
+    const int rows = tt.task[k].rows, n_layers = tt.task[k].n_layers;
+    const unsigned relu_mask = tt.task[k].relu_mask;
+    const _Float16* __restrict__ proj_w = reinterpret_cast<const _Float16*>(tt.task[k].proj_w);
+    float* __restrict__ proj_out = tt.task[k].proj_out;
+    const int tiles_total = (rows + 15) / 16;
+
+    const int tid = threadIdx.x;
+    h2_copy_to_lds(lds, wb, n_layers * LAYER_BYTES, tid, blockDim.x);
+    const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
+    const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
+    if (tid == 0) *ticket = t_beg;
+    h2_stage_wait();
+    __syncthreads();
+
+    const int lane = tid & 63, rl = lane & 15, g = lane >> 4;
+    for (;;) {
+        int tile = 0;
+        if (lane == 0) tile = atomicAdd(ticket, 1);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= t_end) break;
+        const int row = tile * 16 + rl;
+        const bool valid = row < rows;
+        const size_t rbase = (size_t)(valid ? row : rows - 1) * D + g * 4;
+        f32x4 a[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) a[q] = ld4(X + rbase + q * 16);
+        for (int l = 0; l < n_layers; ++l) {
+            const _Float16* wl = reinterpret_cast<const _Float16*>(lds + (size_t)l * LAYER_BYTES);
+            const float* bl = reinterpret_cast<const float*>(lds + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
+            dense_layer_h2<D>(a, wl, wl + D * D, bl, (relu_mask >> l) & 1u, g, rl);
+            if (acts != nullptr && l < n_layers - 1 && valid) {
+                float* dst = acts + (size_t)l * acts_stride + rbase;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) st4(dst + t * 16, a[t]);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) st4(Y + rbase + t * 16, a[t]);
+        }
+    }
+    // second phase of a (small) task: proj_out = 2^s Y P, P packed [D, 4D]
+    if (proj_w != nullptr) {
+        constexpr int NP = D / 4;
+        __threadfence_block();
+        __syncthreads();
+        h2_copy_to_lds(lds, proj_w, 2 * D * 4 * D * 2, tid, blockDim.x);
+        if (tid == 0) *ticket = t_beg;
+        h2_stage_wait();
+        __syncthreads();
+        const _Float16* wp = reinterpret_cast<const _Float16*>(lds);
+        for (;;) {
+            int tile = 0;
+            if (lane == 0) tile = atomicAdd(ticket, 1);
+            tile = __builtin_amdgcn_readfirstlane(tile);
+            if (tile >= t_end) break;
+            const int row = tile * 16 + rl;
+            const bool valid = row < rows;
+            const size_t rc = (size_t)(valid ? row : rows - 1);
+            f32x4 acc[NP];
+#pragma unroll
+            for (int t = 0; t < NP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* yr = Y + rc * D + g * 4;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const f32x4 lo4 = ld4(yr + (2 * kb) * 16), hi4 = ld4(yr + (2 * kb + 1) * 16);
+                float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                f16x8 bh, bl;
+                split2(x, bh, bl);
+                kblock_h2<NP>(acc, wp, wp + D * 4 * D, kb, g, rl, bh, bl);
+            }
+            if (valid) {
+#pragma unroll
+                for (int t = 0; t < NP; ++t) st4(proj_out + rc * 4 * D + t * 16 + g * 4, acc[t]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- LN-LSTM (+ MLP) (f16x2)
+// z = 2^s ([x|h] K (+ gather-init / bias-init)), five LayerNorms and the gate arithmetic of dense.hip's cell --
+// optionally followed, on the same 16 rows while h' is still in registers, by the message MLP that consumes h' in the
+// NEXT time step (and its projection through the receiving cell's Kx), exactly as lnlstm_mlp_fwd_x3_kernel.
+//   resident mode  -- K and the MLP layers fit LDS together (Kh of the edge cell in gather-init mode + three layers:
+//     112 KB at D=64): staged once per workgroup; 16-row tiles are handed out by an LDS ticket.
+//   lock-step mode -- otherwise (the vertex cell's [2D,4D] + MLP + projection): K is streamed in k-block chunks, then
+//     the MLP weights, then the projection matrix are staged into the same LDS region, one tile per wavefront per
+//     round.
+struct CellTaskTableH2 {
+    tspgnn_cell_mlp_task task[kMaxTasksH2];
+    int blk_end[kMaxTasksH2];
+    int kbc[kMaxTasksH2];  // k-blocks (32 rows of K) per LDS chunk; >= all of K: resident
+    int n;
+};
+
+template <int D, int MAXT>
+__global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTableH2 tt) {
+    constexpr int NT4 = D / 4, TPG = D / 16, KBH = D / 32;
+    constexpr int LAYER_BYTES = 2 * D * D * 2 + D * 4;  // { hi, lo, bias } of one MLP layer
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    int k = 0;
+    while (k + 1 < tt.n && (int)blockIdx.x >= tt.blk_end[k]) ++k;
+    const int blk0 = k ? tt.blk_end[k - 1] : 0;
+    const int my_blk = blockIdx.x - blk0, my_grid = tt.blk_end[k] - blk0;
+    const tspgnn_lstm_task& tk = tt.task[k].cell;
+    const float* __restrict__ x = tk.x;
+    const int dx = tk.dx;
+    const float* __restrict__ h = tk.h;
+    const float* __restrict__ c = tk.c;
+    const _Float16* __restrict__ K = reinterpret_cast<const _Float16*>(tk.K);
+    const float* __restrict__ ln = tk.ln;
+    float* __restrict__ h_out = tk.h_out;
+    float* __restrict__ c_out = tk.c_out;
+    const int rows = tk.rows;
+    const int2* __restrict__ uv = reinterpret_cast<const int2*>(tk.uv);
+    const float* __restrict__ Zx = tk.Zx;
+    const float* __restrict__ zbias = tk.zbias;
+    const float* __restrict__ zscale = tk.zscale;
+    const unsigned char* __restrict__ mlp_wb = reinterpret_cast<const unsigned char*>(tt.task[k].mlp_wb);
+    const int n_layers = tt.task[k].mlp_layers;
+    const unsigned relu_mask = tt.task[k].relu_mask;
+    float* __restrict__ mlp_out = tt.task[k].mlp_out;
+    const _Float16* __restrict__ proj_w = reinterpret_cast<const _Float16*>(tt.task[k].proj_w);
+    float* __restrict__ proj_out = tt.task[k].proj_out;
+    const int tiles_total = (rows + 15) / 16;
+    const int KBT = (dx + D) >> 5;       // k-blocks in total
+    const int kbc = tt.kbc[k];
+    const bool resident = kbc >= KBT;
+    const int KBX = dx >> 5;             // k-blocks that come from x
+    const int total = (dx + D) * 4 * D;  // elements per piece of the whole matrix
+    const int chunk_total = (resident ? KBT : kbc) * 32 * 4 * D;
+
+    // LDS: [ln 10*D floats][ticket, pad][weights region]
+    float* lds_ln = reinterpret_cast<float*>(ldsb);
+    int* ticket = reinterpret_cast<int*>(lds_ln + 10 * D);
+    unsigned char* lds_wb = ldsb + (10 * D + 4) * sizeof(float);
+    _Float16* lds_w = reinterpret_cast<_Float16*>(lds_wb);
+    const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4, wave = tid >> 6;
+    const int nw = blockDim.x >> 6;
+    // LayerNorm parameters, rows [g_i, b_i, g_j, b_j, g_f, b_f, g_o, b_o, g_s, b_s]: the gates i, f, o feed sigmoids
+    // only, so their gamma / beta are stored times -log2(e) with the forget bias folded into b_f (lstm_gates<D, true>)
+    for (int i = tid; i < 10 * D; i += blockDim.x) {
+        const int r = i / D;
+        float v = ln[i];
+        if (r == 5) v += 1.0f;
+        if (r < 2 || (r >= 4 && r < 8)) v *= kNegLog2e;
+        lds_ln[i] = v;
+    }
+
+    // stage k-blocks [kb0, kb1) of both pieces (each piece is k-block major in global memory)
+    auto stage = [&](int kb0, int kb1) {
+        const int n = (kb1 - kb0) * 32 * 4 * D;  // elements per piece
+        for (int p = 0; p < 2; ++p)
+            h2_copy_to_lds(lds_w + (size_t)p * chunk_total, K + (size_t)p * total + (size_t)kb0 * 32 * 4 * D, n * 2, tid,
+                           blockDim.x);
+    };
+    // z starts at 2^s * (its non-GEMM part); Zx is stored scaled by its producer (the f16x2 projection)
+    auto init_acc = [&](f32x4 (&acc)[NT4], unsigned rc) {
+        if (uv != nullptr) {
+            const int2 ends = uv[rc];
+            const float* zu = Zx + ((unsigned)ends.x * (4 * D) + g * 4);
+            const float* zv = Zx + ((unsigned)ends.y * (4 * D) + g * 4);
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] = ld4(zu + t * 16);
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] += ld4(zv + t * 16);
+        } else if (zbias != nullptr) {
+            const float sc = zscale[rc] * kH2Scale;
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] = ld4(zbias + t * 16 + g * 4) * sc;
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // k-blocks [kb0, kb1) of the concatenated [x | h] operand; lds_w holds the chunk starting at kb_base
+    auto kloop = [&](f32x4 (&acc)[NT4], unsigned rc, int kb_base, int kb0, int kb1) {
+        const float* xrow = x + (rc * (unsigned)dx + g * 4);
+        const float* hrow = h + (rc * D + g * 4);
+        for (int kb = kb0; kb < kb1; ++kb) {
+            const float* src = kb < KBX ? xrow + kb * 32 : hrow + (kb - KBX) * 32;
+            const f32x4 lo4 = ld4(src), hi4 = ld4(src + 16);
+            float xv[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            f16x8 bh, bl;
+            split2(xv, bh, bl);
+            kblock_h2<NT4>(acc, lds_w, lds_w + chunk_total, kb - kb_base, g, rl, bh, bl);
+        }
+    };
+    // gates + state stores; returns h' in registers (the D layout is the next GEMM's B operand)
+    auto cell = [&](f32x4 (&acc)[NT4], f32x4 (&cf)[TPG], unsigned rc, bool valid, f32x4 (&hn)[TPG]) {
+        f32x4 nc[TPG];
+        lstm_gates<D, true>(acc, cf, lds_ln, g, hn, nc, kH2GateEps);
+        if (valid) {
+            float* hd = h_out + (rc * D + g * 4);
+            float* cd = c_out + (rc * D + g * 4);
+#pragma unroll
+            for (int t = 0; t < TPG; ++t) {
+                st4(hd + t * 16, hn[t]);
+                st4(cd + t * 16, nc[t]);
+            }
+        }
+    };
+
+    if (resident) {
+        // weights region: [K 2 pieces][MLP layers { hi, lo, bias } as in global memory]
+        unsigned char* lds_mlp = lds_wb + (size_t)2 * chunk_total * 2;
+        stage(0, KBT);
+        if (n_layers > 0) h2_copy_to_lds(lds_mlp, mlp_wb, n_layers * LAYER_BYTES, tid, blockDim.x);
+        const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
+        const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
+        if (tid == 0) *ticket = t_beg;
+        h2_stage_wait();
+        __syncthreads();
+        for (;;) {
+            int tile = 0;
+            if (lane == 0) tile = atomicAdd(ticket, 1);
+            tile = __builtin_amdgcn_readfirstlane(tile);
+            if (tile >= t_end) break;
+            const int row = tile * 16 + rl;
+            const bool valid = row < rows;
+            const unsigned rc = (unsigned)(valid ? row : rows - 1);
+            f32x4 hn[TPG];
+            {
+                f32x4 acc[NT4], cf[TPG];
+                init_acc(acc, rc);
+#pragma unroll
+                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + (rc * D + g * 4 + t * 16));
+                kloop(acc, rc, 0, 0, KBT);
+                cell(acc, cf, rc, valid, hn);
+            }
+            if (n_layers > 0) {
+                for (int l = 0; l < n_layers; ++l) {
+                    const _Float16* wh = reinterpret_cast<const _Float16*>(lds_mlp + (size_t)l * LAYER_BYTES);
+                    const float* bias = reinterpret_cast<const float*>(lds_mlp + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
+                    dense_layer_h2<D>(hn, wh, wh + D * D, bias, (relu_mask >> l) & 1u, g, rl);
+                }
+                if (valid && mlp_out != nullptr) {
+#pragma unroll
+                    for (int t = 0; t < TPG; ++t) st4(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                }
+            }
+        }
+    } else {
+        // lock-step rounds: one tile per wavefront; K walked chunk by chunk, then the MLP, then the projection
+        const int rounds = (tiles_total + nw - 1) / nw;
+        for (int r = my_blk; r < rounds; r += my_grid) {
+            const int tile = r * nw + wave;
+            const bool live = tile < tiles_total;
+            const int row = tile * 16 + rl;
+            const bool valid = live && row < rows;
+            const unsigned rc = (unsigned)(valid ? row : rows - 1);
+            f32x4 hn[TPG];
+            {
+                f32x4 acc[NT4], cf[TPG];
+                init_acc(acc, rc);
+#pragma unroll
+                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + (rc * D + g * 4 + t * 16));
+                for (int kb0 = 0; kb0 < KBT; kb0 += kbc) {
+                    const int kb1 = min(KBT, kb0 + kbc);
+                    __syncthreads();
+                    stage(kb0, kb1);
+                    h2_stage_wait();
+                    __syncthreads();
+                    if (live) kloop(acc, rc, kb0, kb0, kb1);
+                }
+                cell(acc, cf, rc, valid, hn);
+            }
+            if (n_layers > 0) {
+                __syncthreads();
+                h2_copy_to_lds(lds_wb, mlp_wb, n_layers * LAYER_BYTES, tid, blockDim.x);
+                h2_stage_wait();
+                __syncthreads();
+                for (int l = 0; l < n_layers; ++l) {
+                    const _Float16* wh = reinterpret_cast<const _Float16*>(lds_wb + (size_t)l * LAYER_BYTES);
+                    const float* bias = reinterpret_cast<const float*>(lds_wb + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
+                    dense_layer_h2<D>(hn, wh, wh + D * D, bias, (relu_mask >> l) & 1u, g, rl);
+                }
+                if (valid && mlp_out != nullptr) {
+#pragma unroll
+                    for (int t = 0; t < TPG; ++t) st4(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                }
+                if (proj_w != nullptr) {  // proj_out = 2^s mlp(h') P, P packed [D, 4D]
+                    __syncthreads();
+                    h2_copy_to_lds(lds_wb, proj_w, 2 * D * 4 * D * 2, tid, blockDim.x);
+                    h2_stage_wait();
+                    __syncthreads();
+                    f32x4 acc[NT4];
+#pragma unroll
+                    for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < KBH; ++kb) {
+                        float xv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xv[j] = hn[2 * kb + (j >> 2)][j & 3];
+                        f16x8 bh, bl;
+                        split2(xv, bh, bl);
+                        kblock_h2<NT4>(acc, lds_w, lds_w + D * 4 * D, kb, g, rl, bh, bl);
+                    }
+                    if (valid) {
+#pragma unroll
+                        for (int t = 0; t < NT4; ++t) st4(proj_out + (rc * (4 * D) + t * 16 + g * 4), acc[t]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int split_blocks_h2(const long long* cost, int n, int grid, int* blk_end) {
+    long long total = 0;
+    for (int k = 0; k < n; ++k) total += cost[k] > 0 ? cost[k] : 1;
+    if (grid < n) grid = n;
+    int used = 0;
+    for (int k = 0; k < n; ++k) {
+        const long long ck = cost[k] > 0 ? cost[k] : 1;
+        int bk = (int)((ck * grid + total / 2) / total);
+        if (bk < 1) bk = 1;
+        used += bk;
+        blk_end[k] = used;
+    }
+    return used;
+}
+
+template <int D>
+static int launch_mlp_h2(const tspgnn_mlp_task* tasks, int n, hipStream_t st) {
+    MlpTaskTableH2 tt;
+    long long cost[kMaxTasksH2];
+    long long tiles_all = 0;
+    for (int k = 0; k < n; ++k) {
+        tt.task[k] = tasks[k];
+        if (tt.task[k].acts && tt.task[k].acts_stride == 0) tt.task[k].acts_stride = (long long)tasks[k].rows * D;
+        cost[k] = ((long long)tasks[k].rows + 15) / 16 * (tasks[k].n_layers + (tasks[k].proj_w ? 5 : 0));
+        tiles_all += ((long long)tasks[k].rows + 15) / 16;
+    }
+    tt.n = n;
+    int grid = n_cus();
+    int nw = 16;
+    if (tiles_all <= (long long)grid * 16) nw = tiles_all <= (long long)grid * 4 ? 4 : 8;
+    const long long max_grid = (tiles_all + nw - 1) / nw;
+    if (grid > max_grid) grid = (int)max_grid;
+    grid = split_blocks_h2(cost, n, grid, tt.blk_end);
+    mlp_fwd_h2_kernel<D><<<grid, nw * 64, 0, st>>>(tt);
+    return launched("tspgnn_mlp_fwd_multi_h2");
+}
+
+// Wavefronts per workgroup of the cell launch.  The kernel is compiled for 12 (<= 168 registers) and for 16
+// (<= 128 registers) wavefronts; TSPGNN_H2_WAVES picks one (development switch, default below).
+static int h2_cell_waves() {
+    static const int nw = [] {
+        const char* e = getenv("TSPGNN_H2_WAVES");
+        const int v = e ? atoi(e) : 0;
+        return (v == 12 || v == 16) ? v : 12;
+    }();
+    return nw;
+}
+
+template <int D>
+static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t st, const char* what) {
+    const size_t head = (10 * D + 4) * sizeof(float);
+    const size_t per_kb = (size_t)2 * 32 * 4 * D * 2;  // bytes of one k-block, two pieces
+    const size_t budget = 160 * 1024 - head;
+    const size_t layer_all = 2 * D * D * 2 + D * 4, proj_bytes = (size_t)2 * D * 4 * D * 2;
+    CellTaskTableH2 tt;
+    long long cost[kMaxTasksH2];
+    long long tiles_all = 0;
+    size_t lds_w = 0;
+    for (int k = 0; k < n; ++k) {
+        tt.task[k] = tasks[k];
+        const tspgnn_lstm_task& c = tasks[k].cell;
+        const int L = tasks[k].mlp_layers;
+        const int KBT = (c.dx + D) / 32;
+        const size_t k_bytes = (size_t)KBT * per_kb;
+        size_t need;
+        if (k_bytes + L * layer_all <= budget && !tasks[k].proj_w) {
+            tt.kbc[k] = KBT;
+            need = k_bytes + L * layer_all;
+        } else {
+            int kbc = k_bytes <= budget ? KBT : (int)(budget / per_kb);
+            if (kbc >= KBT) kbc = KBT - 1;  // lock-step mode is selected by kbc < KBT
+            if (kbc < 1 || L * layer_all > budget || (tasks[k].proj_w && proj_bytes > budget))
+                return fail(TSPGNN_EUNSUPPORTED, "%s: dx=%d, d=%d, %d MLP layers do not fit LDS", what, c.dx, D, L);
+            tt.kbc[k] = kbc;
+            need = (size_t)kbc * per_kb;
+            if (L * layer_all > need) need = L * layer_all;
+            if (tasks[k].proj_w && proj_bytes > need) need = proj_bytes;
+        }
+        if (need > lds_w) lds_w = need;
+        const long long tiles = ((long long)c.rows + 15) / 16;
+        cost[k] = tiles * (KBT * 4 + 2 * L + (tasks[k].proj_w ? 8 : 0) + 8);
+        tiles_all += tiles;
+    }
+    tt.n = n;
+    const size_t lds_bytes = lds_w + head;
+    int grid = n_cus();
+    const int nw_max = h2_cell_waves();
+    const int nw = tiles_all <= (long long)grid * 4 ? 4 : (tiles_all <= (long long)grid * 8 ? 8 : nw_max);
+    const long long max_grid = (tiles_all + nw - 1) / nw;
+    if (grid > max_grid) grid = (int)max_grid;
+    {
+        // A lock-step task is a latency chain (several LDS re-stagings per round) that the resident tasks of the
+        // launch hide: it gets exactly the workgroups of ONE round (more would idle, fewer would double the chain),
+        // capped at half the grid; the resident tasks share the rest in proportion to their cost.
+        int fixed[kMaxTasksH2], fixed_sum = 0, n_res = 0;
+        long long res_cost[kMaxTasksH2];
+        for (int k = 0; k < n; ++k) {
+            const bool lock = tt.kbc[k] < (tasks[k].cell.dx + D) / 32;
+            const long long tiles = ((long long)tasks[k].cell.rows + 15) / 16;
+            fixed[k] = lock ? (int)((tiles + nw - 1) / nw) : 0;
+            fixed_sum += fixed[k];
+            if (!lock) ++n_res;
+        }
+        if (n_res == 0 || fixed_sum == 0 || fixed_sum > grid / 2) {
+            grid = split_blocks_h2(cost, n, grid, tt.blk_end);
+        } else {
+            int res_end[kMaxTasksH2], j = 0;
+            for (int k = 0; k < n; ++k)
+                if (!fixed[k]) res_cost[j++] = cost[k];
+            split_blocks_h2(res_cost, n_res, grid - fixed_sum, res_end);
+            int used = 0;
+            j = 0;
+            for (int k = 0; k < n; ++k) {
+                used += fixed[k] ? fixed[k] : res_end[j] - (j ? res_end[j - 1] : 0);
+                if (!fixed[k]) ++j;
+                tt.blk_end[k] = used;
+            }
+            grid = used;
+        }
+    }
+    const void* fn = nw_max == 16 ? reinterpret_cast<const void*>(&lnlstm_mlp_fwd_h2_kernel<D, 1024>)
+                                  : reinterpret_cast<const void*>(&lnlstm_mlp_fwd_h2_kernel<D, 768>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute(%d B): %s", what, (int)lds_bytes, hipGetErrorString(e));
+    if (nw_max == 16)
+        lnlstm_mlp_fwd_h2_kernel<D, 1024><<<grid, nw * 64, lds_bytes, st>>>(tt);
+    else
+        lnlstm_mlp_fwd_h2_kernel<D, 768><<<grid, nw * 64, lds_bytes, st>>>(tt);
+    return launched(what);
+}
+
+}  // namespace tspgnn
+
+using namespace tspgnn;
+
+extern "C" float tspgnn_h2_weight_scale(void) { return kH2Scale; }
+
+extern "C" int tspgnn_pack_weights_h2(const float* W, void* P, int krows, int ncols, void* stream) {
+    TSPGNN_REQUIRE(krows >= 0 && krows % 32 == 0, "pack_weights_h2: krows=%d must be a multiple of 32", krows);
+    TSPGNN_REQUIRE(ncols > 0 && ncols % 16 == 0, "pack_weights_h2: ncols=%d must be a multiple of 16", ncols);
+    if (krows == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(W && P, "pack_weights_h2: null pointer");
+    int grid = (krows * ncols + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    pack_weights_h2_kernel<<<grid, 256, 0, as_stream(stream)>>>(W, reinterpret_cast<_Float16*>(P), krows, ncols);
+    return launched("tspgnn_pack_weights_h2");
+}
+
+extern "C" int tspgnn_mlp_fwd_multi_h2(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream) {
+    TSPGNN_REQUIRE(tasks && n_tasks >= 1 && n_tasks <= kMaxTasksH2, "mlp_fwd_multi_h2: 1..%d tasks", kMaxTasksH2);
+    TSPGNN_REQUIRE(d == 32 || d == 64, "mlp_fwd_h2: d=%d must be 32 or 64", d);
+    tspgnn_mlp_task live[kMaxTasksH2];
+    int n = 0;
+    for (int k = 0; k < n_tasks; ++k) {
+        const tspgnn_mlp_task& t = tasks[k];
+        TSPGNN_REQUIRE(t.rows >= 0, "mlp_fwd_h2: rows=%d", t.rows);
+        TSPGNN_REQUIRE(t.n_layers >= 1 && t.n_layers <= 4, "mlp_fwd_h2: n_layers=%d must be in 1..4", t.n_layers);
+        if (t.rows == 0) continue;
+        TSPGNN_REQUIRE(t.X && t.wb && t.Y, "mlp_fwd_h2: null pointer");
+        TSPGNN_REQUIRE(!t.proj_w || t.proj_out, "mlp_fwd_h2: projection needs proj_out");
+        live[n++] = t;
+    }
+    if (n == 0) return TSPGNN_OK;
+    return d == 32 ? launch_mlp_h2<32>(live, n, as_stream(stream)) : launch_mlp_h2<64>(live, n, as_stream(stream));
+}
+
+static int cell_mlp_h2(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream, const char* what) {
+    TSPGNN_REQUIRE(tasks && n_tasks >= 1 && n_tasks <= kMaxTasksH2, "%s: 1..%d tasks", what, kMaxTasksH2);
+    TSPGNN_REQUIRE(d == 32 || d == 64, "%s: d=%d must be 32 or 64", what, d);
+    tspgnn_cell_mlp_task live[kMaxTasksH2];
+    int n = 0;
+    for (int k = 0; k < n_tasks; ++k) {
+        const tspgnn_lstm_task& t = tasks[k].cell;
+        TSPGNN_REQUIRE(t.rows >= 0, "%s: rows=%d", what, t.rows);
+        TSPGNN_REQUIRE((long long)t.rows * (4 * d > t.dx ? 4 * d : t.dx) < (1ll << 30), "%s: rows=%d too large for 32-bit offsets",
+                       what, t.rows);
+        TSPGNN_REQUIRE(t.dx >= 0 && t.dx % 32 == 0, "%s: dx=%d must be a non-negative multiple of 32", what, t.dx);
+        TSPGNN_REQUIRE(tasks[k].mlp_layers >= 0 && tasks[k].mlp_layers <= 4, "%s: mlp_layers=%d must be in 0..4", what,
+                       tasks[k].mlp_layers);
+        if (t.rows == 0) continue;
+        TSPGNN_REQUIRE(t.h && t.c && t.K && t.ln && t.h_out && t.c_out && (t.dx == 0 || t.x), "%s: null pointer", what);
+        TSPGNN_REQUIRE(t.h_out != t.h && t.c_out != t.c, "%s: outputs may not alias inputs", what);
+        TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx), "%s: gather-init mode needs dx == 0 and Zx", what);
+        TSPGNN_REQUIRE(!t.zbias || (t.zscale && !t.uv), "%s: zbias needs zscale and excludes gather-init mode", what);
+        TSPGNN_REQUIRE(tasks[k].mlp_layers == 0 || tasks[k].mlp_wb, "%s: mlp_layers > 0 needs mlp_wb", what);
+        TSPGNN_REQUIRE(!tasks[k].proj_w || (tasks[k].proj_out && tasks[k].mlp_layers > 0),
+                       "%s: a projection needs proj_out and at least one MLP layer", what);
+        live[n++] = tasks[k];
+    }
+    if (n == 0) return TSPGNN_OK;
+    return d == 32 ? launch_cell_h2<32>(live, n, as_stream(stream), what) : launch_cell_h2<64>(live, n, as_stream(stream), what);
+}
+
+extern "C" int tspgnn_lnlstm_mlp_fwd_multi_h2(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream) {
+    return cell_mlp_h2(tasks, n_tasks, d, stream, "tspgnn_lnlstm_mlp_fwd_multi_h2");
+}
+
+extern "C" int tspgnn_lnlstm_fwd_multi_h2(const tspgnn_lstm_task* tasks, int n_tasks, int d, void* stream) {
+    TSPGNN_REQUIRE(tasks && n_tasks >= 1 && n_tasks <= kMaxTasksH2, "lnlstm_fwd_multi_h2: 1..%d tasks", kMaxTasksH2);
+    tspgnn_cell_mlp_task wrapped[kMaxTasksH2];
+    for (int k = 0; k < n_tasks; ++k) {
+        wrapped[k] = tspgnn_cell_mlp_task{};
+        wrapped[k].cell = tasks[k];
+    }
+    return cell_mlp_h2(wrapped, n_tasks, d, stream, "tspgnn_lnlstm_fwd_multi_h2");
+}

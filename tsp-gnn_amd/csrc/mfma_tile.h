@@ -95,7 +95,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 template <int TPG>
-__device__ __forceinline__ void ln_gate(f32x4 (&v)[TPG], const float* gamma, const float* beta, int g, int D) {
+__device__ __forceinline__ void ln_gate(f32x4 (&v)[TPG], const float* gamma, const float* beta, int g, int D,
+                                        float eps = 1e-12f) {
     f32x2 s2 = v[0].lo + v[0].hi;
 #pragma unroll
     for (int t = 1; t < TPG; ++t) s2 += v[t].lo + v[t].hi;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void ln_gate(f32x4 (&v)[TPG], const float* gamma, con
         v[t].hi = b;
     }
     const float var = sum_over_lane_groups16(q2[0] + q2[1]) * (1.0f / (float)D);
-    const float rstd = __builtin_amdgcn_rsqf(var + 1e-12f);  // v_rsq_f32, ~1 ulp
+    const float rstd = __builtin_amdgcn_rsqf(var + eps);  // v_rsq_f32, ~1 ulp
     const f32x2 r2 = {rstd, rstd};
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
@@ -132,12 +133,23 @@ __device__ __forceinline__ f32x2 sigmoid2(f32x2 x, float shift = 0.f) {
     return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
 __device__ __forceinline__ f32x2 relu2(f32x2 x) { return f32x2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)}; }
+// the same on an argument that already is t = -log2(e) * (x + shift): 1 / (1 + 2^t)
+__device__ __forceinline__ f32x2 sigmoid2_pre(f32x2 t) {
+    const f32x2 one = {1.f, 1.f};
+    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    const f32x2 d = e + one;
+    return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
 
 // The cell arithmetic on the lane's part of a 16-row tile.  acc = z in the kernel's column order i, j, f, o (TPG
 // tiles each); cf = old c.  LN each gate; c' = LN_s(c*sig(f+1) + sig(i)*relu(j)); h' = relu(c')*sig(o); stores.
-template <int D>
+// PRE: lds_ln holds the gamma / beta of the gates i, f, o already multiplied by -log2(e) (and the forget bias folded into
+// beta_f), so their LayerNorm output is the exponent of the sigmoid directly -- one packed multiply-add per pair less;
+// eps_z: the epsilon of the four gate LayerNorms (a caller whose z is scaled by 2^s passes 2^2s * 1e-12, which makes
+// the normalised gates those of the unscaled z exactly -- a power-of-two scale commutes with every rounding).
+template <int D, bool PRE = false>
 __device__ __forceinline__ void lstm_gates(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 16], const float* lds_ln, int g,
-                                           f32x4 (&hn)[D / 16], f32x4 (&nc)[D / 16]) {
+                                           f32x4 (&hn)[D / 16], f32x4 (&nc)[D / 16], float eps_z = 1e-12f) {
     constexpr int TPG = D / 16;
     f32x4 gi[TPG], gj[TPG], gf[TPG], go[TPG];
 #pragma unroll
@@ -147,20 +159,30 @@ __device__ __forceinline__ void lstm_gates(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 
         gf[t] = acc[2 * TPG + t];
         go[t] = acc[3 * TPG + t];
     }
-    ln_gate<TPG>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D);
-    ln_gate<TPG>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D);
-    ln_gate<TPG>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D);
-    ln_gate<TPG>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D);
+    ln_gate<TPG>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D, eps_z);
+    ln_gate<TPG>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D, eps_z);
+    ln_gate<TPG>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D, eps_z);
+    ln_gate<TPG>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D, eps_z);
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
-        nc[t].lo = fma2(sigmoid2(gi[t].lo), relu2(gj[t].lo), cf[t].lo * sigmoid2(gf[t].lo, 1.0f));
-        nc[t].hi = fma2(sigmoid2(gi[t].hi), relu2(gj[t].hi), cf[t].hi * sigmoid2(gf[t].hi, 1.0f));
+        if constexpr (PRE) {
+            nc[t].lo = fma2(sigmoid2_pre(gi[t].lo), relu2(gj[t].lo), cf[t].lo * sigmoid2_pre(gf[t].lo));
+            nc[t].hi = fma2(sigmoid2_pre(gi[t].hi), relu2(gj[t].hi), cf[t].hi * sigmoid2_pre(gf[t].hi));
+        } else {
+            nc[t].lo = fma2(sigmoid2(gi[t].lo), relu2(gj[t].lo), cf[t].lo * sigmoid2(gf[t].lo, 1.0f));
+            nc[t].hi = fma2(sigmoid2(gi[t].hi), relu2(gj[t].hi), cf[t].hi * sigmoid2(gf[t].hi, 1.0f));
+        }
     }
     ln_gate<TPG>(nc, lds_ln + 8 * D, lds_ln + 9 * D, g, D);
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
-        hn[t].lo = relu2(nc[t].lo) * sigmoid2(go[t].lo);
-        hn[t].hi = relu2(nc[t].hi) * sigmoid2(go[t].hi);
+        if constexpr (PRE) {
+            hn[t].lo = relu2(nc[t].lo) * sigmoid2_pre(go[t].lo);
+            hn[t].hi = relu2(nc[t].hi) * sigmoid2_pre(go[t].hi);
+        } else {
+            hn[t].lo = relu2(nc[t].lo) * sigmoid2(go[t].lo);
+            hn[t].hi = relu2(nc[t].hi) * sigmoid2(go[t].hi);
+        }
     }
 }
 

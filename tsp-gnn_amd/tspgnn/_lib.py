@@ -37,6 +37,10 @@ SIGNATURES = {
     "tspgnn_mlp_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_mlp_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_pack_weights_h2": [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_mlp_fwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_lnlstm_fwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_lnlstm_mlp_fwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_bwd_finish_f32": [c_void_p, c_void_p, c_int, c_void_p],
     "tspgnn_mlp_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
@@ -144,6 +148,8 @@ def _load():
     lib.tspgnn_version.argtypes = []
     lib.tspgnn_last_error.restype = c_char_p
     lib.tspgnn_last_error.argtypes = []
+    lib.tspgnn_h2_weight_scale.restype = c_float
+    lib.tspgnn_h2_weight_scale.argtypes = []
     if lib.tspgnn_version() != ABI_VERSION:
         raise ImportError("libtspgnn.so ABI %d != binding ABI %d" % (lib.tspgnn_version(), ABI_VERSION))
     for name, argtypes in SIGNATURES.items():

@@ -29,6 +29,11 @@ LSTMStateTuple = namedtuple("LSTMStateTuple", ("c", "h"))
 LN_GATES = ("input", "transform", "forget", "output", "state")
 
 
+# GraphNN.gemm -> suffix of the split-operand entry points (None: the fp32-MFMA kernels) and bytes per packed weight
+GEMM_ARITH = {"f16x2": "h2", "bf16x3": "x3", "f32": None}
+SPLIT_BYTES = {"x3": 6, "h2": 4}
+
+
 def _dev_i32(a, device):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
 
@@ -206,16 +211,20 @@ class LayerNormBasicLSTMCell(object):
             return out
         return self.store.packed((key, self.base), build)
 
-    def _packed_x3(self, key, rows_lo, rows_hi):
-        """bf16x3 packing (tspgnn_pack_weights_x3) of kernel rows [rows_lo, rows_hi) as a byte tensor."""
+    def _packed_split(self, arith, key, rows_lo, rows_hi):
+        """Split-operand packing of kernel rows [rows_lo, rows_hi) as a byte tensor: ``arith`` = "x3" (three bf16
+        pieces, tspgnn_pack_weights_x3) or "h2" (two fp16 pieces of 2^s K, tspgnn_pack_weights_h2)."""
         def build(out):
             K = self.kernel()[rows_lo:rows_hi]
             if out is None:
-                out = torch.empty(6 * K.numel(), dtype=torch.uint8, device=K.device)
-            _lib.call("tspgnn_pack_weights_x3", _lib.ptr(K), _lib.ptr(out), rows_hi - rows_lo, 4 * self.d,
+                out = torch.empty(SPLIT_BYTES[arith] * K.numel(), dtype=torch.uint8, device=K.device)
+            _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(K), _lib.ptr(out), rows_hi - rows_lo, 4 * self.d,
                       _lib.current_stream())
             return out
-        return self.store.packed((key, self.base), build)
+        return self.store.packed((key + "." + arith, self.base), build)
+
+    def _packed_x3(self, key, rows_lo, rows_hi):
+        return self._packed_split("x3", key, rows_lo, rows_hi)
 
     def _packed_bf16(self, key, rows_lo, rows_hi):
         """Kernel rows [rows_lo, rows_hi) rounded to bf16 in MFMA fragment order: piece 0 of the bf16x3 packing."""
@@ -234,7 +243,7 @@ class LayerNormBasicLSTMCell(object):
                               _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], _lib.ptr(adj.uv), _lib.ptr(zx))
 
     def x3_ok(self):
-        """The bf16x3 cell kernel covers this shape (tspgnn_lnlstm_fwd_multi_x3)."""
+        """The split-operand cell kernels cover this shape (tspgnn_lnlstm_fwd_multi_x3 / _h2)."""
         return self.d in (32, 64) and self.dx % 32 == 0
 
     def kx_packed(self):
@@ -249,19 +258,19 @@ class LayerNormBasicLSTMCell(object):
     def kh_t_packed(self):
         return self._packed_slice("lstm.khT", self.dx, self.dx + self.d, True)
 
-    def task(self, x, state, out, x3=False):
-        K = self._packed_x3("lstm.x3", 0, self.dx + self.d) if x3 else self.kernel_packed()
+    def task(self, x, state, out, arith=None):
+        K = self._packed_split(arith, "lstm", 0, self.dx + self.d) if arith else self.kernel_packed()
         return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(K),
                              _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None,
                              None, None)
 
-    def gather_task(self, adj, zx, state, out, x3=False):
-        K = self._packed_x3("lstm.kh.x3", self.dx, self.dx + self.d) if x3 else self.kh_packed()
+    def gather_task(self, adj, zx, state, out, arith=None):
+        K = self._packed_split(arith, "lstm.kh", self.dx, self.dx + self.d) if arith else self.kh_packed()
         return _lib.LstmTask(None, 0, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(K),
                              _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0],
                              _lib.ptr(adj.uv), _lib.ptr(zx), None, None)
 
-    def pushed_bias_pack(self, mlp, x3=False):
+    def pushed_bias_pack(self, mlp, arith=None):
         """For a cell whose input is a row-sum aggregation of ``mlp``'s output: the message MLP's last
         (linear) layer W,b pushed through the aggregation and through Kx:
             (sum_e (a_e W + b)) Kx = (sum_e a_e) (W Kx) + degree (b Kx)
@@ -273,7 +282,7 @@ class LayerNormBasicLSTMCell(object):
         def build(out):
             W, b = self.store.view(last + "/kernel"), self.store.view(last + "/bias")
             if out is None:
-                kp = torch.empty(6 * (dx + d) * 4 * d, dtype=torch.uint8, device=W.device) if x3 \
+                kp = torch.empty(SPLIT_BYTES[arith] * (dx + d) * 4 * d, dtype=torch.uint8, device=W.device) if arith \
                     else torch.empty((dx + d, 4 * d), dtype=torch.float32, device=W.device)
                 out = (kp, torch.empty((1, 4 * d), dtype=torch.float32, device=W.device))
             kp, zb = out
@@ -284,24 +293,26 @@ class LayerNormBasicLSTMCell(object):
                       4 * d, 0, W.shape[0], st)
             _lib.call("tspgnn_linear_f32", _lib.ptr(b.view(1, -1)), dx, _lib.ptr(self.kx_packed()), None, 0, _lib.ptr(zb),
                       4 * d, 0, 1, st)
-            if x3:
-                _lib.call("tspgnn_pack_weights_x3", _lib.ptr(kfull), _lib.ptr(kp), dx + d, 4 * d, st)
+            if arith:
+                _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(kfull), _lib.ptr(kp), dx + d, 4 * d, st)
             else:
                 _lib.call("tspgnn_pack_weights_f32", _lib.ptr(kfull), _lib.ptr(kp), dx + d, 4 * d, 0, st)
             return (kp, zb)
-        return self.store.packed(("lstm.pushed.x3" if x3 else "lstm.pushed", self.base, last), build)
+        return self.store.packed(("lstm.pushed." + (arith or "f32"), self.base, last), build)
 
     def pushed_task(self, x, state, out, kp, zb, deg):
         """Cell task whose kernel operand is pushed_bias_pack's K' (either packing) and z starts at deg * zb."""
         return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(kp), _lib.ptr(self.ln()),
                              _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None, _lib.ptr(zb), _lib.ptr(deg))
 
-    def premultiply(self, y, out=None):
-        """Zx = y Kx  ([n_src, 4d])."""
+    def premultiply(self, y, out=None, scale=None):
+        """Zx = y Kx  ([n_src, 4d]); ``scale``: times 2^s for an f16x2 cell, whose z carries that factor."""
         if out is None:
             out = torch.empty((y.shape[0], 4 * self.d), dtype=torch.float32, device=y.device)
         _lib.call("tspgnn_linear_f32", _lib.ptr(y), self.dx, _lib.ptr(self.kx_packed()), None, 0, _lib.ptr(out),
                   4 * self.d, 0, y.shape[0], _lib.current_stream())
+        if scale is not None:
+            out.mul_(scale)
         return out
 
     def gather_call(self, adj, zx, state, out=None):
@@ -418,12 +429,13 @@ class GraphNN(object):
         self.float_dtype = float_dtype
         self.store = store if store is not None else V.get_default_store()
         self.fold_adjacency = True   # (EV y) Kx = EV (y Kx) fast path; False = op-for-op reference order
-        # GEMM arithmetic of the inference forward: "bf16x3" = bf16 matrix cores on exact three-way splits of
-        # the fp32 operands (fp32-class accuracy, see csrc/dense_x3.hip); "f32" = fp32 MFMA.  TSPGNN_GEMM=f32
-        # in the environment selects the latter; shapes the x3 kernels do not cover fall back to it as well.
-        self.gemm = os.environ.get("TSPGNN_GEMM", "bf16x3")
-        if self.gemm not in ("bf16x3", "f32"):
-            raise ValueError("TSPGNN_GEMM must be 'bf16x3' or 'f32', got %r" % self.gemm)
+        # GEMM arithmetic of the inference forward, all fp32-class in accuracy: "f16x2" = fp16 matrix cores on
+        # two-piece splits of the fp32 operands (csrc/dense_h2.hip, the default); "bf16x3" = bf16 matrix cores on
+        # exact three-piece splits (csrc/dense_x3.hip); "f32" = fp32 MFMA.  TSPGNN_GEMM in the environment selects
+        # one; shapes the split kernels do not cover fall back to "f32".
+        self.gemm = os.environ.get("TSPGNN_GEMM", "f16x2")
+        if self.gemm not in GEMM_ARITH:
+            raise ValueError("TSPGNN_GEMM must be one of %s, got %r" % (sorted(GEMM_ARITH), self.gemm))
         self.check_model()
         self._init_parameters()
 
@@ -631,7 +643,7 @@ class GraphNN(object):
                         if folded[v] is not None:
                             cv = self._RNN_cells[v]
                             zxs[v] = torch.empty((y.shape[0], 4 * self.var[v]), **bf)
-                            pw, po = cv._packed_bf16("lstm.kx.x3", 0, cv.dx), zxs[v]
+                            pw, po = cv._packed_bf16("lstm.kx", 0, cv.dx), zxs[v]
                         n = mlp.n_square
                         mlp_tasks.setdefault(d, []).append(_lib.MlpTaskB(
                             _lib.ptr(y), _lib.ptr(mlp.wb_packed_bf16(0, n - 1, d)), _lib.ptr(out), y.shape[0], n,
@@ -682,13 +694,16 @@ class GraphNN(object):
                 _lib.call_multi("tspgnn_lnlstm_fwd_multi_bf16", arr, d)
         return buf[T & 1]
 
-    def _x3_ok(self, n_rows=None):
-        """The bf16x3 kernels cover this network (widths 32/64, cell inputs in multiples of 32) and, when the row
-        counts are given, this batch (they address rows with 32-bit element offsets: rows * 4d < 2^30)."""
+    def _split_arith(self, n_rows=None):
+        """"h2" / "x3" when the selected split-operand kernels cover this network (widths 32/64, cell inputs in
+        multiples of 32) and, when the row counts are given, this batch (they address rows with 32-bit element
+        offsets: rows * 4d < 2^30); None = the fp32-MFMA kernels."""
         if n_rows is not None and any(int(n) * 4 * self.var[v] >= 2 ** 30 for v, n in n_rows.items()):
-            return False
-        return self.gemm == "bf16x3" and all(c.x3_ok() for c in self._RNN_cells.values()) \
-            and all(m.sizes[-1] in (32, 64) for m in self._msg_MLPs.values())
+            return None
+        if GEMM_ARITH[self.gemm] and all(c.x3_ok() for c in self._RNN_cells.values()) \
+                and all(m.sizes[-1] in (32, 64) for m in self._msg_MLPs.values()):
+            return GEMM_ARITH[self.gemm]
+        return None
 
     def _plan_fused(self, states, mats, folded):
         """bf16x3 plan with every message MLP fused behind the cell of its SOURCE variable: the launch that
@@ -697,7 +712,8 @@ class GraphNN(object):
         cell+message launch}.  The messages of step 0 come from one plain MLP launch, the last step runs
         the cells alone.  Applies when every variable's h feeds exactly one loop entry and that entry has a
         single-kernel message MLP; returns run(T) -> states, or None."""
-        if not self._x3_ok({v: st.h.shape[0] for v, st in states.items()}):
+        arith = self._split_arith({v: st.h.shape[0] for v, st in states.items()})
+        if arith is None:
             return None
         consumers = {u: [] for u in self.var}
         for v in self.var:
@@ -736,9 +752,9 @@ class GraphNN(object):
             pw = po = None
             if folded[v] is not None:
                 cv = self._RNN_cells[v]
-                pw, po = cv._packed_x3("lstm.kx.x3", 0, cv.dx), zxs[p][v]
+                pw, po = cv._packed_split(arith, "lstm.kx", 0, cv.dx), zxs[p][v]
             out = mo[p].get((v, i))
-            return (mlp.wb_packed_x3(0, n - 1, d), n, mlp.relu_mask(0, n), out, pw, po)
+            return (mlp.wb_packed_split(arith, 0, n - 1, d), n, mlp.relu_mask(0, n), out, pw, po)
 
         def cell_tasks(p, with_messages):
             src, dst = buf[p], buf[1 - p]
@@ -747,7 +763,7 @@ class GraphNN(object):
                 cell, st = self._RNN_cells[v], src[v]
                 out = (dst[v].h, dst[v].c)
                 if folded[v] is not None:
-                    t = cell.gather_task(mats[folded[v]["mat"]], zxs[p][v], st, out, x3=True)
+                    t = cell.gather_task(mats[folded[v]["mat"]], zxs[p][v], st, out, arith=arith)
                 else:
                     inputs = []
                     for i, u in enumerate(self.loop[v]):
@@ -768,13 +784,13 @@ class GraphNN(object):
                     keep.append(x)
                     if pushed[v]:
                         u0 = self.loop[v][0]
-                        kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], x3=True)
+                        kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], arith=arith)
                         rowptr = (mats[u0["mat"]].csr_t if u0.get("transpose?", False) else mats[u0["mat"]].csr)[0]
                         deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
                         keep.append(deg)
                         t = cell.pushed_task(x, st, out, kp, zb, deg)
                     else:
-                        t = cell.task(x, st, out, x3=True)
+                        t = cell.task(x, st, out, arith=arith)
                 if with_messages:   # the message MLP that reads this variable's new h in the next step
                     (cv, ci), = consumers[v]
                     wb, n, mask, mout, pw, po = message(cv, ci, 1 - p)
@@ -804,13 +820,13 @@ class GraphNN(object):
 
         def run(T):
             for arr, d in pre_calls:
-                _lib.call_multi("tspgnn_mlp_fwd_multi_x3", arr, d)
+                _lib.call_multi("tspgnn_mlp_fwd_multi_" + arith, arr, d)
             for t in range(T):
                 mid, calls = (steps if t < T - 1 else lasts)[t & 1]
                 for fn, args in mid:
                     fn(*args)
                 for arr, d in calls:
-                    _lib.call_multi("tspgnn_lnlstm_mlp_fwd_multi_x3", arr, d)
+                    _lib.call_multi("tspgnn_lnlstm_mlp_fwd_multi_" + arith, arr, d)
             return buf[T & 1]
         return run
 
@@ -831,7 +847,8 @@ class GraphNN(object):
         buf = [{v: LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) for v, st in states.items()},
                {v: LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h)) for v, st in states.items()}]
         runs, keep = [], []
-        x3 = self._x3_ok({v: st.h.shape[0] for v, st in states.items()})
+        arith = self._split_arith({v: st.h.shape[0] for v, st in states.items()})
+        zx_scale = _lib.lib.tspgnn_h2_weight_scale() if arith == "h2" else None
         for p in (0, 1):
             src_states, dst_states = buf[p], buf[1 - p]
             mlp_tasks, lstm_tasks, mid, msg_out, zxs = {}, {}, [], {}, {}
@@ -843,15 +860,15 @@ class GraphNN(object):
                         mlp = self._msg_MLPs[u["msg"]]
                         out = torch.empty((y.shape[0], mlp.sizes[-1]), **f32)
                         if pushed[v]:   # last hidden activation only; the last layer is folded into the cell
-                            mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.prefix_task(y, out, mlp.n_square - 1, x3=x3))
+                            mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.prefix_task(y, out, mlp.n_square - 1, arith=arith))
                             msg_out[(v, i)] = out
                             continue
                         proj = None
                         if folded[v] is not None:   # Zx = msg(y) Kx rides in the MLP launch
                             zxs[v] = torch.empty((y.shape[0], 4 * self.var[v]), **f32)
                             cv = self._RNN_cells[v]
-                            proj = (cv._packed_x3("lstm.kx.x3", 0, cv.dx) if x3 else cv.kx_packed(), zxs[v])
-                        mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.task(y, out, proj=proj, x3=x3))
+                            proj = (cv._packed_split(arith, "lstm.kx", 0, cv.dx) if arith else cv.kx_packed(), zxs[v])
+                        mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.task(y, out, proj=proj, arith=arith))
                         y = out
                     msg_out[(v, i)] = y
             for v, d in self.var.items():
@@ -862,8 +879,8 @@ class GraphNN(object):
                         zx = zxs[v]
                     else:
                         zx = torch.empty((msg_out[(v, 0)].shape[0], 4 * d), **f32)
-                        mid.append((cell.premultiply, (msg_out[(v, 0)], zx)))
-                    lstm_tasks.setdefault(d, []).append(cell.gather_task(mats[folded[v]["mat"]], zx, st, out, x3=x3))
+                        mid.append((cell.premultiply, (msg_out[(v, 0)], zx, zx_scale)))
+                    lstm_tasks.setdefault(d, []).append(cell.gather_task(mats[folded[v]["mat"]], zx, st, out, arith=arith))
                     keep.append(zx)
                     continue
                 inputs = []
@@ -884,21 +901,21 @@ class GraphNN(object):
                     raise ValueError("cell input must be [%d,%d], got %s" % (st.h.shape[0], cell.dx, tuple(x.shape)))
                 if pushed[v]:
                     u0 = self.loop[v][0]
-                    kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], x3=x3)
+                    kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], arith=arith)
                     rowptr = (mats[u0["mat"]].csr_t if u0.get("transpose?", False) else mats[u0["mat"]].csr)[0]
                     deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
                     lstm_tasks.setdefault(d, []).append(cell.pushed_task(x, st, out, kp, zb, deg))
                     keep.append(deg)
                 else:
-                    lstm_tasks.setdefault(d, []).append(cell.task(x, st, out, x3=x3))
+                    lstm_tasks.setdefault(d, []).append(cell.task(x, st, out, arith=arith))
                 keep.append(x)
             keep.append(msg_out)
 
             mlp_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in mlp_tasks.items() for k in range(0, len(ts), 4)]
             lstm_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in lstm_tasks.items() for k in range(0, len(ts), 4)]
 
-            mlp_fn = "tspgnn_mlp_fwd_multi_x3" if x3 else "tspgnn_mlp_fwd_multi_f32"
-            lstm_fn = "tspgnn_lnlstm_fwd_multi_x3" if x3 else "tspgnn_lnlstm_fwd_multi_f32"
+            mlp_fn = "tspgnn_mlp_fwd_multi_" + (arith or "f32")
+            lstm_fn = "tspgnn_lnlstm_fwd_multi_" + (arith or "f32")
 
             def run(mlp_calls=mlp_calls, mid=mid, lstm_calls=lstm_calls, mlp_fn=mlp_fn, lstm_fn=lstm_fn):
                 for arr, d in mlp_calls:
@@ -1012,9 +1029,11 @@ class GraphNN(object):
                 tape.ZX[v] = torch.empty((T, rows_x, 4 * self.var[v]), **f32)
         tape.acts = {}
         # forward GEMMs on the bf16 matrix cores (fp32-class accuracy); backward stays fp32 MFMA
-        x3 = self._x3_ok({v: initial_embeddings[v].shape[0] for v in self.var})
-        mlp_fn = "tspgnn_mlp_fwd_multi_x3" if x3 else "tspgnn_mlp_fwd_multi_f32"
-        lstm_fn = "tspgnn_lnlstm_fwd_multi_x3" if x3 else "tspgnn_lnlstm_fwd_multi_f32"
+        # (bf16x3 also when the inference arithmetic is f16x2: the tape's projected messages ZX feed the fp32 backward
+        # kernels, which recompute z from them unscaled)
+        arith = "x3" if self._split_arith({v: initial_embeddings[v].shape[0] for v in self.var}) else None
+        mlp_fn = "tspgnn_mlp_fwd_multi_" + (arith or "f32")
+        lstm_fn = "tspgnn_lnlstm_fwd_multi_" + (arith or "f32")
         for v in self.var:
             tape.H[v][0].copy_(initial_embeddings[v])
             tape.C[v][0].zero_()
@@ -1039,10 +1058,10 @@ class GraphNN(object):
                         proj = None
                         if tape.folded[v] is not None:
                             cv = self._RNN_cells[v]
-                            proj = (cv._packed_x3("lstm.kx.x3", 0, cv.dx) if x3 else cv.kx_packed(), tape.ZX[v][t])
-                        task = mlp.task(y, out, acts[:, t], acts.stride(0), proj=proj, x3=x3)
+                            proj = (cv._packed_split(arith, "lstm.kx", 0, cv.dx) if arith else cv.kx_packed(), tape.ZX[v][t])
+                        task = mlp.task(y, out, acts[:, t], acts.stride(0), proj=proj, arith=arith)
                         if task is None:
-                            if x3:
+                            if arith:
                                 raise NotImplementedError("bf16x3 training forward needs single-kernel message MLPs")
                             mlp.forward_saving(y, out, acts[:, t], acts.stride(0))
                             if proj is not None:
@@ -1081,9 +1100,9 @@ class GraphNN(object):
                 st = LSTMStateTuple(c=tape.C[v][t], h=tape.H[v][t])
                 out = (tape.H[v][t + 1], tape.C[v][t + 1])
                 if tape.folded[v] is not None:
-                    task = cell.gather_task(mats[tape.folded[v]["mat"]], tape.ZX[v][t], st, out, x3=x3)
+                    task = cell.gather_task(mats[tape.folded[v]["mat"]], tape.ZX[v][t], st, out, arith=arith)
                 else:
-                    task = cell.task(tape.X[v][t], st, out, x3=x3)
+                    task = cell.task(tape.X[v][t], st, out, arith=arith)
                 lstm_tasks.setdefault(d, []).append(task)
             for d, ts in lstm_tasks.items():
                 for k in range(0, len(ts), 4):

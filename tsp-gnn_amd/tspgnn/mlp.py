@@ -104,21 +104,30 @@ class Mlp(object):
             return out
         return self.store.packed(("mlp", self.name, first, last), build)
 
-    def wb_packed_x3(self, first, last, d):
-        """Byte tensor of {bf16x3 pack(W) [3*d*d*2 B], b [d*4 B]} per square layer first..last
-        (tspgnn_pack_weights_x3) for the bf16x3 kernels, cached until the variables change."""
+    def wb_packed_split(self, arith, first, last, d):
+        """Byte tensor of {split pack(W), bias [d*4 B]} per square layer first..last for the split-operand kernels,
+        cached until the variables change.  ``arith`` = "x3": three bf16 pieces (3*d*d*2 B, tspgnn_pack_weights_x3);
+        "h2": two fp16 pieces of 2^s W (2*d*d*2 B, tspgnn_pack_weights_h2) next to 2^s b."""
+        nb = {"x3": 6, "h2": 4}[arith]
+
         def build(out):
             src = self.wb(first, last)
-            per_src, per = d * d + d, 6 * d * d + 4 * d
+            per_src, per = d * d + d, nb * d * d + 4 * d
             if out is None:
                 out = torch.empty((last - first + 1) * per, dtype=torch.uint8, device=src.device)
             st = _lib.current_stream()
             for j in range(last - first + 1):
                 o, q = j * per_src, j * per
-                _lib.call("tspgnn_pack_weights_x3", _lib.ptr(src[o:o + d * d]), _lib.ptr(out[q:q + 6 * d * d]), d, d, st)
-                out[q + 6 * d * d:q + per].copy_(src[o + d * d:o + per_src].view(torch.uint8))
+                _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(src[o:o + d * d]), _lib.ptr(out[q:q + nb * d * d]), d, d, st)
+                bias = src[o + d * d:o + per_src]
+                if arith == "h2":
+                    bias = bias * _lib.lib.tspgnn_h2_weight_scale()
+                out[q + nb * d * d:q + per].copy_(bias.view(torch.uint8))
             return out
-        return self.store.packed(("mlp.x3", self.name, first, last), build)
+        return self.store.packed(("mlp." + arith, self.name, first, last), build)
+
+    def wb_packed_x3(self, first, last, d):
+        return self.wb_packed_split("x3", first, last, d)
 
     def wb_packed_bf16(self, first, last, d):
         """Byte tensor of {bf16 pack(W) [d*d*2 B] (weights rounded to bf16, fragment order), b [d*4 B]} per square
@@ -157,24 +166,25 @@ class Mlp(object):
                 mask |= 1 << j
         return mask
 
-    def task(self, x, out, acts=None, acts_stride=0, proj=None, x3=False):
+    def task(self, x, out, acts=None, acts_stride=0, proj=None, arith=None):
         """An _lib.MlpTask for a single-kernel square chain (None if this Mlp needs several kernels).
         ``proj`` = (packed [d,4d] matrix, output [rows,4d]): also emit out @ P from the same launch.
-        ``x3``: weights in the bf16x3 packing (for tspgnn_mlp_fwd_multi_x3; proj packed likewise)."""
+        ``arith``: "x3" / "h2" = weights in that split packing (for tspgnn_mlp_fwd_multi_x3 / _h2; proj packed
+        likewise)."""
         kind, d, n_sq, head = self._plan
         if kind != "square" or head or len(self._chunks()) != 1:
             return None
         pw, po = (proj if proj is not None else (None, None))
-        wb = self.wb_packed_x3(0, n_sq - 1, d) if x3 else self.wb_packed(0, n_sq - 1, d)
+        wb = self.wb_packed_split(arith, 0, n_sq - 1, d) if arith else self.wb_packed(0, n_sq - 1, d)
         return _lib.MlpTask(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(out), _lib.ptr(acts),
                             acts_stride, x.shape[0], n_sq, self.relu_mask(0, n_sq), _lib.ptr(pw), _lib.ptr(po))
 
-    def prefix_task(self, x, out, n_layers, x3=False):
+    def prefix_task(self, x, out, n_layers, arith=None):
         """Task running only the first ``n_layers`` square layers (the rest is folded elsewhere)."""
         kind, d, n_sq, head = self._plan
         if kind != "square" or head or len(self._chunks()) != 1 or not (1 <= n_layers <= n_sq):
             return None
-        wb = self.wb_packed_x3(0, n_layers - 1, d) if x3 else self.wb_packed(0, n_layers - 1, d)
+        wb = self.wb_packed_split(arith, 0, n_layers - 1, d) if arith else self.wb_packed(0, n_layers - 1, d)
         return _lib.MlpTask(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(out), None, 0,
                             x.shape[0], n_layers, self.relu_mask(0, n_layers), None, None)
 
@@ -243,17 +253,18 @@ class Mlp(object):
                       _lib.ptr(ws), st)
 
     # ------------------------------------------------------------------ forward
-    def forward_x3(self, x):
-        """Inference forward with the square layers on the bf16x3 kernel (fp32-class accuracy, see csrc/dense_x3.hip);
-        falls back to __call__ for shapes that kernel does not cover."""
+    def forward_split(self, x, arith="h2"):
+        """Inference forward with the square layers on a split-operand kernel (``arith`` = "h2" / "x3": fp32-class
+        accuracy on the fp16 / bf16 matrix cores, see csrc/dense_h2.hip, dense_x3.hip); falls back to __call__ for
+        shapes those kernels do not cover."""
         kind, d, n_sq, head = self._plan
         if kind != "square" or d not in (32, 64) or len(self._chunks()) != 1 or x.dtype != torch.float32 \
                 or not x.is_contiguous() or x.shape[1] != self.input_size:
             return self(x)
         out = torch.empty((x.shape[0], d), dtype=torch.float32, device=x.device)
-        task = _lib.MlpTask(_lib.ptr(x), _lib.ptr(self.wb_packed_x3(0, n_sq - 1, d)), _lib.ptr(out), None, 0, x.shape[0],
-                            n_sq, self.relu_mask(0, n_sq), None, None)
-        _lib.call_multi("tspgnn_mlp_fwd_multi_x3", [task], d)
+        task = _lib.MlpTask(_lib.ptr(x), _lib.ptr(self.wb_packed_split(arith, 0, n_sq - 1, d)), _lib.ptr(out), None, 0,
+                            x.shape[0], n_sq, self.relu_mask(0, n_sq), None, None)
+        _lib.call_multi("tspgnn_mlp_fwd_multi_" + arith, [task], d)
         if not head:
             return out
         y = torch.empty((x.shape[0], 1), dtype=torch.float32, device=x.device)
@@ -261,6 +272,9 @@ class Mlp(object):
         _lib.call("tspgnn_rowdot_f32", _lib.ptr(out), _lib.ptr(self.store.view(last + "/kernel")),
                   _lib.ptr(self.store.view(last + "/bias")), _lib.ptr(y), x.shape[0], d, _lib.current_stream())
         return y
+
+    def forward_x3(self, x):
+        return self.forward_split(x, "x3")
 
     def __call__(self, inputs, save=None):
         """inputs: fp32 device tensor [rows, input_size].  ``save`` (optional list) receives the

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from . import variables as V
-from .graphnn import GraphNN, LSTMStateTuple
+from .graphnn import GEMM_ARITH, GraphNN, LSTMStateTuple
 from .instance_loader import SparseEV
 from .mlp import Mlp
 
@@ -286,8 +286,8 @@ class Session(object):
                   _lib.ptr(V0), b.N, d, st)
         last = m["gnn"]({"EV": b.adj}, {"V": V0, "E": E0}, b.T)               # model.py:118-122
         Eh = last["E"].h.to(torch.float32)                                    # (bf16 storage: widened once)
-        vote_mlp = m.E_vote_MLP.forward_x3 if m["gnn"].gemm == "bf16x3" else m.E_vote_MLP
-        vote = vote_mlp(Eh).view(-1)                                          # model.py:128
+        arith = GEMM_ARITH[m["gnn"].gemm]
+        vote = (m.E_vote_MLP.forward_split(Eh, arith) if arith else m.E_vote_MLP(Eh)).view(-1)   # model.py:128
         logits = torch.empty(b.B, dtype=torch.float32, device=self.device)
         _lib.call("tspgnn_segment_mean_f32", _lib.ptr(vote), _lib.ptr(b.seg), _lib.ptr(logits), b.B, st)
         pred = torch.empty(b.B, dtype=torch.float32, device=self.device)
