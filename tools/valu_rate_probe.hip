@@ -87,6 +87,14 @@ __global__ __launch_bounds__(1024) void probe(float* __restrict__ out, int round
 #pragma unroll
                 for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[t], 0, 0, 0);
         }
+        if constexpr (KIND >= 20 && KIND <= 23) {  // dependent chains: 1, 2, 4 accumulators in rotation; 23: 3-chains per acc
+            constexpr int NA = KIND == 20 ? 1 : (KIND == 21 ? 2 : 4);
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                const int t = KIND == 23 ? (k / 3) % 8 : k % NA;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc[t], 0, 0, 0);
+            }
+        }
         if constexpr (KIND == 17) {  // 8 MFMA + 8 v_exp interleaved
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -171,5 +179,9 @@ int main() {
     run<17>("mfma_f16 + v_exp (per pair)", out, 64);
     run<18>("mfma_f16 + v_fma (per pair)", out, 64);
     run<19>("mfma_f16 + 4 v_fma (per group)", out, 64);
+    run<20>("mfma_f16 dependent chain (1 acc)", out, 64);
+    run<21>("mfma_f16 2 accs alternating", out, 64);
+    run<22>("mfma_f16 4 accs alternating", out, 64);
+    run<23>("mfma_f16 3-chains, 8 accs", out, 64);
     return 0;
 }

@@ -86,25 +86,37 @@ __device__ __forceinline__ f16x8 ldw(const _Float16* p) { return *reinterpret_ca
 // acc[t] += W-block(kb, all NT tiles) x B for one 32-feature k-block; wh / wl = the two pieces of the packed matrix
 // (LDS), (bh, bl) = split2 of the lane's eight B values.  The fragments of tile t+1 are fetched while the three
 // (dependent) MFMAs of tile t run.
+#ifndef H2_PF
+#define H2_PF 1   // fragment pairs in flight ahead of the MFMAs (2 and 3 measured slower: registers)
+#endif
+#ifndef H2_LN_SWAP
+#define H2_LN_SWAP 1
+#endif
 template <int NT>
 __device__ __forceinline__ void kblock_h2(f32x4 (&acc)[NT], const _Float16* wh, const _Float16* wl, int kb, int g, int jl,
                                           const f16x8& bh, const f16x8& bl) {
     const int off = ((kb * 4 + g) * NT * 16 + jl) * 8;
-    f16x8 ah = ldw(wh + off), al = ldw(wl + off);
+    // The fragments of the next PF tiles are in flight while the three MFMAs of this one run (the compiler interleaves
+    // the MFMA chains of neighbouring tiles on top of that).
+    constexpr int PF = H2_PF < NT ? H2_PF : NT;
+    f16x8 ah[PF + 1], al[PF + 1];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        ah[p] = ldw(wh + off + p * 128);
+        al[p] = ldw(wl + off + p * 128);
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        f16x8 nah = ah, nal = al;
-        if (t + 1 < NT) {
-            nah = ldw(wh + off + (t + 1) * 128);
-            nal = ldw(wl + off + (t + 1) * 128);
+        if (t + PF < NT) {
+            ah[(t + PF) % (PF + 1)] = ldw(wh + off + (t + PF) * 128);
+            al[(t + PF) % (PF + 1)] = ldw(wl + off + (t + PF) * 128);
         }
+        const f16x8 a_h = ah[t % (PF + 1)], a_l = al[t % (PF + 1)];
         f32x4 c = acc[t];
-        c = MFMA_F16(al, bh, c);  // smallest terms first
-        c = MFMA_F16(ah, bl, c);
-        c = MFMA_F16(ah, bh, c);
+        c = MFMA_F16(a_l, bh, c);  // smallest terms first
+        c = MFMA_F16(a_h, bl, c);
+        c = MFMA_F16(a_h, bh, c);
         acc[t] = c;
-        ah = nah;
-        al = nal;
     }
 }
 
@@ -265,13 +277,17 @@ __global__ __launch_bounds__(1024) void mlp_fwd_h2_kernel(const MlpTaskTableH2 t
 // NEXT time step (and its projection through the receiving cell's Kx), exactly as lnlstm_mlp_fwd_x3_kernel.
 //   resident mode  -- K and the MLP layers fit LDS together (Kh of the edge cell in gather-init mode + three layers:
 //     112 KB at D=64): staged once per workgroup; 16-row tiles are handed out by an LDS ticket.
-//   lock-step mode -- otherwise (the vertex cell's [2D,4D] + MLP + projection): K is streamed in k-block chunks, then
-//     the MLP weights, then the projection matrix are staged into the same LDS region, one tile per wavefront per
-//     round.
+//   lock-step mode -- otherwise (the vertex cell's [2D,4D] + MLP + projection): one tile per wavefront per round, the
+//     workgroup in lock step through two LDS residencies -- K (whole if it fits alone: 128 KB at D=64, else in
+//     k-block chunks), then the MLP layers together with the projection matrix (130 KB; one after the other when
+//     they do not fit together).  The second staging is issued as soon as the last wavefront has left the K GEMM
+//     and lands behind the LayerNorm / gate arithmetic.
 struct CellTaskTableH2 {
     tspgnn_cell_mlp_task task[kMaxTasksH2];
     int blk_end[kMaxTasksH2];
-    int kbc[kMaxTasksH2];  // k-blocks (32 rows of K) per LDS chunk; >= all of K: resident
+    int kbc[kMaxTasksH2];       // k-blocks (32 rows of K) per LDS chunk
+    int lockstep[kMaxTasksH2];  // 0: K and the MLP resident together, tiles by ticket; 1: lock-step rounds
+    int together[kMaxTasksH2];  // lock-step: MLP layers and projection matrix staged together
     int n;
 };
 
@@ -307,10 +323,10 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     const int tiles_total = (rows + 15) / 16;
     const int KBT = (dx + D) >> 5;       // k-blocks in total
     const int kbc = tt.kbc[k];
-    const bool resident = kbc >= KBT;
+    const bool resident = !tt.lockstep[k];
     const int KBX = dx >> 5;             // k-blocks that come from x
     const int total = (dx + D) * 4 * D;  // elements per piece of the whole matrix
-    const int chunk_total = (resident ? KBT : kbc) * 32 * 4 * D;
+    const int chunk_total = kbc * 32 * 4 * D;
 
     // LDS: [ln 10*D floats][ticket, pad][weights region]
     float* lds_ln = reinterpret_cast<float*>(ldsb);
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     // gates + state stores; returns h' in registers (the D layout is the next GEMM's B operand)
     auto cell = [&](f32x4 (&acc)[NT4], f32x4 (&cf)[TPG], unsigned rc, bool valid, f32x4 (&hn)[TPG]) {
         f32x4 nc[TPG];
-        lstm_gates<D, true>(acc, cf, lds_ln, g, hn, nc, kH2GateEps);
+        lstm_gates<D, true, H2_LN_SWAP != 0>(acc, cf, lds_ln, g, hn, nc, kH2GateEps);
         if (valid) {
             float* hd = h_out + (rc * D + g * 4);
             float* cd = c_out + (rc * D + g * 4);
@@ -423,7 +439,9 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
             }
         }
     } else {
-        // lock-step rounds: one tile per wavefront; K walked chunk by chunk, then the MLP, then the projection
+        // lock-step rounds: one tile per wavefront; K (whole or chunk by chunk), then the MLP + the projection
+        const bool together = tt.together[k] != 0;
+        unsigned char* lds_proj = together ? lds_wb + (size_t)n_layers * LAYER_BYTES : lds_wb;
         const int rounds = (tiles_total + nw - 1) / nw;
         for (int r = my_blk; r < rounds; r += my_grid) {
             const int tile = r * nw + wave;
@@ -445,11 +463,14 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                     __syncthreads();
                     if (live) kloop(acc, rc, kb0, kb0, kb1);
                 }
+                if (n_layers > 0) {  // every wavefront is done with K: the next residency loads behind the gates
+                    __syncthreads();
+                    h2_copy_to_lds(lds_wb, mlp_wb, n_layers * LAYER_BYTES, tid, blockDim.x);
+                    if (proj_w != nullptr && together) h2_copy_to_lds(lds_proj, proj_w, 2 * D * 4 * D * 2, tid, blockDim.x);
+                }
                 cell(acc, cf, rc, valid, hn);
             }
             if (n_layers > 0) {
-                __syncthreads();
-                h2_copy_to_lds(lds_wb, mlp_wb, n_layers * LAYER_BYTES, tid, blockDim.x);
                 h2_stage_wait();
                 __syncthreads();
                 for (int l = 0; l < n_layers; ++l) {
@@ -462,10 +483,13 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                     for (int t = 0; t < TPG; ++t) st4(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
                 if (proj_w != nullptr) {  // proj_out = 2^s mlp(h') P, P packed [D, 4D]
-                    __syncthreads();
-                    h2_copy_to_lds(lds_wb, proj_w, 2 * D * 4 * D * 2, tid, blockDim.x);
-                    h2_stage_wait();
-                    __syncthreads();
+                    if (!together) {
+                        __syncthreads();
+                        h2_copy_to_lds(lds_proj, proj_w, 2 * D * 4 * D * 2, tid, blockDim.x);
+                        h2_stage_wait();
+                        __syncthreads();
+                    }
+                    const _Float16* wp = reinterpret_cast<const _Float16*>(lds_proj);
                     f32x4 acc[NT4];
 #pragma unroll
                     for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -476,7 +500,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                         for (int j = 0; j < 8; ++j) xv[j] = hn[2 * kb + (j >> 2)][j & 3];
                         f16x8 bh, bl;
                         split2(xv, bh, bl);
-                        kblock_h2<NT4>(acc, lds_w, lds_w + D * 4 * D, kb, g, rl, bh, bl);
+                        kblock_h2<NT4>(acc, wp, wp + D * 4 * D, kb, g, rl, bh, bl);
                     }
                     if (valid) {
 #pragma unroll
@@ -526,12 +550,12 @@ static int launch_mlp_h2(const tspgnn_mlp_task* tasks, int n, hipStream_t st) {
 }
 
 // Wavefronts per workgroup of the cell launch.  The kernel is compiled for 12 (<= 168 registers) and for 16
-// (<= 128 registers) wavefronts; TSPGNN_H2_WAVES picks one (development switch, default below).
+// (<= 128 registers) wavefronts; TSPGNN_H2_WAVES picks one (development switch; 16 measured 3-4 % faster at C2).
 static int h2_cell_waves() {
     static const int nw = [] {
         const char* e = getenv("TSPGNN_H2_WAVES");
         const int v = e ? atoi(e) : 0;
-        return (v == 12 || v == 16) ? v : 12;
+        return (v == 12 || v == 16) ? v : 16;
     }();
     return nw;
 }
@@ -553,18 +577,28 @@ static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
         const int KBT = (c.dx + D) / 32;
         const size_t k_bytes = (size_t)KBT * per_kb;
         size_t need;
+        tt.together[k] = 0;
         if (k_bytes + L * layer_all <= budget && !tasks[k].proj_w) {
             tt.kbc[k] = KBT;
+            tt.lockstep[k] = 0;
             need = k_bytes + L * layer_all;
         } else {
-            int kbc = k_bytes <= budget ? KBT : (int)(budget / per_kb);
-            if (kbc >= KBT) kbc = KBT - 1;  // lock-step mode is selected by kbc < KBT
+            const int kbc = k_bytes <= budget ? KBT : (int)(budget / per_kb);
             if (kbc < 1 || L * layer_all > budget || (tasks[k].proj_w && proj_bytes > budget))
                 return fail(TSPGNN_EUNSUPPORTED, "%s: dx=%d, d=%d, %d MLP layers do not fit LDS", what, c.dx, D, L);
             tt.kbc[k] = kbc;
+            tt.lockstep[k] = 1;
             need = (size_t)kbc * per_kb;
-            if (L * layer_all > need) need = L * layer_all;
-            if (tasks[k].proj_w && proj_bytes > need) need = proj_bytes;
+            size_t second = L * layer_all;
+            if (tasks[k].proj_w) {
+                if (L * layer_all + proj_bytes <= budget) {
+                    tt.together[k] = 1;
+                    second += proj_bytes;
+                } else if (proj_bytes > second) {
+                    second = proj_bytes;
+                }
+            }
+            if (second > need) need = second;
         }
         if (need > lds_w) lds_w = need;
         const long long tiles = ((long long)c.rows + 15) / 16;
@@ -585,7 +619,7 @@ static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
         int fixed[kMaxTasksH2], fixed_sum = 0, n_res = 0;
         long long res_cost[kMaxTasksH2];
         for (int k = 0; k < n; ++k) {
-            const bool lock = tt.kbc[k] < (tasks[k].cell.dx + D) / 32;
+            const bool lock = tt.lockstep[k] != 0;
             const long long tiles = ((long long)tasks[k].cell.rows + 15) / 16;
             fixed[k] = lock ? (int)((tiles + nw - 1) / nw) : 0;
             fixed_sum += fixed[k];
@@ -669,7 +703,8 @@ static int cell_mlp_h2(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, vo
                        tasks[k].mlp_layers);
         if (t.rows == 0) continue;
         TSPGNN_REQUIRE(t.h && t.c && t.K && t.ln && t.h_out && t.c_out && (t.dx == 0 || t.x), "%s: null pointer", what);
-        TSPGNN_REQUIRE(t.h_out != t.h && t.c_out != t.c, "%s: outputs may not alias inputs", what);
+        // (h_out == h and c_out == c are fine: a tile reads its own rows of h and c, and only those, before it writes
+        // them -- the in-place update keeps the states' footprint at one copy, inside the Infinity Cache)
         TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx), "%s: gather-init mode needs dx == 0 and Zx", what);
         TSPGNN_REQUIRE(!t.zbias || (t.zscale && !t.uv), "%s: zbias needs zscale and excludes gather-init mode", what);
         TSPGNN_REQUIRE(tasks[k].mlp_layers == 0 || tasks[k].mlp_wb, "%s: mlp_layers > 0 needs mlp_wb", what);

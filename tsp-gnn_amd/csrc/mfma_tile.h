@@ -94,13 +94,29 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <int TPG>
+// The same sum (same order, bit-identical) by gfx950's lane-swap VALU instructions instead of two ds_bpermute round
+// trips: v_permlane16_swap(v, v) leaves {even rows of v, odd rows of v} duplicated in the two results, so their sum is
+// v[l] + v[l^16] in every lane; v_permlane32_swap does the same for the two 32-lane halves.  Needs the full EXEC mask
+// (tools/permlane_probe.hip pins the semantics): forward kernels only.
+__device__ __forceinline__ float sum_over_lane_groups16_swap(float v) {
+    // (inline asm: hipcc 7.2's __builtin_amdgcn_permlane16_swap returns its two results in one register when both are
+    // used in the same expression -- the probe's sum came out as 2 * a[0]; the s_nop covers the VALU-write -> swap-read
+    // hazard the compiler cannot see inside an asm)
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    float s = a + b, t = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(s), "+v"(t));
+    return s + t;
+}
+
+template <int TPG, bool SWAP = false>
 __device__ __forceinline__ void ln_gate(f32x4 (&v)[TPG], const float* gamma, const float* beta, int g, int D,
                                         float eps = 1e-12f) {
+    auto lane_sum = [](float x) { return SWAP ? sum_over_lane_groups16_swap(x) : sum_over_lane_groups16(x); };
     f32x2 s2 = v[0].lo + v[0].hi;
 #pragma unroll
     for (int t = 1; t < TPG; ++t) s2 += v[t].lo + v[t].hi;
-    const float mean = sum_over_lane_groups16(s2[0] + s2[1]) * (1.0f / (float)D);
+    const float mean = lane_sum(s2[0] + s2[1]) * (1.0f / (float)D);
     const f32x2 m2 = {mean, mean};
     f32x2 q2 = {0.f, 0.f};
 #pragma unroll
@@ -111,7 +127,7 @@ __device__ __forceinline__ void ln_gate(f32x4 (&v)[TPG], const float* gamma, con
         v[t].lo = a;
         v[t].hi = b;
     }
-    const float var = sum_over_lane_groups16(q2[0] + q2[1]) * (1.0f / (float)D);
+    const float var = lane_sum(q2[0] + q2[1]) * (1.0f / (float)D);
     const float rstd = __builtin_amdgcn_rsqf(var + eps);  // v_rsq_f32, ~1 ulp
     const f32x2 r2 = {rstd, rstd};
 #pragma unroll
@@ -147,7 +163,7 @@ __device__ __forceinline__ f32x2 sigmoid2_pre(f32x2 t) {
 // beta_f), so their LayerNorm output is the exponent of the sigmoid directly -- one packed multiply-add per pair less;
 // eps_z: the epsilon of the four gate LayerNorms (a caller whose z is scaled by 2^s passes 2^2s * 1e-12, which makes
 // the normalised gates those of the unscaled z exactly -- a power-of-two scale commutes with every rounding).
-template <int D, bool PRE = false>
+template <int D, bool PRE = false, bool SWAP = false>
 __device__ __forceinline__ void lstm_gates(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 16], const float* lds_ln, int g,
                                            f32x4 (&hn)[D / 16], f32x4 (&nc)[D / 16], float eps_z = 1e-12f) {
     constexpr int TPG = D / 16;
@@ -159,10 +175,10 @@ __device__ __forceinline__ void lstm_gates(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 
         gf[t] = acc[2 * TPG + t];
         go[t] = acc[3 * TPG + t];
     }
-    ln_gate<TPG>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D, eps_z);
-    ln_gate<TPG>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D, eps_z);
-    ln_gate<TPG>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D, eps_z);
-    ln_gate<TPG>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D, eps_z);
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
         if constexpr (PRE) {
@@ -173,7 +189,7 @@ __device__ __forceinline__ void lstm_gates(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 
             nc[t].hi = fma2(sigmoid2(gi[t].hi), relu2(gj[t].hi), cf[t].hi * sigmoid2(gf[t].hi, 1.0f));
         }
     }
-    ln_gate<TPG>(nc, lds_ln + 8 * D, lds_ln + 9 * D, g, D);
+    ln_gate<TPG, SWAP>(nc, lds_ln + 8 * D, lds_ln + 9 * D, g, D);
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
         if constexpr (PRE) {

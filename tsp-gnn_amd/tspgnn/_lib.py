@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtspgnn.so")
+LIB_PATH = os.environ.get("TSPGNN_LIB") or os.path.join(_HERE, "libtspgnn.so")   # (TSPGNN_LIB: A/B builds)
 ABI_VERSION = 1
 
 c_int, c_uint, c_float, c_void_p, c_char_p, c_longlong = (ctypes.c_int, ctypes.c_uint, ctypes.c_float,
