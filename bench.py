@@ -32,12 +32,15 @@ BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* peak = fp32 vector peak
 
 WORKLOADS = {
-    # name: (graph sizes, d, T)
-    "c1": ([20] * 32, 64, 8),      # BASELINE.json configs[0]
-    "c2": ([40] * 128, 64, 32),    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    # name: (graph sizes, d, T, storage)
+    "c1": ([20] * 32, 64, 8, "f32"),      # BASELINE.json configs[0]
+    "c2": ([40] * 128, 64, 32, "f32"),    # BASELINE.json configs[1]: the configuration the metric is quoted on
     # BASELINE.json configs[3]: ragged n in {20..80}, batch 512 (N=25 362, M=695 849; the SpMM operands exceed the
     # 256 MB Infinity Cache).  Not the metric's configuration; no cpu_baseline (the dense EV would be 70 GB).
-    "c4": (list(np.random.RandomState(0).randint(20, 81, size=512)), 64, 32),
+    "c4": (list(np.random.RandomState(0).randint(20, 81, size=512)), 64, 32, "f32"),
+    # BASELINE.json configs[4], ONE GPU's shard of it: n=200, 32 of the 256 graphs, embed=128, T=64, bf16 embeddings
+    # with fp32 accumulation (M=636 800 edges; 340 MB of SpMM operands per step).  Not the metric's configuration.
+    "c5": ([200] * 32, 128, 64, "bf16"),
 }
 
 
@@ -98,13 +101,16 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    sizes, d, T = WORKLOADS[args.workload]
+    sizes, d, T, storage = WORKLOADS[args.workload]
+    bf16 = storage == "bf16"
+    if bf16 and args.mode == "train":
+        args.train_steps = 0
     t_pack0 = time.perf_counter()
     batch = tspgnn.synthetic_batch(sizes, seed=1234 + rank)
     t_pack = time.perf_counter() - t_pack0
     EV, W, C, route_exists, n_vertices, n_edges = batch
     M, N = EV.shape
-    model = tspgnn.build_network(d)
+    model = tspgnn.build_network(d, float_dtype=torch.bfloat16 if bf16 else torch.float32)
     sess = tspgnn.Session(model, device=device)
     sess.run(tspgnn.global_variables_initializer(seed=0))
     feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
@@ -158,7 +164,7 @@ def main():
     if not np.isfinite(loss):
         raise SystemExit("non-finite loss in the timed region")
     train = None
-    if args.mode == "forward" and args.train_steps > 0:
+    if args.mode == "forward" and args.train_steps > 0 and not bf16:
         # the training step (backward + RCCL all-reduce of the 462 KB gradient bucket + fused optimiser), reported
         # next to the headline number; a failure here (e.g. the collective) must not lose the forward measurement
         try:
@@ -176,7 +182,7 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         mp_steps_per_s = world * args.steps * T / elapsed
-        gather_b, rowsum_b = spmm_bytes(N, M, d)
+        gather_b, rowsum_b = spmm_bytes(N, M, d, eb=2 if bf16 else 4)
 
         # ---- the same forward with the other GEMM arithmetics, next to the headline: their time, and how far their
         # predictions are from the headline's on this batch (all three are fp32-class; the parity tests hold them to
@@ -190,7 +196,7 @@ def main():
                       "terms per product accumulated in fp32 (dropped terms <= 2^-24 relative)",
             "f32": "f32: v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate)",
         }
-        if args.mode == "forward":
+        if args.mode == "forward" and not bf16:
             headline = gnn.gemm
             pred0 = sess.forward_device(dev_batch)["predictions"].clone()
             alts = {}
@@ -230,18 +236,20 @@ def main():
 
         # ---- SpMM-only (SURVEY.md §8d M1 i): the two aggregation kernels back to back, >= 200 warm iterations
         adj = dev_batch.adj
-        X = torch.randn((N, d), device=device)
-        Z = torch.randn((M, d), device=device)
-        Y = torch.empty((M, d), device=device)
-        Vout = torch.empty((N, d), device=device)
+        sdt = torch.bfloat16 if bf16 else torch.float32
+        sfx = "bf16" if bf16 else "f32"
+        X = torch.randn((N, d), device=device).to(sdt)
+        Z = torch.randn((M, d), device=device).to(sdt)
+        Y = torch.empty((M, d), device=device, dtype=sdt)
+        Vout = torch.empty((N, d), device=device, dtype=sdt)
         rowptr, eid, _ = adj.csr_t
         st = _lib.current_stream()
 
         def gather():
-            _lib.call("tspgnn_gather2_sum_f32", _lib.ptr(adj.uv), _lib.ptr(X), _lib.ptr(Y), M, N, d, st)
+            _lib.call("tspgnn_gather2_sum_" + sfx, _lib.ptr(adj.uv), _lib.ptr(X), _lib.ptr(Y), M, N, d, st)
 
         def rowsum():
-            _lib.call("tspgnn_csr_rowsum_f32", _lib.ptr(rowptr), _lib.ptr(eid), _lib.ptr(Z), _lib.ptr(Vout), N, M, d, st)
+            _lib.call("tspgnn_csr_rowsum_" + sfx, _lib.ptr(rowptr), _lib.ptr(eid), _lib.ptr(Z), _lib.ptr(Vout), N, M, d, st)
 
         def time_loop(fns, iters=300):
             for _ in range(20):
@@ -260,20 +268,33 @@ def main():
             _lib.call("tspgnn_spmm_pair_f32", _lib.ptr(adj.uv), _lib.ptr(X), _lib.ptr(Y), _lib.ptr(rowptr), _lib.ptr(eid),
                       _lib.ptr(Z), _lib.ptr(Vout), M, N, d, st)
 
-        t_gather, t_rowsum, t_pair, t_two = time_loop([gather]), time_loop([rowsum]), time_loop([pair]), \
-            time_loop([gather, rowsum])
+        t_gather, t_rowsum, t_two = time_loop([gather]), time_loop([rowsum]), time_loop([gather, rowsum])
+        t_pair = t_two if bf16 else time_loop([pair])   # (the bf16-storage kernels have no one-launch pair)
         pair_gbs = (gather_b + rowsum_b) / (t_pair * 1e-6) / 1e9
-        traffic = None   # HBM-side bytes per launch pair from the committed PMC pass (rocprofv3 --pmc cannot run in here)
-        tpath = os.path.join(ROOT, "profiles", "r01_spmm_pmc_traffic.json")
-        if args.workload == "c2" and os.path.exists(tpath):
+        # HBM-side bytes per launch (pair) from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py):
+        # profiles/r02_spmm_pmc_traffic.json, keyed by workload
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_spmm_pmc_traffic.json")
+        if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("pair_traffic_bytes")
+                ent = json.load(f).get(args.workload)
+            if ent:
+                traffic, traffic_src = ent.get("pair_traffic_bytes"), "profiles/r02_spmm_pmc_traffic.json: " + ent.get("how", "")
+        # the SAME kernels where they execute: inside the forward pass (the instrumented eager pass above -- HIP events on
+        # the launch stream around every launch, operands produced by the preceding launch, not replayed from cache)
+        in_forward = {}
+        for kname, bytes_ in (("tspgnn_csr_rowsum_" + sfx, rowsum_b), ("tspgnn_gather2_sum_" + sfx, gather_b)):
+            if kname in kernels_us:
+                us = kernels_us[kname]["avg_us"]
+                in_forward[kname] = {"avg_us": round(us, 2), "launches": kernels_us[kname]["n"],
+                                     "GBs": round(bytes_ / us / 1e3, 1), "frac": round(bytes_ / us / 1e3 / HBM_PEAK_GBS, 4)}
         roofline = {
-            "kernel": "tspgnn_spmm_pair_f32 (E<-V gather + V<-E CSR row-sum of one step in one launch)",
+            "kernel": ("tspgnn_gather2_sum_bf16 + tspgnn_csr_rowsum_bf16 (the two aggregation launches of one step)" if bf16
+                       else "tspgnn_spmm_pair_f32 (E<-V gather + V<-E CSR row-sum of one step in one launch)"),
             "bound": "hbm", "achieved": round(pair_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(pair_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": "profiles/r01_spmm_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
-                              if traffic else None,
+            "traffic_source": traffic_src,
+            "in_forward": in_forward,
             "algorithmic_bytes_per_launch": {"gather2_sum": gather_b, "csr_rowsum": rowsum_b},
             "avg_us": {"gather2_sum": round(t_gather, 2), "csr_rowsum": round(t_rowsum, 2), "pair": round(t_pair, 2),
                        "two_launches": round(t_two, 2)},
@@ -282,20 +303,22 @@ def main():
             "spmm_steps_per_s": round(1e6 / t_pair, 1),
             "incidences_per_s": round(4 * M * 1e6 / t_pair, 1),
             "note": "north_star's target kernel, measured back to back on the benchmark batch (HIP events on the launch "
-                    "stream, 300 launches).  In the timed forward the V<-E direction is this row-sum kernel "
-                    "(kernels_us.tspgnn_csr_rowsum_f32) and the E<-V gather is folded into the edge cell's operand "
-                    "load (Zx[u] + Zx[v] inside the fused cell launch, whose figures are in roofline_dense).",
+                    "stream, 300 launches).  In the timed forward the V<-E direction is the row-sum kernel -- `in_forward` "
+                    "gives its duration and roofline fraction THERE, reading messages the cell launch has just "
+                    "written -- and the E<-V gather is folded into the edge cell's operand load (Zx[u] + Zx[v] inside "
+                    "the fused cell launch, whose figures are in roofline_dense).",
         }
         dense_names = ("tspgnn_mlp_fwd_f32", "tspgnn_mlp_fwd_multi_f32", "tspgnn_lnlstm_fwd_f32",
                        "tspgnn_lnlstm_fwd_multi_f32", "tspgnn_lnlstm_gather_fwd_f32", "tspgnn_linear_f32",
                        "tspgnn_mlp_fwd_multi_x3", "tspgnn_lnlstm_fwd_multi_x3", "tspgnn_lnlstm_mlp_fwd_multi_x3",
-                       "tspgnn_mlp_fwd_multi_h2", "tspgnn_lnlstm_fwd_multi_h2", "tspgnn_lnlstm_mlp_fwd_multi_h2")
+                       "tspgnn_mlp_fwd_multi_h2", "tspgnn_lnlstm_fwd_multi_h2", "tspgnn_lnlstm_mlp_fwd_multi_h2",
+                       "tspgnn_mlp_fwd_multi_bf16", "tspgnn_lnlstm_fwd_multi_bf16")
         dense_us = sum(v["total_us"] for k, v in kernels_us.items() if k in dense_names)
         h2 = any(k.endswith("_h2") and "pack" not in k for k in kernels_us)
         x3 = h2 or any(k.endswith("_x3") and "pack" not in k for k in kernels_us)
         # split operands: every fp32 product costs three fp16 (f16x2) or six bf16 (bf16x3) MFMA terms -> the matrix-pipe
         # ceiling in fp32-equivalent flops is the 16-bit dense peak over 3 or 6
-        dense_peak = BF16_MFMA_PEAK_TF / (3.0 if h2 else 6.0) if x3 else FP32_MFMA_PEAK_TF
+        dense_peak = BF16_MFMA_PEAK_TF / (3.0 if h2 else 6.0) if x3 else (BF16_MFMA_PEAK_TF if bf16 else FP32_MFMA_PEAK_TF)
         # E_vote's 3 hidden layers also run through mlp_fwd: count their flops too
         dense_flops = T * dense_flops_per_step(N, M, d, folded=True) + M * 3 * 2 * d * d
         roofline_dense = {
@@ -303,6 +326,7 @@ def main():
                        "per fp32 product; peak = fp16 dense peak (2.5 PFLOP/s) / 3") if h2 else
                       ("lnlstm_mlp_fwd_multi_x3 (+ mlp_fwd_multi_x3, fp32 vote MLP): v_mfma_f32_16x16x32_bf16 on exact "
                        "3-way bf16 splits, 6 terms per fp32 product; peak = bf16 dense peak / 6") if x3 else
+                      "mlp_fwd_multi_bf16 + lnlstm_fwd_multi_bf16 (v_mfma_f32_16x16x32_bf16 on bf16-rounded operands)" if bf16 else
                       "mlp_fwd_multi + lnlstm_fwd_multi + linear (fp32 MFMA v_mfma_f32_16x16x4_f32)",
             "bound": "mfma", "achieved": round(dense_flops / (dense_us * 1e-6) / 1e12, 2) if dense_us else None,
             "peak": round(dense_peak, 1), "unit": "TFLOP/s (fp32-equivalent)" if x3 else "TFLOP/s",
@@ -323,11 +347,12 @@ def main():
             "value": round(mp_steps_per_s, 2), "unit": "mp-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d complete Euclidean graphs n=%s, d=%d, T=%d, fp32, forward pass "
+            "vs_baseline": None, "dtype": "bf16 storage, f32 accumulate" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d complete Euclidean graphs n=%s, d=%d, T=%d, %s, forward pass "
                                    "(E_init -> T x {msg MLPs, SpMM pair, LN-LSTMs} -> vote -> loss)%s"
                                    % (args.workload, len(sizes), ("%d" % sizes[0]) if min(sizes) == max(sizes)
                                       else "%d..%d" % (min(sizes), max(sizes)), d, T,
+                                      "bf16 embeddings / fp32 accumulate" if bf16 else "fp32",
                                       "" if args.mode == "forward" else " + backward + all-reduce + Adam"),
                        "per_gpu_batch": len(sizes), "global_batch": len(sizes) * world, "N": N, "M": M,
                        "parallelism": "shard-by-instance x%d, no data-path collective" % world},

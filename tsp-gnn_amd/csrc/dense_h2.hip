@@ -613,17 +613,28 @@ static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
     const long long max_grid = (tiles_all + nw - 1) / nw;
     if (grid > max_grid) grid = (int)max_grid;
     {
-        // A lock-step task is a latency chain (several LDS re-stagings per round) that the resident tasks of the
-        // launch hide: it gets exactly the workgroups of ONE round (more would idle, fewer would double the chain),
-        // capped at half the grid; the resident tasks share the rest in proportion to their cost.
+        // A lock-step task is a latency chain (two LDS stagings per round) that the resident tasks of the launch hide.
+        // It gets the workgroups of a whole number of rounds -- ONE round while that stays within about twice its share
+        // of the grid by cost (more workgroups would idle, fewer would double the chain: C2's 320 vertex tiles take 20
+        // of 256), otherwise as many rounds as bring it back to its share (C4's 1 586 vertex tiles: 7 rounds on 15
+        // workgroups instead of starving the edge task of 99); the resident tasks share the rest by cost.
+        long long total_cost = 0;
+        for (int k = 0; k < n; ++k) total_cost += cost[k] > 0 ? cost[k] : 1;
         int fixed[kMaxTasksH2], fixed_sum = 0, n_res = 0;
         long long res_cost[kMaxTasksH2];
         for (int k = 0; k < n; ++k) {
-            const bool lock = tt.lockstep[k] != 0;
-            const long long tiles = ((long long)tasks[k].cell.rows + 15) / 16;
-            fixed[k] = lock ? (int)((tiles + nw - 1) / nw) : 0;
+            fixed[k] = 0;
+            if (tt.lockstep[k]) {
+                const long long tiles = ((long long)tasks[k].cell.rows + 15) / 16;
+                const long long per_round = (tiles + nw - 1) / nw;
+                long long share = (2 * cost[k] * grid + total_cost - 1) / total_cost;  // twice the proportional share
+                if (share < 1) share = 1;
+                const long long n_rounds = (per_round + share - 1) / share;
+                fixed[k] = (int)((per_round + n_rounds - 1) / n_rounds);
+            } else {
+                ++n_res;
+            }
             fixed_sum += fixed[k];
-            if (!lock) ++n_res;
         }
         if (n_res == 0 || fixed_sum == 0 || fixed_sum > grid / 2) {
             grid = split_blocks_h2(cost, n, grid, tt.blk_end);
