@@ -325,6 +325,15 @@ typedef struct tspgnn_mlp_bwd_task {
 } tspgnn_mlp_bwd_task;    /* fields as the arguments of tspgnn_mlp_bwd_f32 (uv = NULL there) */
 
 int tspgnn_lnlstm_bwd_multi_f32(const tspgnn_lstm_bwd_task* tasks, int n_tasks, int d, void* stream);
+/*
+ * tspgnn_lnlstm_bwd_multi_f32 with both GEMMs (the recomputation of z and dh = dz Kh^T) on the fp16 matrix cores
+ * (f16x2, csrc/dense_bwd_h2.hip).  Same task structure; d in {32, 64}, dx a multiple of 32, K (and K^T) resident in LDS:
+ *   K  = tspgnn_pack_weights_h2 of kernel[dx+d, 4d] (Kh[d,4d] in gather-init mode);
+ *   KT = tspgnn_pack_weights_h2 of Kh^T laid out [4d, d] (row-major transpose of Kh), dx == 0;
+ *   Zx = the projected messages as the f16x2 forward wrote them (scaled by 2^TSPGNN_H2_WEIGHT_SCALE_LOG2).
+ * dz, dc_in, dxh and the LayerNorm gradients come back unscaled, exactly as from the _f32 function.
+ */
+int tspgnn_lnlstm_bwd_multi_h2(const tspgnn_lstm_bwd_task* tasks, int n_tasks, int d, void* stream);
 /* ln_grad[10d] += fixed-order sum of the deferred partials in `workspace` (tspgnn_lnlstm_bwd_workspace_floats(d)). */
 int tspgnn_lnlstm_bwd_finish_f32(const float* workspace, float* ln_grad, int d, void* stream);
 int tspgnn_mlp_bwd_multi_f32(const tspgnn_mlp_bwd_task* tasks, int n_tasks, int d, void* stream);

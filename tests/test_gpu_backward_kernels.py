@@ -154,6 +154,100 @@ def test_lnlstm_gather_backward_fused_dh(cuda_device, rows):
         assert np.array_equal(a, b)      # same arithmetic in the same order, from registers instead of from HBM
 
 
+def packed_h2(W, device):
+    """tspgnn_pack_weights_h2 (two fp16 pieces of 2^s W) as a byte tensor."""
+    src = dev(W, device)
+    out = torch.empty(4 * W.size, dtype=torch.uint8, device=device)
+    _KEEP.append(out)
+    _lib.call("tspgnn_pack_weights_h2", _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], None)
+    return out
+
+
+@pytest.mark.parametrize("d,dx,rows,grad_scale", [(64, 64, 333, 1.0), (32, 32, 50, 1.0), (64, 64, 1000, 1e-6), (32, 32, 100, 1e3),
+                                                   (64, 0, 77, 1.0)])
+def test_lnlstm_backward_h2_vs_autograd(cuda_device, d, dx, rows, grad_scale):
+    """tspgnn_lnlstm_bwd_multi_h2 (both GEMMs on the fp16 matrix cores): dz, dc, the LayerNorm gradients, and the
+    downstream [dx | dh] = dz K^T and dK = [x|h]^T dz against float64 autograd -- also with incoming gradients of
+    magnitude 1e-6 and 1e3 (nothing in the kernel may depend on the scale of the gradient)."""
+    rng = np.random.RandomState(d + rows)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    x, h, c = f32(rng.randn(rows, dx)), f32(rng.randn(rows, d)), f32(rng.randn(rows, d))
+    K = f32(rng.randn(dx + d, 4 * d) / np.sqrt(dx + d))
+    ln = f32(np.stack([np.stack([1 + 0.2 * rng.randn(d), 0.2 * rng.randn(d)]) for _ in range(5)]))
+    dh_o, dc_o = f32(grad_scale * rng.randn(rows, d)), f32(grad_scale * rng.randn(rows, d))
+    tx, th, tc, tK = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, h, c, K))
+    tln = torch.tensor(ln, dtype=torch.float64, requires_grad=True)
+    params = {"TSP/Q_cell/layer_norm_basic_lstm_cell/kernel": tK}
+    for i, gname in enumerate(("input", "transform", "forget", "output", "state")):
+        params["TSP/Q_cell/layer_norm_basic_lstm_cell/%s/gamma" % gname] = tln[i, 0]
+        params["TSP/Q_cell/layer_norm_basic_lstm_cell/%s/beta" % gname] = tln[i, 1]
+    nh, nc = TO.lnlstm_cell(tx, th, tc, params, "Q")
+    loss = (nh * torch.tensor(dh_o, dtype=torch.float64)).sum() + (nc * torch.tensor(dc_o, dtype=torch.float64)).sum()
+    gx, gh, gc, gK, gln = torch.autograd.grad(loss, [tx, th, tc, tK, tln])
+    dz, dc_in = empty((rows, 4 * d), cuda_device), empty((rows, d), cuda_device)
+    ln_grad = empty((10 * d,), cuda_device, 0.0)
+    wsl = ws("tspgnn_lnlstm_bwd_workspace_floats", d, device=cuda_device)
+    xd, hd, cd = (dev(x, cuda_device) if dx else None), dev(h, cuda_device), dev(c, cuda_device)
+    task = _lib.LstmBwdTask(_lib.ptr(xd), dx, _lib.ptr(hd), _lib.ptr(cd), _lib.ptr(packed_h2(K, cuda_device)),
+                            _lib.ptr(dev(ln, cuda_device)), _lib.ptr(dev(dh_o, cuda_device)), _lib.ptr(dev(dc_o, cuda_device)),
+                            _lib.ptr(dz), _lib.ptr(dc_in), _lib.ptr(ln_grad), _lib.ptr(wsl), rows, None, None, None, None, 0)
+    _lib.call_multi("tspgnn_lnlstm_bwd_multi_h2", [task], d)
+    dxo = empty((rows, max(dx, 1)), cuda_device); dho = empty((rows, d), cuda_device)
+    _lib.call("tspgnn_linear_f32", _lib.ptr(dz), 4 * d, _lib.ptr(packed(K, cuda_device, transposed=1)),
+              _lib.ptr(dxo) if dx else None, dx, _lib.ptr(dho), d, 0, rows, None)
+    dK = empty((dx + d, 4 * d), cuda_device, 0.0)
+    w2 = ws("tspgnn_wgrad_workspace_floats", rows, d, 4 * d, device=cuda_device)
+    if dx:
+        w1 = ws("tspgnn_wgrad_workspace_floats", rows, dx, 4 * d, device=cuda_device)
+        _lib.call("tspgnn_wgrad_f32", _lib.ptr(xd), _lib.ptr(dz), rows, dx, 4 * d, _lib.ptr(dK[:dx]), None, _lib.ptr(w1), None)
+    _lib.call("tspgnn_wgrad_f32", _lib.ptr(hd), _lib.ptr(dz), rows, d, 4 * d, _lib.ptr(dK[dx:]), None, _lib.ptr(w2), None)
+    torch.cuda.synchronize()
+    assert rel_err(dc_in.cpu().numpy(), gc.numpy()) < TOL
+    if dx:
+        assert rel_err(dxo.cpu().numpy(), gx.numpy()) < TOL
+    assert rel_err(dho.cpu().numpy(), gh.numpy()) < TOL
+    assert rel_err(dK.cpu().numpy(), gK.numpy()) < TOL
+    assert rel_err(ln_grad.cpu().numpy().reshape(5, 2, d), gln.numpy()) < TOL
+
+
+@pytest.mark.parametrize("rows", [1, 333, 9000])
+def test_lnlstm_gather_backward_h2_fused_dh(cuda_device, rows):
+    """Gather-init mode of tspgnn_lnlstm_bwd_multi_h2 with the fused data gradient dh = dz Kh^T: against the fp32-MFMA
+    kernel on the same inputs (Zx scaled by 2^s for the f16x2 side), with the rows' incoming gradients spread over
+    twelve orders of magnitude -- the per-row power-of-two normalisation must keep every row at fp32-class accuracy."""
+    d, N = 64, 257
+    rng = np.random.RandomState(rows)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    sc = float(_lib.lib.tspgnn_h2_weight_scale())
+    uv = np.stack([rng.randint(0, N, rows), rng.randint(0, N, rows)], 1).astype(np.int32)
+    Zx, h, c = f32(rng.randn(N, 4 * d)), f32(rng.randn(rows, d)), f32(rng.randn(rows, d))
+    Kh = f32(rng.randn(d, 4 * d) / np.sqrt(d))
+    ln = f32(np.stack([np.stack([1 + 0.2 * rng.randn(d), 0.2 * rng.randn(d)]) for _ in range(5)]))
+    row_scale = 10.0 ** rng.uniform(-9, 3, size=(rows, 1))
+    dh_o, dc_o = f32(row_scale * rng.randn(rows, d)), f32(row_scale * rng.randn(rows, d))
+    common = dict(uv=dev(uv, cuda_device, np.int32), h=dev(h, cuda_device), c=dev(c, cuda_device), ln=dev(ln, cuda_device),
+                  dh=dev(dh_o, cuda_device), dc=dev(dc_o, cuda_device))
+    outs = {}
+    for arith in ("f32", "h2"):
+        if arith == "f32":
+            K, KT, zx = packed(Kh, cuda_device), packed(Kh, cuda_device, transposed=1), dev(Zx, cuda_device)
+        else:
+            K, KT, zx = packed_h2(Kh, cuda_device), packed_h2(np.ascontiguousarray(Kh.T), cuda_device), dev(sc * Zx, cuda_device)
+        dz, dc_in, dh_in = empty((rows, 4 * d), cuda_device), empty((rows, d), cuda_device), empty((rows, d), cuda_device)
+        ln_grad = empty((10 * d,), cuda_device, 0.0)
+        wsl = ws("tspgnn_lnlstm_bwd_workspace_floats", d, device=cuda_device)
+        task = _lib.LstmBwdTask(None, 0, _lib.ptr(common["h"]), _lib.ptr(common["c"]), _lib.ptr(K), _lib.ptr(common["ln"]),
+                                _lib.ptr(common["dh"]), _lib.ptr(common["dc"]), _lib.ptr(dz), _lib.ptr(dc_in), _lib.ptr(ln_grad),
+                                _lib.ptr(wsl), rows, _lib.ptr(common["uv"]), _lib.ptr(zx), _lib.ptr(KT), _lib.ptr(dh_in), 0)
+        _lib.call_multi("tspgnn_lnlstm_bwd_multi_" + arith, [task], d)
+        torch.cuda.synchronize()
+        outs[arith] = [t.cpu().numpy().astype(np.float64) for t in (dz, dc_in, dh_in)]
+    for a, b, name in zip(outs["h2"], outs["f32"], ("dz", "dc", "dh")):
+        # row by row, relative to the row's own scale
+        scale = np.maximum(np.abs(b).max(axis=1, keepdims=True), 1e-300)
+        assert (np.abs(a - b) / scale).max() < 2e-5, name
+
+
 @pytest.mark.parametrize("d,L,mask,rows", [(64, 4, 0b0111, 500), (64, 3, 0b111, 333), (32, 4, 0b0111, 40), (32, 2, 0b01, 17),
                                            (128, 2, 0b11, 100), (64, 1, 0, 64)])
 def test_mlp_backward_and_wgrad(cuda_device, d, L, mask, rows):

@@ -6,11 +6,18 @@
 namespace tspgnn {
 
 // ------------------------------------------------------------- E0 = E_init_MLP([W, C])
-// One thread per edge; the layer weights are read with wave-uniform indices (scalar loads).
+// 256 edges per workgroup.  Phase 1: one thread per edge runs the three narrow layers (2 -> D/8 -> D/4 -> D/2, weights read
+// with wave-uniform indices = scalar loads) and parks its D/2 activations in LDS.  Phase 2 is the wide layer (D/2 -> D,
+// three quarters of the flops and ALL of the output bytes) with D/4 lanes per row: lane j keeps columns 4j..4j+3 of W4 in
+// registers (LDS when D > 64), reads the row's activations as LDS broadcasts, and the lanes of a row store 4D contiguous
+// bytes -- full-line stores (the one-thread-per-row version wrote 16 B pieces of 64 different rows per instruction:
+// 39 us for a 25.6 MB array at C2).
 template <int D>
 __global__ __launch_bounds__(256) void einit_fwd_kernel(const float2* __restrict__ WC, const float* __restrict__ wb,
                                                         float* __restrict__ E0, int M) {
     constexpr int H1 = D / 8, H2 = D / 4, H3 = D / 2;
+    constexpr int LPR = D / 4, RPP = 256 / LPR;  // lanes per row, rows per pass
+    constexpr bool W4_LDS = D > 64;
     const float* W1 = wb;
     const float* b1 = W1 + 2 * H1;
     const float* W2 = b1 + H1;
@@ -19,40 +26,61 @@ __global__ __launch_bounds__(256) void einit_fwd_kernel(const float2* __restrict
     const float* b3 = W3 + H2 * H3;
     const float* W4 = b3 + H3;
     const float* b4 = W4 + H3 * D;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= M) return;
-    const float2 wc = WC[e];
-    const float w = wc.x, c = wc.y;
-    float a1[H1], a2[H2], a3[H3];
+    __shared__ __attribute__((aligned(16))) float a3s[256][H3 + 4];  // (+4: rows 16 B aligned, bank-staggered)
+    __shared__ __attribute__((aligned(16))) float w4s[W4_LDS ? H3 * D : 4];
+    const int tid = threadIdx.x;
+    const int e0 = blockIdx.x * 256;
+    {
+        const int e = min(e0 + tid, M - 1);
+        const float2 wc = WC[e];
+        const float w = wc.x, c = wc.y;
+        float a1[H1], a2[H2];
 #pragma unroll
-    for (int j = 0; j < H1; ++j) a1[j] = fmaxf(fmaf(c, W1[H1 + j], fmaf(w, W1[j], 0.f)) + b1[j], 0.f);
+        for (int j = 0; j < H1; ++j) a1[j] = fmaxf(fmaf(c, W1[H1 + j], fmaf(w, W1[j], 0.f)) + b1[j], 0.f);
 #pragma unroll
-    for (int j = 0; j < H2; ++j) {
-        float s = 0.f;
+        for (int j = 0; j < H2; ++j) {
+            float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < H1; ++k) s = fmaf(a1[k], W2[k * H2 + j], s);
-        a2[j] = fmaxf(s + b2[j], 0.f);
-    }
-#pragma unroll
-    for (int j = 0; j < H3; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < H2; ++k) s = fmaf(a2[k], W3[k * H3 + j], s);
-        a3[j] = fmaxf(s + b3[j], 0.f);
-    }
-    float4* out = reinterpret_cast<float4*>(E0 + (size_t)e * D);
-    for (int j4 = 0; j4 < D / 4; ++j4) {
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < H3; ++k) {
-            const float4 wv = *reinterpret_cast<const float4*>(W4 + k * D + j4 * 4);
-            s[0] = fmaf(a3[k], wv.x, s[0]);
-            s[1] = fmaf(a3[k], wv.y, s[1]);
-            s[2] = fmaf(a3[k], wv.z, s[2]);
-            s[3] = fmaf(a3[k], wv.w, s[3]);
+            for (int k = 0; k < H1; ++k) s = fmaf(a1[k], W2[k * H2 + j], s);
+            a2[j] = fmaxf(s + b2[j], 0.f);
         }
-        const float4 bv = *reinterpret_cast<const float4*>(b4 + j4 * 4);
-        out[j4] = make_float4(s[0] + bv.x, s[1] + bv.y, s[2] + bv.z, s[3] + bv.w);
+#pragma unroll
+        for (int j = 0; j < H3; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < H2; ++k) s = fmaf(a2[k], W3[k * H3 + j], s);
+            a3s[tid][j] = fmaxf(s + b3[j], 0.f);
+        }
+    }
+    if constexpr (W4_LDS) {
+        for (int i = tid; i < H3 * D / 4; i += 256) reinterpret_cast<float4*>(w4s)[i] = reinterpret_cast<const float4*>(W4)[i];
+    }
+    __syncthreads();
+    const int j = tid % LPR, sub = tid / LPR;
+    const float4 bv = *reinterpret_cast<const float4*>(b4 + j * 4);
+    float4 wreg[W4_LDS ? 1 : H3];
+    if constexpr (!W4_LDS) {
+#pragma unroll
+        for (int k = 0; k < H3; ++k) wreg[k] = *reinterpret_cast<const float4*>(W4 + k * D + j * 4);
+    }
+    for (int r = sub; r < 256; r += RPP) {
+        if (e0 + r >= M) break;
+        float4 s = bv;
+#pragma unroll
+        for (int k4 = 0; k4 < H3 / 4; ++k4) {
+            const float4 a = *reinterpret_cast<const float4*>(&a3s[r][k4 * 4]);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k4 * 4 + i;
+                const float4 wv = W4_LDS ? *reinterpret_cast<const float4*>(&w4s[k * D + j * 4]) : wreg[W4_LDS ? 0 : k];
+                s.x = fmaf(av[i], wv.x, s.x);
+                s.y = fmaf(av[i], wv.y, s.y);
+                s.z = fmaf(av[i], wv.z, s.z);
+                s.w = fmaf(av[i], wv.w, s.w);
+            }
+        }
+        *reinterpret_cast<float4*>(E0 + (size_t)(e0 + r) * D + j * 4) = s;
     }
 }
 

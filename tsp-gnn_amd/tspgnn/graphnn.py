@@ -324,21 +324,39 @@ class LayerNormBasicLSTMCell(object):
                   self.d, _lib.current_stream())
         return h_out, LSTMStateTuple(c=c_out, h=h_out)
 
-    def backward_task(self, x, h, c, dh_out, dc_out, dz, dc_in, ws, defer=False):
-        return _lib.LstmBwdTask(_lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(self.kernel_packed()),
+    def _packed_h2_t(self, key, rows_lo, rows_hi):
+        """f16x2 packing of the TRANSPOSE of kernel rows [rows_lo, rows_hi) ([4d, rows]): the weight operand of the data
+        gradient dz K^T in tspgnn_lnlstm_bwd_multi_h2."""
+        def build(out):
+            KT = self.kernel()[rows_lo:rows_hi].t().contiguous()
+            if out is None:
+                out = torch.empty(SPLIT_BYTES["h2"] * KT.numel(), dtype=torch.uint8, device=KT.device)
+            _lib.call("tspgnn_pack_weights_h2", _lib.ptr(KT), _lib.ptr(out), 4 * self.d, rows_hi - rows_lo,
+                      _lib.current_stream())
+            return out
+        return self.store.packed((key + ".h2", self.base), build)
+
+    def backward_task(self, x, h, c, dh_out, dc_out, dz, dc_in, ws, defer=False, arith=None):
+        K = self._packed_split("h2", "lstm", 0, self.dx + self.d) if arith == "h2" else self.kernel_packed()
+        return _lib.LstmBwdTask(_lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(K),
                                 _lib.ptr(self.ln()), _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in),
                                 _lib.ptr(self.ln_grad()), _lib.ptr(ws), h.shape[0], None, None, None, None,
                                 1 if defer else 0)
 
-    def gather_backward_task(self, adj, zx, h, c, dh_out, dc_out, dz, dc_in, ws, dh_in=None, defer=False):
+    def gather_backward_task(self, adj, zx, h, c, dh_out, dc_out, dz, dc_in, ws, dh_in=None, defer=False, arith=None):
         """``dh_in`` given (d == 64): dh_in = dz Kh^T is formed in the same launch, from dz in registers.
-        ``defer``: LayerNorm-gradient partials accumulate in ``ws`` (see backward_finish)."""
+        ``defer``: LayerNorm-gradient partials accumulate in ``ws`` (see backward_finish).
+        ``arith`` = "h2": operands for tspgnn_lnlstm_bwd_multi_h2 (``zx`` as the f16x2 forward wrote it)."""
         fuse = dh_in is not None and self.d == 64
-        return _lib.LstmBwdTask(None, 0, _lib.ptr(h), _lib.ptr(c), _lib.ptr(self.kh_packed()), _lib.ptr(self.ln()),
+        if arith == "h2":
+            K = self._packed_split("h2", "lstm.kh", self.dx, self.dx + self.d)
+            KT = self._packed_h2_t("lstm.khT", self.dx, self.dx + self.d) if fuse else None
+        else:
+            K, KT = self.kh_packed(), (self.kh_t_packed() if fuse else None)
+        return _lib.LstmBwdTask(None, 0, _lib.ptr(h), _lib.ptr(c), _lib.ptr(K), _lib.ptr(self.ln()),
                                 _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in),
                                 _lib.ptr(self.ln_grad()), _lib.ptr(ws), h.shape[0], _lib.ptr(adj.uv), _lib.ptr(zx),
-                                _lib.ptr(self.kh_t_packed()) if fuse else None, _lib.ptr(dh_in) if fuse else None,
-                                1 if defer else 0)
+                                _lib.ptr(KT), _lib.ptr(dh_in) if fuse else None, 1 if defer else 0)
 
     def backward_finish(self, ws):
         """Fold the LayerNorm-gradient partials that the deferred backward launches of all time steps left in ws."""
@@ -1033,10 +1051,11 @@ class GraphNN(object):
             if u is not None:
                 tape.ZX[v] = torch.empty((T, rows_x, 4 * self.var[v]), **f32)
         tape.acts = {}
-        # forward GEMMs on the bf16 matrix cores (fp32-class accuracy); backward stays fp32 MFMA
-        # (bf16x3 also when the inference arithmetic is f16x2: the tape's projected messages ZX feed the fp32 backward
-        # kernels, which recompute z from them unscaled)
-        arith = "x3" if self._split_arith({v: initial_embeddings[v].shape[0] for v in self.var}) else None
+        # forward GEMMs in the split-operand arithmetic selected by self.gemm (fp32-class accuracy).  With f16x2 the
+        # cells' backward recomputes z in the same arithmetic (tspgnn_lnlstm_bwd_multi_h2; the tape's projected
+        # messages ZX carry the factor 2^s both sides expect); with bf16x3 the backward is fp32 MFMA.
+        arith = self._split_arith({v: initial_embeddings[v].shape[0] for v in self.var})
+        tape.arith = arith
         mlp_fn = "tspgnn_mlp_fwd_multi_" + (arith or "f32")
         lstm_fn = "tspgnn_lnlstm_fwd_multi_" + (arith or "f32")
         for v in self.var:
@@ -1132,6 +1151,7 @@ class GraphNN(object):
         # LayerNorm-gradient partials of all T steps accumulate here (zeroed); one fold per cell after the loop
         ws = {v: _lib.workspace("tspgnn_lnlstm_bwd_workspace_floats", d, device=device).zero_() for v, d in self.var.items()}
         folded = tape.folded
+        bwd_arith = "h2" if getattr(tape, "arith", None) == "h2" else None   # the cells' backward follows the forward
         DZX = {v: torch.empty_like(tape.ZX[v]) for v in self.var if folded[v] is not None}
         dH = {v: (dstates.get(v, (None, None))[0]) for v in self.var}
         dC = {v: (dstates.get(v, (None, None))[1]) for v in self.var}
@@ -1145,14 +1165,15 @@ class GraphNN(object):
                 cell = self._RNN_cells[v]
                 if folded[v] is not None:
                     task = cell.gather_backward_task(mats[folded[v]["mat"]], tape.ZX[v][t], tape.H[v][t], tape.C[v][t],
-                                                     dH[v], dC[v], DZ[v][t], ndC[v], ws[v], dh_in=ndH[v], defer=True)
+                                                     dH[v], dC[v], DZ[v][t], ndC[v], ws[v], dh_in=ndH[v], defer=True,
+                                                     arith=bwd_arith)
                 else:
                     task = cell.backward_task(tape.X[v][t], tape.H[v][t], tape.C[v][t], dH[v], dC[v], DZ[v][t], ndC[v],
-                                              ws[v], defer=True)
+                                              ws[v], defer=True, arith=bwd_arith)
                 tasks.setdefault(d, []).append(task)
             for d, ts in tasks.items():
                 for k in range(0, len(ts), 4):
-                    _lib.call_multi("tspgnn_lnlstm_bwd_multi_f32", ts[k:k + 4], d)
+                    _lib.call_multi("tspgnn_lnlstm_bwd_multi_" + (bwd_arith or "f32"), ts[k:k + 4], d)
             # ---- 2: data gradients of the cell GEMMs; these WRITE dh, the message paths below ACCUMULATE into it
             for v in self.var:
                 cell = self._RNN_cells[v]
