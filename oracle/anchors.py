@@ -18,6 +18,27 @@ ANCHORS = {
 ANCHOR_ROWS = 512
 
 
+# BASELINE config 5 at one GPU's graph size and depth (n=200, d=128, T=64, bf16 embeddings / fp32 accumulate) on 4 of the 32
+# graphs of a shard: oracle = torch_oracle.forward(..., bf16=True), the float64 restatement with the build's rounding points
+BF16_ANCHORS = {"c5": (lambda: [200] * 4, 128, 64)}
+
+
+def bf16_anchor_inputs(name):
+    sys.path.insert(0, os.path.join(ROOT, "tsp-gnn_amd"))
+    import tspgnn
+    from oracle import params as P
+    import zlib
+    sizes, d, T = BF16_ANCHORS[name]
+    batch = tspgnn.synthetic_batch(sizes(), seed=7)
+    params = P.init_params(d, seed=3)
+    EV, W, C = batch[0], batch[1], batch[2]
+    finger = np.array([float(EV.shape[0]), float(EV.shape[1]), float(zlib.crc32(np.ascontiguousarray(EV.uv).view(np.uint8).reshape(-1))),
+                       float(np.sum(W, dtype=np.float64)), float(np.sum(C, dtype=np.float64)),
+                       float(sum(np.sum(np.asarray(v, dtype=np.float64)) for v in params.values())),
+                       float(sum(np.sum(np.abs(np.asarray(v, dtype=np.float64))) for v in params.values()))])
+    return batch, params, d, T, finger
+
+
 def anchor_inputs(name):
     """The batch and the weights an anchor was computed on (also called by tests/test_gpu_anchors.py)."""
     sys.path.insert(0, os.path.join(ROOT, "tsp-gnn_amd"))

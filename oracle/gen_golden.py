@@ -21,7 +21,7 @@
 4. ``graph_*.npz`` -- ``.graph`` instance files (text) together with what the REFERENCE's own ``read_graph``
    (/root/reference/instance_loader.py:95-127, imported here) parses out of them: pins the native reader.
 
-Usage:  python oracle/gen_golden.py [pack] [oracle] [anchors] [graph]      (default: all)
+Usage:  python oracle/gen_golden.py [pack] [oracle] [anchors] [graph] [bf16]      (default: all)
 """
 import os
 import sys
@@ -113,7 +113,7 @@ def gen_oracle():
         print("oracle", name, d, T, "loss", data["loss"])
 
 
-from oracle.anchors import ANCHORS, anchor_inputs, anchor_rows  # noqa: E402
+from oracle.anchors import ANCHORS, BF16_ANCHORS, anchor_inputs, anchor_rows, bf16_anchor_inputs  # noqa: E402
 
 
 def gen_anchors():
@@ -141,6 +141,34 @@ def gen_anchors():
                 data["%s%s_absmax" % (var, part)] = np.float64(np.abs(a).max())
         np.savez_compressed(os.path.join(OUT, "anchor_%s.npz" % name), **data)
         print("anchor", name, "T", T, "M", EV.shape[0], "loss %.9f" % data["loss"], "%.1f s" % (time.time() - t0))
+
+
+def gen_bf16_anchors():
+    """anchor_bf16_*.npz: the bf16-storage oracle (torch_oracle.forward(bf16=True)) and the plain float64 oracle at the
+    depth and width of BASELINE config 5 (tests/test_gpu_anchors.py::test_bf16_storage_at_config5_depth)."""
+    import time
+    import torch
+    from oracle import torch_oracle as TO
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    for name in BF16_ANCHORS:
+        batch, params, d, T, finger = bf16_anchor_inputs(name)
+        EV, W, C, route_exists, n_vertices, n_edges = batch
+        ob = {"ev_uv": EV.uv, "W": W, "C": C, "route_exists": route_exists, "n_vertices": n_vertices, "n_edges": n_edges}
+        t0 = time.time()
+        data = {"T": np.int64(T), "d": np.int64(d), "fingerprint": finger}
+        with torch.no_grad():
+            tp = TO.to_torch(params, torch.float64)
+            for tag, ref in (("bf16", TO.forward(tp, ob, T, bf16=True)), ("f64", TO.forward(tp, ob, T))):
+                data[tag + "_predictions"] = ref["predictions"].numpy()
+                data[tag + "_loss"] = np.float64(ref["loss"].item())
+                for var in ("E", "V"):
+                    for k, part in enumerate(("h", "c")):
+                        a = ref["last_states"][var][k].numpy()
+                        data["%s_%s%s_rows" % (tag, var, part)] = a[anchor_rows(a.shape[0])].astype(np.float32)
+                        data["%s_%s%s_absmax" % (tag, var, part)] = np.float64(np.abs(a).max())
+        np.savez_compressed(os.path.join(OUT, "anchor_bf16_%s.npz" % name), **data)
+        print("bf16 anchor", name, "d", d, "T", T, "M", EV.shape[0], "loss %.9f" % data["bf16_loss"], "%.0f s" % (time.time() - t0))
 
 
 def gen_graph():
@@ -176,7 +204,7 @@ def gen_graph():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    what = sys.argv[1:] or ["pack", "oracle", "anchors", "graph"]
+    what = sys.argv[1:] or ["pack", "oracle", "anchors", "graph", "bf16"]
     if "pack" in what:
         gen_pack()
     if "oracle" in what:
@@ -185,3 +213,5 @@ if __name__ == "__main__":
         gen_anchors()
     if "graph" in what:
         gen_graph()
+    if "bf16" in what:
+        gen_bf16_anchors()

@@ -300,8 +300,9 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTabl
 
     if (resident) {
         stage(0, KBT);
-        const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
-        const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
+        const int pos = xcd_contiguous(my_blk, my_grid);   // the edges of an XCD gather from one slice of Zx
+        const int t_beg = (int)((long long)tiles_total * pos / my_grid);
+        const int t_end = (int)((long long)tiles_total * (pos + 1) / my_grid);
         if (tid == 0) *ticket = t_beg;
         __syncthreads();
         for (;;) {

@@ -45,6 +45,15 @@ __device__ __forceinline__ float sigmoidf_(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 
+// Workgroup b of a launch runs on XCD b mod 8 (observed placement, used for speed only -- any value is correct).  Maps the
+// task-relative workgroup index b in [0, n) to a position such that the workgroups of one XCD hold CONSECUTIVE positions:
+// with contiguous tile ranges per position, an XCD then works on one contiguous eighth of the rows, so the vertex rows its
+// edges gather (Zx, a few MB in total at the ragged / n=200 sizes) stay within its own 4 MB L2.
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+    const int per = n >> 3, rem = n & 7, x = b & 7;
+    return x * per + (x < rem ? x : rem) + (b >> 3);
+}
+
 // Sum over the four 16-lane groups of a wavefront (lanes l, l^16, l^32, l^48); every lane
 // ends with the total.  The order (l + l^16) + (l^32 + l^48) is fixed -> deterministic.
 __device__ __forceinline__ float sum_over_lane_groups16(float v) {

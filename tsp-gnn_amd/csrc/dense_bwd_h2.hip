@@ -176,7 +176,10 @@ static int split_blocks_bwd_h2(const long long* cost, int n, int grid, int* blk_
 
 template <int D>
 static int launch_lnlstm_bwd_h2(const tspgnn_lstm_bwd_task* tasks, int n, hipStream_t st) {
-    constexpr int NWMAX = 8;
+#ifndef H2_BWD_NW
+#define H2_BWD_NW 8
+#endif
+    constexpr int NWMAX = H2_BWD_NW;
     auto extra = [&](int nw_) { return (size_t)(10 * D + nw_ * 10 * D + 4) * sizeof(float); };
     LstmBwdTaskTable tt;
     long long cost[kMaxTasks];

@@ -323,8 +323,9 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         unsigned char* lds_mlp = lds_wb + (size_t)2 * chunk_total * 2;
         stage(0, KBT);
         if (n_layers > 0) h2_copy_to_lds(lds_mlp, mlp_wb, n_layers * LAYER_BYTES, tid, blockDim.x);
-        const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
-        const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
+        const int pos = xcd_contiguous(my_blk, my_grid);   // the edges of an XCD gather from one slice of Zx
+        const int t_beg = (int)((long long)tiles_total * pos / my_grid);
+        const int t_end = (int)((long long)tiles_total * (pos + 1) / my_grid);
         if (tid == 0) *ticket = t_beg;
         h2_stage_wait();
         __syncthreads();
