@@ -46,3 +46,48 @@ def test_full_size_forward_matches_float64_anchor(cuda_device, name, gemm):
     print("anchor %s gemm=%s: %s" % (name, model["gnn"].gemm, "  ".join("%s %.1e" % kv for kv in worst.items())))
     for k, v in worst.items():
         assert v < REL_TOL, (k, v)
+
+
+def test_bf16_storage_at_config5_depth(cuda_device):
+    """BASELINE config 5's mode (bf16 embeddings, fp32 accumulate) at ITS graph size, width and depth -- n=200, d=128,
+    T=64 -- on 4 graphs of a shard (M = 79 600 edges), against committed outputs of the oracle that rounds to bf16 at the
+    same points (oracle/torch_oracle.message_passing_bf16; 2 min of float64 on the build host, so it is an anchor).
+    Two kinds of bars: the bulk of the values (rms, relative to the tensor's largest entry) must agree to a small
+    fraction of a bf16 ulp; single entries may land on the other side of a rounding boundary and then differ by whole
+    ulps at the top of the range (2^-8 = 3.9e-3 each), so the max bar is a few ulps.  The fp32 semantics (plain float64
+    oracle) are an approximation target: bf16 storage over 64 recurrent steps stays within 2e-2 of them."""
+    import torch
+    import tspgnn
+    from oracle.anchors import anchor_rows, bf16_anchor_inputs
+    z = np.load(os.path.join(GOLDEN, "anchor_bf16_c5.npz"))
+    batch, params, d, T, finger = bf16_anchor_inputs("c5")
+    assert T == int(z["T"]) and d == int(z["d"]) and np.array_equal(finger, z["fingerprint"]), "inputs differ from the anchor's"
+    EV, W, C, route_exists, n_vertices, n_edges = batch
+    model = tspgnn.build_network(d, float_dtype=torch.bfloat16)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T, model["route_exists"]: route_exists,
+            model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    pred, loss, last = sess.run([model["predictions"], model["loss"], model["last_states"]], feed_dict=feed)
+
+    def errs(a, ref, scale):
+        e = np.abs(np.asarray(a, dtype=np.float64) - ref) / scale
+        return float(e.max()), float(np.sqrt((e ** 2).mean()))
+
+    report = []
+    for var in ("E", "V"):
+        for part in ("h", "c"):
+            a = np.asarray(getattr(last[var], part), dtype=np.float64)
+            rows = anchor_rows(a.shape[0])
+            mx, rms = errs(a[rows], z["bf16_%s%s_rows" % (var, part)], float(z["bf16_%s%s_absmax" % (var, part)]))
+            fmx, frms = errs(a[rows], z["f64_%s%s_rows" % (var, part)], float(z["f64_%s%s_absmax" % (var, part)]))
+            report.append("%s.%s max %.1e rms %.1e (fp32 semantics: %.1e / %.1e)" % (var, part, mx, rms, fmx, frms))
+            assert mx < 2e-2 and rms < 1.5e-3, (var, part, mx, rms)
+            assert fmx < 4e-2 and frms < 6e-3, (var, part, fmx, frms)
+    e_pred = np.abs(pred - z["bf16_predictions"]).max() / np.abs(z["bf16_predictions"]).max()
+    f_pred = np.abs(pred - z["f64_predictions"]).max() / np.abs(z["f64_predictions"]).max()
+    print("bf16 @ config-5 depth: pred %.1e (fp32 semantics %.1e)  loss diff %.1e  %s"
+          % (e_pred, f_pred, abs(float(loss) - float(z["bf16_loss"])), "  ".join(report)))
+    assert e_pred < 5e-4 and abs(float(loss) - float(z["bf16_loss"])) < 2e-4
+    assert f_pred < 1e-2

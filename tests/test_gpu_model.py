@@ -524,11 +524,18 @@ def test_bf16_storage_mode(cuda_device, name, d, T):
     e_p = rel_err(pred, ref["predictions"].numpy())
     a_h = rel_err(last["E"].h, full["last_states"]["E"][0].numpy())
     a_p = rel_err(pred, full["predictions"].numpy())
-    print("\n[%s d=%d T=%d bf16] vs bf16 oracle: E.h %.2e V.c %.2e pred %.2e | vs fp32 semantics: E.h %.2e pred %.2e"
-          % (name, d, T, e_h, e_c, e_p, a_h, a_p))
-    assert e_h < 3e-2 and e_c < 3e-2 and e_p < 1e-2
-    assert a_h < 1e-1 and a_p < 3e-2
-    assert abs(float(loss) - ref["loss"].item()) < 1e-2
+
+    def rms(a, b):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        return float(np.sqrt(((a - b) ** 2).mean()) / np.abs(b).max())
+    r_h = rms(last["E"].h, ref["last_states"]["E"][0].numpy())
+    print("\n[%s d=%d T=%d bf16] vs bf16 oracle: E.h %.2e (rms %.2e) V.c %.2e pred %.2e | vs fp32 semantics: E.h %.2e pred %.2e"
+          % (name, d, T, e_h, r_h, e_c, e_p, a_h, a_p))
+    # against the oracle that rounds at the same points: single entries may sit on the other side of a bf16 rounding
+    # boundary (whole ulps of 2^-8 at the top of the range), the bulk agrees to a fraction of an ulp
+    assert e_h < 2e-2 and e_c < 1e-2 and r_h < 2e-3 and e_p < 1e-3
+    assert a_h < 4e-2 and a_p < 1e-2
+    assert abs(float(loss) - ref["loss"].item()) < 5e-4
     with pytest.raises(NotImplementedError):
         sess.run([model["train_step"]], feed_dict=feed)
 
