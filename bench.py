@@ -273,13 +273,14 @@ def main():
         pair_gbs = (gather_b + rowsum_b) / (t_pair * 1e-6) / 1e9
         # HBM-side bytes per launch (pair) from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py):
         # profiles/r02_spmm_pmc_traffic.json, keyed by workload
-        traffic, traffic_src = None, None
+        traffic, traffic_src, prof_fwd = None, None, {}
         tpath = os.path.join(ROOT, "profiles", "r02_spmm_pmc_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 ent = json.load(f).get(args.workload)
             if ent:
                 traffic, traffic_src = ent.get("pair_traffic_bytes"), "profiles/r02_spmm_pmc_traffic.json: " + ent.get("how", "")
+                prof_fwd = ent.get("in_forward", {})
         # the SAME kernels where they execute: inside the forward pass (the instrumented eager pass above -- HIP events on
         # the launch stream around every launch, operands produced by the preceding launch, not replayed from cache)
         in_forward = {}
@@ -287,7 +288,19 @@ def main():
             if kname in kernels_us:
                 us = kernels_us[kname]["avg_us"]
                 in_forward[kname] = {"avg_us": round(us, 2), "launches": kernels_us[kname]["n"],
-                                     "GBs": round(bytes_ / us / 1e3, 1), "frac": round(bytes_ / us / 1e3 / HBM_PEAK_GBS, 4)}
+                                     "GBs": round(bytes_ / us / 1e3, 1), "frac": round(bytes_ / us / 1e3 / HBM_PEAK_GBS, 4),
+                                     "how": "HIP events around each launch in the eager forward (includes ~2 us of "
+                                            "launch gap on a ~7 us kernel)"}
+                # the same launches as rocprofv3's kernel trace saw them (kernel begin -> end, committed profile)
+                tag = "csr_rowsum" if "rowsum" in kname else "gather2_sum"
+                for grid_key, pf in sorted(prof_fwd.get(tag, {}).items()):
+                    pus = pf.get("avg_us_under_profiler")
+                    if pus:
+                        in_forward[kname]["rocprof"] = {
+                            "avg_us": pus, "dispatches": pf.get("dispatches"), "GBs": round(bytes_ / pus / 1e3, 1),
+                            "frac": round(bytes_ / pus / 1e3 / HBM_PEAK_GBS, 4), "traffic_bytes": pf.get("traffic_bytes"),
+                            "source": "profiles/r02_spmm_pmc_traffic.json in_forward (rocprofv3 --kernel-trace --pmc, "
+                                      "tools/forward_only.py)"}
         roofline = {
             "kernel": ("tspgnn_gather2_sum_bf16 + tspgnn_csr_rowsum_bf16 (the two aggregation launches of one step)" if bf16
                        else "tspgnn_spmm_pair_f32 (E<-V gather + V<-E CSR row-sum of one step in one launch)"),
