@@ -470,12 +470,13 @@ static int launch_mlp_h2(const tspgnn_mlp_task* tasks, int n, hipStream_t st) {
 }
 
 // Wavefronts per workgroup of the cell launch.  The kernel is compiled for 12 (<= 168 registers) and for 16
-// (<= 128 registers) wavefronts; TSPGNN_H2_WAVES picks one (development switch; 16 measured 3-4 % faster at C2).
+// (<= 128 registers) wavefronts; TSPGNN_H2_WAVES picks one (development switch; final build, A/B/A/B on one box: 12
+// wavefronts 1.68-1.69 ms vs 1.75-1.77 ms at C2, 11.0 vs 11.4 ms at C4 -- the 16-wavefront build spills 16 registers).
 static int h2_cell_waves() {
     static const int nw = [] {
         const char* e = getenv("TSPGNN_H2_WAVES");
         const int v = e ? atoi(e) : 0;
-        return (v == 12 || v == 16) ? v : 16;
+        return (v == 12 || v == 16) ? v : 12;
     }();
     return nw;
 }
