@@ -38,6 +38,17 @@ def _dev_i32(a, device):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
 
 
+class _States(dict):
+    """{var: LSTMStateTuple} as returned by GraphNN.__call__, carrying the scratch buffers its launch plan points at:
+    the task structures hold raw device pointers, so the buffers must live as long as anything that may replay those
+    launches -- a captured HIP graph keeps the outputs (Session.capture_forward's closure), hence the buffers, alive,
+    independently of later calls that build other plans."""
+
+    def __init__(self, states, keep):
+        dict.__init__(self, states)
+        self._keep = keep
+
+
 class DeviceAdjacency(object):
     """A sparse [R, C] matrix resident on the device in CSR, both orientations."""
 
@@ -605,12 +616,12 @@ class GraphNN(object):
         if T > 0:
             plan = self._plan_fused(states, mats, folded)
             if plan is not None:
-                return plan(T)
+                return _States(plan(T), self._plan_keep)
             plan = self._plan(states, mats, folded)
             if plan is not None:
                 for t in range(T):
                     plan[t & 1]()
-                return plan[2][T & 1]
+                return _States(plan[2][T & 1], self._plan_keep)
         for _ in range(T):
             states = self._step(states, mats, dense_mats, folded)
         return states
@@ -710,7 +721,7 @@ class GraphNN(object):
                 fn(*args)
             for arr, d in lstm_calls:
                 _lib.call_multi("tspgnn_lnlstm_fwd_multi_bf16", arr, d)
-        return buf[T & 1]
+        return _States(buf[T & 1], keep)
 
     def _split_arith(self, n_rows=None):
         """"h2" / "x3" when the selected split-operand kernels cover this network (widths 32/64, cell inputs in
