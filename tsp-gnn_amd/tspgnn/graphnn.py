@@ -756,10 +756,7 @@ class GraphNN(object):
         if any(len(c) != 1 for c in consumers.values()):
             return None
         f32 = dict(dtype=torch.float32, device=self.store.theta.device)
-        inplace = arith == "h2" and os.environ.get("TSPGNN_INPLACE", "0") == "1"
-        single_mo = os.environ.get("TSPGNN_SINGLE_MO", "0") == "1"
-        first = {v: LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) for v, st in states.items()}
-        buf = [first, first if inplace else
+        buf = [{v: LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) for v, st in states.items()},
                {v: LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h)) for v, st in states.items()}]
         pushed = {v: self._pushable(v, mats, folded) for v in self.var}
         # message outputs / projected messages, double-buffered by step parity (a launch reads one set and
@@ -772,8 +769,6 @@ class GraphNN(object):
                 for p in (0, 1):
                     if folded[v] is not None:
                         zxs[p][v] = torch.empty((rows, 4 * self.var[v]), **f32)
-                    elif p == 1 and single_mo:
-                        mo[p][(v, i)] = mo[0][(v, i)]
                     else:
                         mo[p][(v, i)] = torch.empty((rows, width), **f32)
         keep = [buf, mo, zxs]
