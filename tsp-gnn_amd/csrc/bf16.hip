@@ -256,7 +256,14 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTabl
     int* ticket = reinterpret_cast<int*>(lds_ln + 10 * D);
     __bf16* lds_w = reinterpret_cast<__bf16*>(ldsb + (10 * D + 4) * sizeof(float));
     const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4, wave = tid >> 6;
-    for (int i = tid; i < 10 * D; i += blockDim.x) lds_ln[i] = ln[i];
+    // (gates i, f, o feed sigmoids only: gamma / beta stored times -log2(e), forget bias folded in -- lstm_gates<D, true>)
+    for (int i = tid; i < 10 * D; i += blockDim.x) {
+        const int r = i / D;
+        float v = ln[i];
+        if (r == 5) v += 1.0f;
+        if (r < 2 || (r >= 4 && r < 8)) v *= -1.4426950408889634f;
+        lds_ln[i] = v;
+    }
 
     auto stage = [&](int kb0, int kb1) {  // K is k-block major: one contiguous range
         copy_to_lds(reinterpret_cast<float*>(lds_w), reinterpret_cast<const float*>(K + (size_t)kb0 * 32 * 4 * D),
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTabl
         f32x4 cf[TPG], hn[TPG], nc[TPG];
 #pragma unroll
         for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + rc * D + g * 4 + t * 16);
-        lstm_gates<D>(acc, cf, lds_ln, g, hn, nc);
+        lstm_gates<D, true, true>(acc, cf, lds_ln, g, hn, nc);
         if (valid) {
 #pragma unroll
             for (int t = 0; t < TPG; ++t) {
