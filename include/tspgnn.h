@@ -183,8 +183,12 @@ int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_task
  *     s = TSPGNN_H2_WEIGHT_SCALE_LOG2 (keeps the lo piece of a typical weight out of the fp16 subnormals;
  *     |W| < 2^10 required);
  *   mlp task:  wb = n_layers blocks of { packed[2*d*d] fp16, 2^s * bias[d] float }; Y comes back unscaled;
- *              proj_out = 2^s * (Y P): it only ever feeds the z of an f16x2 cell (Zx of gather-init mode);
- *   lstm task: K packed [dx+d, 4d]; Zx as written by an f16x2 projection (scaled by 2^s); zbias unscaled.
+ *              proj_out = the PROJECTED-MESSAGE FORMAT of this family: 2^s * (Y P), blocked by 16 source rows -- the
+ *              float4 (columns 16t + 4g .. 4g+3) of row v at float offset (((v/16) * d/4 + t) * 4 + g) * 64 + (v%16) * 4;
+ *              buffer of ceil(rows/16)*16 rows x 4d floats.  It only ever feeds the z of an f16x2 cell (Zx of
+ *              gather-init mode): producer tiles store 1 KiB contiguous, and the edges' gathers find consecutive
+ *              vertices in one 64-byte segment;
+ *   lstm task: K packed [dx+d, 4d]; Zx in the projected-message format above; zbias unscaled.
  *     The cell normalises the scaled z with epsilon 2^2s * 1e-12, which reproduces the gates of the unscaled z
  *     bit for bit (power-of-two scaling commutes with rounding).
  */
@@ -330,7 +334,7 @@ int tspgnn_lnlstm_bwd_multi_f32(const tspgnn_lstm_bwd_task* tasks, int n_tasks, 
  * (f16x2, csrc/dense_bwd_h2.hip).  Same task structure; d in {32, 64}, dx a multiple of 32, K (and K^T) resident in LDS:
  *   K  = tspgnn_pack_weights_h2 of kernel[dx+d, 4d] (Kh[d,4d] in gather-init mode);
  *   KT = tspgnn_pack_weights_h2 of Kh^T laid out [4d, d] (row-major transpose of Kh), dx == 0;
- *   Zx = the projected messages as the f16x2 forward wrote them (scaled by 2^TSPGNN_H2_WEIGHT_SCALE_LOG2).
+ *   Zx = the projected messages as the f16x2 forward wrote them (its projected-message format: scaled, blocked).
  * dz, dc_in, dxh and the LayerNorm gradients come back unscaled, exactly as from the _f32 function.
  */
 int tspgnn_lnlstm_bwd_multi_h2(const tspgnn_lstm_bwd_task* tasks, int n_tasks, int d, void* stream);

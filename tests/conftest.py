@@ -55,3 +55,22 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     scale = max(float(np.abs(b).max()), 1e-30)
     return float(np.abs(a - b).max()) / scale
+
+
+def h2_zx_pack(Zx, scale):
+    """Row-major projected messages [N, 4d] -> the f16x2 kernels' format (include/tspgnn.h): times 2^s, rows padded to a
+    multiple of 16, blocked by 16 rows: float4 (columns 16t + 4g .. +3) of row v at (((v/16)*d/4 + t)*4 + g)*64 + (v%16)*4."""
+    Zx = np.asarray(Zx, dtype=np.float32)
+    n, w = Zx.shape
+    pad = (n + 15) // 16 * 16
+    flat = np.zeros((pad, w), dtype=np.float32)
+    flat[:n] = scale * Zx
+    return np.ascontiguousarray(flat.reshape(pad // 16, 16, w // 16, 4, 4).transpose(0, 2, 3, 1, 4)).reshape(pad, w)
+
+
+def h2_zx_unpack(blocked, n, scale):
+    """Inverse of h2_zx_pack: -> row-major [n, 4d], unscaled."""
+    b = np.asarray(blocked, dtype=np.float32)
+    pad, w = b.shape
+    flat = b.reshape(pad // 16, w // 16, 4, 16, 4).transpose(0, 3, 1, 2, 4).reshape(pad, w)
+    return flat[:n] / scale

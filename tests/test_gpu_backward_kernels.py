@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import h2_zx_pack, rel_err
 from oracle import torch_oracle as TO
 from tspgnn import _lib
 
@@ -232,7 +232,7 @@ def test_lnlstm_gather_backward_h2_fused_dh(cuda_device, rows):
         if arith == "f32":
             K, KT, zx = packed(Kh, cuda_device), packed(Kh, cuda_device, transposed=1), dev(Zx, cuda_device)
         else:
-            K, KT, zx = packed_h2(Kh, cuda_device), packed_h2(np.ascontiguousarray(Kh.T), cuda_device), dev(sc * Zx, cuda_device)
+            K, KT, zx = packed_h2(Kh, cuda_device), packed_h2(np.ascontiguousarray(Kh.T), cuda_device), dev(h2_zx_pack(Zx, sc), cuda_device)
         dz, dc_in, dh_in = empty((rows, 4 * d), cuda_device), empty((rows, d), cuda_device), empty((rows, d), cuda_device)
         ln_grad = empty((10 * d,), cuda_device, 0.0)
         wsl = ws("tspgnn_lnlstm_bwd_workspace_floats", d, device=cuda_device)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import h2_zx_pack, h2_zx_unpack, rel_err
 from oracle import np_oracle as NO
 from tspgnn import _lib
 
@@ -33,6 +33,21 @@ def _release_uploads():
 
 ARITHS = ["h2", "x3"]
 PIECES = {"x3": 3, "h2": 2}
+
+
+def zx_in(arith, Zx):
+    """Projected messages as the cell of this arithmetic reads them."""
+    return h2_zx_pack(Zx, zscale("h2")) if arith == "h2" else Zx
+
+
+def zx_buffer(arith, n, width, device):
+    rows = (n + 15) // 16 * 16 if arith == "h2" else n
+    return torch.empty((rows, width), dtype=torch.float32, device=device)
+
+
+def zx_out(arith, t, n):
+    """What a projection of this arithmetic wrote, as the row-major unscaled [n, 4d] matrix."""
+    return h2_zx_unpack(t.cpu().numpy(), n, zscale("h2")) if arith == "h2" else t.cpu().numpy()
 
 
 def zscale(arith):
@@ -138,7 +153,7 @@ def test_mlp_two_tasks_with_projection(cuda_device, arith, d):
     P = (rng.randn(d, 4 * d) / np.sqrt(d)).astype(np.float32)
     Ya = torch.empty((rows_a, d), dtype=torch.float32, device=cuda_device)
     Yb = torch.empty((rows_b, d), dtype=torch.float32, device=cuda_device)
-    Zb = torch.empty((rows_b, 4 * d), dtype=torch.float32, device=cuda_device)
+    Zb = zx_buffer(arith, rows_b, 4 * d, cuda_device)
     ta = _lib.MlpTask(_lib.ptr(dev(Xa, cuda_device)), _lib.ptr(mlp_blocks(arith, la, cuda_device)), _lib.ptr(Ya), None, 0, rows_a, 3,
                       0b111, None, None)
     tb = _lib.MlpTask(_lib.ptr(dev(Xb, cuda_device)), _lib.ptr(mlp_blocks(arith, lb, cuda_device)), _lib.ptr(Yb), None, 0, rows_b, 4,
@@ -153,7 +168,7 @@ def test_mlp_two_tasks_with_projection(cuda_device, arith, d):
         xb = NO.dense(xb, W.astype(np.float64), b.astype(np.float64), l < 3)
     assert rel_err(Ya.cpu().numpy(), xa) < 2e-6
     assert rel_err(Yb.cpu().numpy(), xb) < 2e-6
-    assert rel_err(Zb.cpu().numpy(), zscale(arith) * (xb @ P.astype(np.float64))) < 2e-6
+    assert rel_err(zx_out(arith, Zb, rows_b), xb @ P.astype(np.float64)) < 2e-6
 
 
 def ln_params(rng, d):
@@ -208,7 +223,7 @@ def test_lnlstm_gather_init_and_zbias_tasks_in_one_launch(cuda_device, arith, d)
     hv_o = torch.empty((N, d), dtype=torch.float32, device=cuda_device); cv_o = torch.empty_like(hv_o)
     te = _lib.LstmTask(None, 0, _lib.ptr(dev(he, cuda_device)), _lib.ptr(dev(ce, cuda_device)), _lib.ptr(packed(arith, Kh, cuda_device)),
                        _lib.ptr(dev(ln_e, cuda_device)), _lib.ptr(he_o), _lib.ptr(ce_o), M,
-                       _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev(zscale(arith) * Zx, cuda_device)), None, None)
+                       _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev(zx_in(arith, Zx), cuda_device)), None, None)
     tv = _lib.LstmTask(_lib.ptr(dev(xv, cuda_device)), d, _lib.ptr(dev(hv, cuda_device)), _lib.ptr(dev(cv, cuda_device)),
                        _lib.ptr(packed(arith, Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o), N,
                        None, None, _lib.ptr(dev(zb, cuda_device)), _lib.ptr(dev(deg, cuda_device)))
@@ -248,10 +263,10 @@ def test_cell_fused_with_next_step_mlp(cuda_device, arith, d):
     f32 = dict(dtype=torch.float32, device=cuda_device)
     he_o, ce_o, ae_o = torch.empty((M, d), **f32), torch.empty((M, d), **f32), torch.empty((M, d), **f32)
     hv_o, cv_o, yv_o = torch.empty((N, d), **f32), torch.empty((N, d), **f32), torch.empty((N, d), **f32)
-    zv_o = torch.empty((N, 4 * d), **f32)
+    zv_o = zx_buffer(arith, N, 4 * d, cuda_device)
     te = _lib.LstmTask(None, 0, _lib.ptr(dev(he, cuda_device)), _lib.ptr(dev(ce, cuda_device)), _lib.ptr(packed(arith, Kh, cuda_device)),
                        _lib.ptr(dev(ln_e, cuda_device)), _lib.ptr(he_o), _lib.ptr(ce_o), M,
-                       _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev(zscale(arith) * Zx, cuda_device)), None, None)
+                       _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev(zx_in(arith, Zx), cuda_device)), None, None)
     tv = _lib.LstmTask(_lib.ptr(dev(xv, cuda_device)), d, _lib.ptr(dev(hv, cuda_device)), _lib.ptr(dev(cv, cuda_device)),
                        _lib.ptr(packed(arith, Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o), N,
                        None, None, _lib.ptr(dev(zb, cuda_device)), _lib.ptr(dev(deg, cuda_device)))
@@ -274,7 +289,7 @@ def test_cell_fused_with_next_step_mlp(cuda_device, arith, d):
     for l, (W, b) in enumerate(lv):
         y = NO.dense(y, W.astype(np.float64), b.astype(np.float64), l < 3)
     assert rel_err(yv_o.cpu().numpy(), y) < 5e-6
-    assert rel_err(zv_o.cpu().numpy(), zscale(arith) * (y @ P.astype(np.float64))) < 5e-6
+    assert rel_err(zx_out(arith, zv_o, N), y @ P.astype(np.float64)) < 5e-6
 
 
 @pytest.mark.parametrize("arith", ARITHS)

@@ -80,14 +80,14 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
         const bool valid = row < rows;
         const unsigned rc = (unsigned)(valid ? row : rows - 1);
         f32x4 acc[NT4];
-        if (uv != nullptr) {  // gather-init mode: Zx as the f16x2 projection wrote it (2^s Zx)
+        if (uv != nullptr) {  // gather-init mode: Zx as the f16x2 projection wrote it (2^s Zx, blocked by 16 rows)
             const int2 ends = uv[rc];
-            const float* zu = Zx + ((unsigned)ends.x * (4 * D) + g * 4);
-            const float* zv = Zx + ((unsigned)ends.y * (4 * D) + g * 4);
+            const float* zu = Zx + h2_zx_row<D>((unsigned)ends.x, g);
+            const float* zv = Zx + h2_zx_row<D>((unsigned)ends.y, g);
 #pragma unroll
-            for (int t = 0; t < NT4; ++t) acc[t] = ld4(zu + t * 16);
+            for (int t = 0; t < NT4; ++t) acc[t] = ld4(zu + t * 256);
 #pragma unroll
-            for (int t = 0; t < NT4; ++t) acc[t] += ld4(zv + t * 16);
+            for (int t = 0; t < NT4; ++t) acc[t] += ld4(zv + t * 256);
         } else {
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};

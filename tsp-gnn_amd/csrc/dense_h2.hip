@@ -87,7 +87,8 @@ constexpr int kMaxTasksH2 = 4;
 
 // ---------------------------------------------------------------------------------- MLP (f16x2)
 // Task fields as tspgnn_mlp_task; wb points at n_layers blocks of { fp16 packed[2*D*D] , float bias[D] (= 2^s b) };
-// proj_w at an fp16 packed [2 * D * 4D] matrix; proj_out = 2^s * (Y P): it feeds the scaled z of an f16x2 cell.
+// proj_w at an fp16 packed [2 * D * 4D] matrix; proj_out = 2^s * (Y P) in the blocked layout of h2_tile.h: it feeds the
+// scaled z of an f16x2 cell.
 struct MlpTaskTableH2 {
     tspgnn_mlp_task task[kMaxTasksH2];
     int blk_end[kMaxTasksH2];
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(1024) void mlp_fwd_h2_kernel(const MlpTaskTableH2 t
             }
             if (valid) {
 #pragma unroll
-                for (int t = 0; t < NP; ++t) st4(proj_out + rc * 4 * D + t * 16 + g * 4, acc[t]);
+                for (int t = 0; t < NP; ++t) st4(proj_out + h2_zx_row<D>((unsigned)rc, g) + t * 256, acc[t]);
             }
         }
     }
@@ -275,12 +276,12 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     auto init_acc = [&](f32x4 (&acc)[NT4], unsigned rc) {
         if (uv != nullptr) {
             const int2 ends = uv[rc];
-            const float* zu = Zx + ((unsigned)ends.x * (4 * D) + g * 4);
-            const float* zv = Zx + ((unsigned)ends.y * (4 * D) + g * 4);
+            const float* zu = Zx + h2_zx_row<D>((unsigned)ends.x, g);
+            const float* zv = Zx + h2_zx_row<D>((unsigned)ends.y, g);
 #pragma unroll
-            for (int t = 0; t < NT4; ++t) acc[t] = ld4(zu + t * 16);
+            for (int t = 0; t < NT4; ++t) acc[t] = ld4(zu + t * 256);
 #pragma unroll
-            for (int t = 0; t < NT4; ++t) acc[t] += ld4(zv + t * 16);
+            for (int t = 0; t < NT4; ++t) acc[t] += ld4(zv + t * 256);
         } else if (zbias != nullptr) {
             const float sc = zscale[rc] * kH2Scale;
 #pragma unroll
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                     }
                     if (valid) {
 #pragma unroll
-                        for (int t = 0; t < NT4; ++t) st4(proj_out + (rc * (4 * D) + t * 16 + g * 4), acc[t]);
+                        for (int t = 0; t < NT4; ++t) st4(proj_out + h2_zx_row<D>(rc, g) + t * 256, acc[t]);
                     }
                 }
             }

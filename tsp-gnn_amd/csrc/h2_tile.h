@@ -36,6 +36,18 @@ __device__ __forceinline__ void split2(const float (&x)[8], f16x8& hi, f16x8& lo
     }
 }
 
+// The projected messages Zx = 2^s (y Kx) between an f16x2 projection (producer, vertex rows) and an f16x2 cell in
+// gather-init mode (consumer, edge rows) are stored BLOCKED by 16 source rows: the float4 (columns 16t + 4g .. +3) of
+// row v lives at  (((v / 16) * (D/4) + t) * 4 + g) * 64 + (v % 16) * 4  floats.  The producer's 16-row tile then stores
+// 1 KiB contiguous per instruction, and the consumer -- lane (rl, g) gathers row v_rl, and consecutive edges of a graph
+// have consecutive far endpoints -- finds the four lanes of a load quad in ONE 64-byte segment instead of in four
+// different 1 KB rows (the L1 looks up a line per distinct segment of a quad: 64 -> ~20 cycles per gather instruction).
+// Rows are padded to a multiple of 16.  h2_zx_row(v, g): offset of (v, t = 0, g); add 256 floats per tile t.
+template <int D>
+__device__ __forceinline__ unsigned h2_zx_row(unsigned v, int g) {
+    return (v >> 4) * (unsigned)(D / 4 * 256) + (unsigned)g * 64u + (v & 15u) * 4u;
+}
+
 __device__ __forceinline__ f16x8 ldw(const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); }
 
 // acc[t] += W-block(kb, all NT tiles) x B for one 32-feature k-block; wh / wl = the two pieces of the packed matrix

@@ -34,6 +34,11 @@ GEMM_ARITH = {"f16x2": "h2", "bf16x3": "x3", "f32": None}
 SPLIT_BYTES = {"x3": 6, "h2": 4}
 
 
+def _pad16(rows):
+    """Row count of a projected-message buffer of the f16x2 kernels (blocked by 16 source rows, include/tspgnn.h)."""
+    return (int(rows) + 15) // 16 * 16
+
+
 def _dev_i32(a, device):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
 
@@ -320,10 +325,16 @@ class LayerNormBasicLSTMCell(object):
         """Zx = y Kx  ([n_src, 4d]); ``scale``: times 2^s for an f16x2 cell, whose z carries that factor."""
         if out is None:
             out = torch.empty((y.shape[0], 4 * self.d), dtype=torch.float32, device=y.device)
-        _lib.call("tspgnn_linear_f32", _lib.ptr(y), self.dx, _lib.ptr(self.kx_packed()), None, 0, _lib.ptr(out),
-                  4 * self.d, 0, y.shape[0], _lib.current_stream())
-        if scale is not None:
-            out.mul_(scale)
+        if scale is None:
+            _lib.call("tspgnn_linear_f32", _lib.ptr(y), self.dx, _lib.ptr(self.kx_packed()), None, 0, _lib.ptr(out),
+                      4 * self.d, 0, y.shape[0], _lib.current_stream())
+            return out
+        # the f16x2 cells' projected-message format: times 2^s, blocked by 16 source rows (include/tspgnn.h)
+        n, d4 = y.shape[0], 4 * self.d
+        flat = torch.zeros((_pad16(n), d4), dtype=torch.float32, device=y.device)
+        _lib.call("tspgnn_linear_f32", _lib.ptr(y), self.dx, _lib.ptr(self.kx_packed()), None, 0, _lib.ptr(flat), d4, 0, n,
+                  _lib.current_stream())
+        out.view(-1, d4 // 16, 4, 16, 4).copy_(flat.mul_(scale).view(-1, 16, d4 // 16, 4, 4).permute(0, 2, 3, 1, 4))
         return out
 
     def gather_call(self, adj, zx, state, out=None):
@@ -768,7 +779,7 @@ class GraphNN(object):
                 rows, width = states[u["var"]].h.shape[0], self._msg_MLPs[u["msg"]].sizes[-1]
                 for p in (0, 1):
                     if folded[v] is not None:
-                        zxs[p][v] = torch.empty((rows, 4 * self.var[v]), **f32)
+                        zxs[p][v] = torch.empty((_pad16(rows), 4 * self.var[v]), **f32)   # (fused plan: f16x2 / x3 only)
                     else:
                         mo[p][(v, i)] = torch.empty((rows, width), **f32)
         keep = [buf, mo, zxs]
@@ -894,7 +905,7 @@ class GraphNN(object):
                             continue
                         proj = None
                         if folded[v] is not None:   # Zx = msg(y) Kx rides in the MLP launch
-                            zxs[v] = torch.empty((y.shape[0], 4 * self.var[v]), **f32)
+                            zxs[v] = torch.empty((_pad16(y.shape[0]), 4 * self.var[v]), **f32)
                             cv = self._RNN_cells[v]
                             proj = (cv._packed_split(arith, "lstm.kx", 0, cv.dx) if arith else cv.kx_packed(), zxs[v])
                         mlp_tasks.setdefault(mlp.sizes[-1], []).append(mlp.task(y, out, proj=proj, arith=arith))
@@ -907,7 +918,7 @@ class GraphNN(object):
                     if v in zxs:
                         zx = zxs[v]
                     else:
-                        zx = torch.empty((msg_out[(v, 0)].shape[0], 4 * d), **f32)
+                        zx = torch.empty((_pad16(msg_out[(v, 0)].shape[0]), 4 * d), **f32)
                         mid.append((cell.premultiply, (msg_out[(v, 0)], zx, zx_scale)))
                     lstm_tasks.setdefault(d, []).append(cell.gather_task(mats[folded[v]["mat"]], zx, st, out, arith=arith))
                     keep.append(zx)
@@ -1055,7 +1066,7 @@ class GraphNN(object):
             rows_x = n[v] if u is None else n[u["var"]]
             tape.X[v] = torch.empty((T, rows_x, self._RNN_cells[v].dx), **f32)
             if u is not None:
-                tape.ZX[v] = torch.empty((T, rows_x, 4 * self.var[v]), **f32)
+                tape.ZX[v] = torch.empty((T, _pad16(rows_x), 4 * self.var[v]), **f32)
         tape.acts = {}
         # forward GEMMs in the split-operand arithmetic selected by self.gemm (fp32-class accuracy).  With f16x2 the
         # cells' backward recomputes z in the same arithmetic (tspgnn_lnlstm_bwd_multi_h2; the tape's projected
@@ -1109,7 +1120,8 @@ class GraphNN(object):
                     u = tape.folded[v]
                     if "msg" not in u:   # with a message MLP, Zx was produced by the MLP launch itself
                         tape.X[v][t].copy_(msg_out[(v, 0)])
-                        self._RNN_cells[v].premultiply(tape.X[v][t], out=tape.ZX[v][t])
+                        self._RNN_cells[v].premultiply(tape.X[v][t], out=tape.ZX[v][t],
+                                                       scale=_lib.lib.tspgnn_h2_weight_scale() if arith == "h2" else None)
                     continue
                 single = len(self.loop[v]) == 1
                 inputs = []
@@ -1158,7 +1170,7 @@ class GraphNN(object):
         ws = {v: _lib.workspace("tspgnn_lnlstm_bwd_workspace_floats", d, device=device).zero_() for v, d in self.var.items()}
         folded = tape.folded
         bwd_arith = "h2" if getattr(tape, "arith", None) == "h2" else None   # the cells' backward follows the forward
-        DZX = {v: torch.empty_like(tape.ZX[v]) for v in self.var if folded[v] is not None}
+        DZX = {v: torch.empty((T, tape.X[v].shape[1], 4 * self.var[v]), **f32) for v in self.var if folded[v] is not None}
         dH = {v: (dstates.get(v, (None, None))[0]) for v in self.var}
         dC = {v: (dstates.get(v, (None, None))[1]) for v in self.var}
         for t in range(T - 1, -1, -1):
