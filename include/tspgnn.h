@@ -171,6 +171,12 @@ typedef struct tspgnn_cell_mlp_task {
     tspgnn_lstm_task cell;
     const void* mlp_wb; int mlp_layers; unsigned relu_mask; float* mlp_out;
     const void* proj_w; float* proj_out;
+    /* _h2 entry points only (the others require 0): the states h, c are read / h_out, c_out are written BLOCKED by 16
+     * rows -- float4 (columns 16t + 4g .. +3) of row r at (((r/16) * d/16 + t) * 4 + g) * 64 + (r%16) * 4, buffers of
+     * ceil(rows/16)*16 rows -- instead of row-major.  A state that only this launch sequence reads (the T-step loop's
+     * ping-pong buffers) is then loaded and stored 1 KiB contiguous per instruction instead of as 16-byte pieces of 16
+     * different rows. */
+    int state_in_blocked; int state_out_blocked;
 } tspgnn_cell_mlp_task;
 int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream);
 

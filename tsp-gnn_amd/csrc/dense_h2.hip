@@ -240,6 +240,8 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     float* __restrict__ mlp_out = tt.task[k].mlp_out;
     const _Float16* __restrict__ proj_w = reinterpret_cast<const _Float16*>(tt.task[k].proj_w);
     float* __restrict__ proj_out = tt.task[k].proj_out;
+    const bool in_blk = tt.task[k].state_in_blocked != 0, out_blk = tt.task[k].state_out_blocked != 0;
+    const int in_ts = in_blk ? 256 : 16, out_ts = out_blk ? 256 : 16;   // floats between the 16-column tiles of a state row
     const int tiles_total = (rows + 15) / 16;
     const int KBT = (dx + D) >> 5;       // k-blocks in total
     const int kbc = tt.kbc[k];
@@ -294,10 +296,10 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     // k-blocks [kb0, kb1) of the concatenated [x | h] operand; lds_w holds the chunk starting at kb_base
     auto kloop = [&](f32x4 (&acc)[NT4], unsigned rc, int kb_base, int kb0, int kb1) {
         const float* xrow = x + (rc * (unsigned)dx + g * 4);
-        const float* hrow = h + (rc * D + g * 4);
+        const float* hrow = h + h2_state_row<D>(rc, g, in_blk);
         for (int kb = kb0; kb < kb1; ++kb) {
-            const float* src = kb < KBX ? xrow + kb * 32 : hrow + (kb - KBX) * 32;
-            const f32x4 lo4 = ld4(src), hi4 = ld4(src + 16);
+            const float* src = kb < KBX ? xrow + kb * 32 : hrow + (kb - KBX) * 2 * in_ts;
+            const f32x4 lo4 = ld4(src), hi4 = ld4(src + (kb < KBX ? 16 : in_ts));
             float xv[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
             f16x8 bh, bl;
             split2(xv, bh, bl);
@@ -309,12 +311,12 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         f32x4 nc[TPG];
         lstm_gates<D, true, H2_LN_SWAP != 0>(acc, cf, lds_ln, g, hn, nc, kH2GateEps);
         if (valid) {
-            float* hd = h_out + (rc * D + g * 4);
-            float* cd = c_out + (rc * D + g * 4);
+            float* hd = h_out + h2_state_row<D>(rc, g, out_blk);
+            float* cd = c_out + h2_state_row<D>(rc, g, out_blk);
 #pragma unroll
             for (int t = 0; t < TPG; ++t) {
-                st4(hd + t * 16, hn[t]);
-                st4(cd + t * 16, nc[t]);
+                st4(hd + t * out_ts, hn[t]);
+                st4(cd + t * out_ts, nc[t]);
             }
         }
     };
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 f32x4 acc[NT4], cf[TPG];
                 init_acc(acc, rc);
 #pragma unroll
-                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + (rc * D + g * 4 + t * 16));
+                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts);
                 kloop(acc, rc, 0, 0, KBT);
                 cell(acc, cf, rc, valid, hn);
             }
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 f32x4 acc[NT4], cf[TPG];
                 init_acc(acc, rc);
 #pragma unroll
-                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + (rc * D + g * 4 + t * 16));
+                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts);
                 for (int kb0 = 0; kb0 < KBT; kb0 += kbc) {
                     const int kb1 = min(KBT, kb0 + kbc);
                     __syncthreads();

@@ -48,6 +48,13 @@ __device__ __forceinline__ unsigned h2_zx_row(unsigned v, int g) {
     return (v >> 4) * (unsigned)(D / 4 * 256) + (unsigned)g * 64u + (v & 15u) * 4u;
 }
 
+// The same blocking for a [rows, D] state array (h, c of the T-step loop's ping-pong buffers): offset of (r, t = 0, g)
+// and the stride between tiles t, row-major when `blocked` is false.
+template <int D>
+__device__ __forceinline__ unsigned h2_state_row(unsigned r, int g, bool blocked) {
+    return blocked ? (r >> 4) * (unsigned)(D / 16 * 256) + (unsigned)g * 64u + (r & 15u) * 4u : r * (unsigned)D + (unsigned)g * 4u;
+}
+
 __device__ __forceinline__ f16x8 ldw(const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); }
 
 // acc[t] += W-block(kb, all NT tiles) x B for one 32-feature k-block; wh / wl = the two pieces of the packed matrix

@@ -767,8 +767,28 @@ class GraphNN(object):
         if any(len(c) != 1 for c in consumers.values()):
             return None
         f32 = dict(dtype=torch.float32, device=self.store.theta.device)
-        buf = [{v: LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) for v, st in states.items()},
-               {v: LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h)) for v, st in states.items()}]
+        # f16x2: the states of a folded (edge-side) variable live BLOCKED by 16 rows between the steps (include/tspgnn.h,
+        # tspgnn_cell_mlp_task.state_*_blocked): nothing but the variable's own cell task reads them -- the message MLP
+        # takes h' from registers -- so the loop's ping-pong buffers are loaded and stored 1 KiB contiguous per
+        # instruction; the first step reads the caller's row-major states, the last one writes row-major again.
+        blocked = {v: arith == "h2" and folded[v] is not None for v in self.var}
+        rows_of = {v: st.h.shape[0] for v, st in states.items()}
+
+        def state_buffers(init):
+            out = {}
+            for v, st in states.items():
+                if blocked[v]:
+                    hb = torch.empty((_pad16(rows_of[v]), st.h.shape[1]), **f32)
+                    cb = torch.empty((_pad16(rows_of[v]), st.c.shape[1]), **f32)
+                    if init:
+                        hb[:rows_of[v]].copy_(st.h)
+                        cb[:rows_of[v]].copy_(st.c)
+                    out[v] = LSTMStateTuple(c=cb, h=hb)
+                else:
+                    out[v] = LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) if init else \
+                        LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h))
+            return out
+        buf = [state_buffers(True), state_buffers(False)]
         pushed = {v: self._pushable(v, mats, folded) for v in self.var}
         # message outputs / projected messages, double-buffered by step parity (a launch reads one set and
         # writes the other)
@@ -796,11 +816,15 @@ class GraphNN(object):
             out = mo[p].get((v, i))
             return (mlp.wb_packed_split(arith, 0, n - 1, d), n, mlp.relu_mask(0, n), out, pw, po)
 
-        def cell_tasks(p, with_messages):
+        def cell_tasks(p, with_messages, first):
+            """Launches of a step of parity p; ``first``: the step reads the caller's (row-major) states; a step
+            without messages is the last one and writes row-major states."""
             src, dst = buf[p], buf[1 - p]
             mid, tasks = [], {}
             for v, d in self.var.items():
-                cell, st = self._RNN_cells[v], src[v]
+                cell = self._RNN_cells[v]
+                n_v = rows_of[v]
+                st = LSTMStateTuple(c=src[v].c[:n_v], h=src[v].h[:n_v])
                 out = (dst[v].h, dst[v].c)
                 if folded[v] is not None:
                     t = cell.gather_task(mats[folded[v]["mat"]], zxs[p][v], st, out, arith=arith)
@@ -831,12 +855,14 @@ class GraphNN(object):
                         t = cell.pushed_task(x, st, out, kp, zb, deg)
                     else:
                         t = cell.task(x, st, out, arith=arith)
+                s_in = 1 if blocked[v] and not first else 0
+                s_out = 1 if blocked[v] and with_messages else 0
                 if with_messages:   # the message MLP that reads this variable's new h in the next step
                     (cv, ci), = consumers[v]
                     wb, n, mask, mout, pw, po = message(cv, ci, 1 - p)
-                    ct = _lib.CellMlpTask(t, _lib.ptr(wb), n, mask, _lib.ptr(mout), _lib.ptr(pw), _lib.ptr(po))
+                    ct = _lib.CellMlpTask(t, _lib.ptr(wb), n, mask, _lib.ptr(mout), _lib.ptr(pw), _lib.ptr(po), s_in, s_out)
                 else:
-                    ct = _lib.CellMlpTask(t, None, 0, 0, None, None, None)
+                    ct = _lib.CellMlpTask(t, None, 0, 0, None, None, None, s_in, s_out)
                 tasks.setdefault(d, []).append(ct)
             calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in tasks.items() for k in range(0, len(ts), 4)]
             return mid, calls
@@ -846,7 +872,7 @@ class GraphNN(object):
         for v in self.var:
             for i, u in enumerate(self.loop[v]):
                 wb, n, mask, mout, pw, po = message(v, i, 0)
-                y = buf[0][u["var"]].h
+                y = buf[0][u["var"]].h[:rows_of[u["var"]]]
                 if mout is None:
                     mout = torch.empty((y.shape[0], self._msg_MLPs[u["msg"]].sizes[-1]), **f32)
                     keep.append(mout)
@@ -854,20 +880,23 @@ class GraphNN(object):
                     _lib.MlpTask(_lib.ptr(y), _lib.ptr(wb), _lib.ptr(mout), None, 0, y.shape[0], n, mask,
                                  _lib.ptr(pw), _lib.ptr(po)))
         pre_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in pre.items() for k in range(0, len(ts), 4)]
-        steps = [cell_tasks(p, True) for p in (0, 1)]
-        lasts = [cell_tasks(p, False) for p in (0, 1)]
+        built = {}
         self._plan_keep = keep
 
         def run(T):
             for arr, d in pre_calls:
                 _lib.call_multi("tspgnn_mlp_fwd_multi_" + arith, arr, d)
             for t in range(T):
-                mid, calls = (steps if t < T - 1 else lasts)[t & 1]
+                kind = (t & 1, t < T - 1, t == 0)
+                if kind not in built:
+                    built[kind] = cell_tasks(*kind)
+                mid, calls = built[kind]
                 for fn, args in mid:
                     fn(*args)
                 for arr, d in calls:
                     _lib.call_multi("tspgnn_lnlstm_mlp_fwd_multi_" + arith, arr, d)
-            return buf[T & 1]
+            final = buf[T & 1]
+            return {v: LSTMStateTuple(c=final[v].c[:rows_of[v]], h=final[v].h[:rows_of[v]]) for v in self.var}
         return run
 
     def _plan(self, states, mats, folded):
