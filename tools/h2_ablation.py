@@ -24,18 +24,18 @@ SKIP_GATES = '''{
                     if (valid) {
 #pragma unroll
                         for (int t = 0; t < TPG; ++t) {
-                            st4(h_out + (rc * D + g * 4) + t * 16, hn[t]);
-                            st4(c_out + (rc * D + g * 4) + t * 16, hn[t]);
+                            st4(h_out + h2_state_row<D>(rc, g, out_blk) + t * out_ts, hn[t]);
+                            st4(c_out + h2_state_row<D>(rc, g, out_blk) + t * out_ts, hn[t]);
                         }
                     }
                 }'''
 
-rep('            const float* zv = Zx + ((unsigned)ends.y * (4 * D) + g * 4);',
-    '            const float* zv = Zx + ((unsigned)((H2_ABL & 32) ? __builtin_amdgcn_readfirstlane(ends.y) : ends.y) * (4 * D) + g * 4);')
+rep('            const float* zv = Zx + h2_zx_row<D>((unsigned)ends.y, g);',
+    '            const float* zv = Zx + h2_zx_row<D>((unsigned)((H2_ABL & 32) ? __builtin_amdgcn_readfirstlane(ends.y) : ends.y), g);')
 # resident (edge) tile loop
 rep('''                init_acc(acc, rc);
 #pragma unroll
-                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + (rc * D + g * 4 + t * 16));
+                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts);
                 kloop(acc, rc, 0, 0, KBT);
                 cell(acc, cf, rc, valid, hn);
             }
@@ -48,7 +48,7 @@ rep('''                init_acc(acc, rc);
                 } else
                     init_acc(acc, rc);
 #pragma unroll
-                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + (rc * D + g * 4 + t * 16));
+                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts);
                 if constexpr (!(H2_ABL & 2)) kloop(acc, rc, 0, 0, KBT);
                 if constexpr (H2_ABL & 4) ''' + SKIP_GATES + ''' else
                     cell(acc, cf, rc, valid, hn);
@@ -57,22 +57,21 @@ rep('''                init_acc(acc, rc);
                 for (int l = 0; l < n_layers; ++l) {
                     const _Float16* wh = reinterpret_cast<const _Float16*>(lds_mlp''')
 # lock-step (vertex) rounds
-rep('''        const int rounds = (tiles_total + nw - 1) / nw;
+rep('''        const int rounds = (tiles_total + lw - 1) / lw;
         for (int r = my_blk; r < rounds; r += my_grid) {''',
-    '''        const int rounds = (H2_ABL & 16) ? 0 : (tiles_total + nw - 1) / nw;
+    '''        const int rounds = (H2_ABL & 16) ? 0 : (tiles_total + lw - 1) / lw;
         for (int r = my_blk; r < rounds; r += my_grid) {''')
 rep('''                    __syncthreads();
                     stage(kb0, kb1);
                     h2_stage_wait();
                     __syncthreads();
-                    if (live) kloop(acc, rc, kb0, kb0, kb1);''',
+                    if (live && pre) {''',
     '''                    __syncthreads();
                     if constexpr (!(H2_ABL & 512)) stage(kb0, kb1);
                     h2_stage_wait();
                     __syncthreads();
-                    if constexpr (!(H2_ABL & 128)) {
-                        if (live) kloop(acc, rc, kb0, kb0, kb1);
-                    }''')
+                    if (H2_ABL & 128) {
+                    } else if (live && pre) {''')
 rep('''                if (n_layers > 0) {  // every wavefront is done with K''', '''                if (n_layers > 0 && !(H2_ABL & 64)) {  // every wavefront is done with K''')
 rep('''                cell(acc, cf, rc, valid, hn);
             }

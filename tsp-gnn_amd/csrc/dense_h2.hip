@@ -208,6 +208,7 @@ struct CellTaskTableH2 {
     int kbc[kMaxTasksH2];       // k-blocks (32 rows of K) per LDS chunk
     int lockstep[kMaxTasksH2];  // 0: K and the MLP resident together, tiles by ticket; 1: lock-step rounds
     int together[kMaxTasksH2];  // lock-step: MLP layers and projection matrix staged together
+    int lock_tiles[kMaxTasksH2];  // lock-step: tiles (= working wavefronts) per workgroup and round, <= wavefronts per workgroup
     int n;
 };
 
@@ -365,10 +366,13 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         // lock-step rounds: one tile per wavefront; K (whole or chunk by chunk), then the MLP + the projection
         const bool together = tt.together[k] != 0;
         unsigned char* lds_proj = together ? lds_wb + (size_t)n_layers * LAYER_BYTES : lds_wb;
-        const int rounds = (tiles_total + nw - 1) / nw;
+        // (fewer working wavefronts per workgroup than it has -- lock_tiles -- spread the task over more CUs: its GEMMs
+        // are bound by the matrix pipes of the few CUs it runs on)
+        const int lw = tt.lock_tiles[k];
+        const int rounds = (tiles_total + lw - 1) / lw;
         for (int r = my_blk; r < rounds; r += my_grid) {
-            const int tile = r * nw + wave;
-            const bool live = tile < tiles_total;
+            const int tile = r * lw + wave;
+            const bool live = wave < lw && tile < tiles_total;
             const int row = tile * 16 + rl;
             const bool valid = live && row < rows;
             const unsigned rc = (unsigned)(valid ? row : rows - 1);
@@ -378,13 +382,43 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 init_acc(acc, rc);
 #pragma unroll
                 for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts);
+                // The [x | h] operand rows of up to four k-blocks are fetched before the K staging is waited for: every
+                // wavefront of the workgroup is in the same phase here, nobody hides a global round trip per k-block.
+                constexpr int KBP = 4;
+                const bool pre = KBT <= KBP;
+                f32x4 opr[2 * KBP];
+                if (pre) {
+                    const float* xrow = x + (rc * (unsigned)dx + g * 4);
+                    const float* hrow = h + h2_state_row<D>(rc, g, in_blk);
+#pragma unroll
+                    for (int kb = 0; kb < KBP; ++kb) {
+                        if (kb < KBT) {
+                            const float* src = kb < KBX ? xrow + kb * 32 : hrow + (kb - KBX) * 2 * in_ts;
+                            opr[2 * kb] = ld4(src);
+                            opr[2 * kb + 1] = ld4(src + (kb < KBX ? 16 : in_ts));
+                        }
+                    }
+                }
                 for (int kb0 = 0; kb0 < KBT; kb0 += kbc) {
                     const int kb1 = min(KBT, kb0 + kbc);
                     __syncthreads();
                     stage(kb0, kb1);
                     h2_stage_wait();
                     __syncthreads();
-                    if (live) kloop(acc, rc, kb0, kb0, kb1);
+                    if (live && pre) {
+#pragma unroll
+                        for (int kb = 0; kb < KBP; ++kb) {
+                            if (kb >= kb0 && kb < kb1) {
+                                const f32x4 lo4 = opr[2 * kb], hi4 = opr[2 * kb + 1];
+                                float xv[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                                f16x8 bh, bl;
+                                split2(xv, bh, bl);
+                                kblock_h2<NT4>(acc, lds_w, lds_w + chunk_total, kb - kb0, g, rl, bh, bl);
+                            }
+                        }
+                    } else if (live) {
+                        kloop(acc, rc, kb0, kb0, kb1);
+                    }
                 }
                 if (n_layers > 0) {  // every wavefront is done with K: the next residency loads behind the gates
                     __syncthreads();
@@ -484,6 +518,18 @@ static int h2_cell_waves() {
     return nw;
 }
 
+// Working wavefronts per workgroup of a lock-step task (development switch TSPGNN_H2_LOCK_TILES; default: all of them --
+// 8 / 6 / 4 measured 40.3 / 54.1 / 52.3 us per C2 launch against 37.9: the edge task misses the CUs more than the vertex
+// chain gains from emptier matrix pipes).
+static int h2_lock_tiles() {
+    static const int v = [] {
+        const char* e = getenv("TSPGNN_H2_LOCK_TILES");
+        const int x = e ? atoi(e) : 0;
+        return (x >= 1 && x <= 16) ? x : 16;
+    }();
+    return v;
+}
+
 template <int D>
 static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t st, const char* what) {
     const size_t head = (10 * D + 4) * sizeof(float);
@@ -502,6 +548,7 @@ static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
         const size_t k_bytes = (size_t)KBT * per_kb;
         size_t need;
         tt.together[k] = 0;
+        tt.lock_tiles[k] = 0;
         if (k_bytes + L * layer_all <= budget && !tasks[k].proj_w) {
             tt.kbc[k] = KBT;
             tt.lockstep[k] = 0;
@@ -550,7 +597,9 @@ static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
             fixed[k] = 0;
             if (tt.lockstep[k]) {
                 const long long tiles = ((long long)tasks[k].cell.rows + 15) / 16;
-                const long long per_round = (tiles + nw - 1) / nw;
+                const int lw = nw < h2_lock_tiles() ? nw : h2_lock_tiles();
+                tt.lock_tiles[k] = lw;
+                const long long per_round = (tiles + lw - 1) / lw;
                 long long share = (2 * cost[k] * grid + total_cost - 1) / total_cost;  // twice the proportional share
                 if (share < 1) share = 1;
                 const long long n_rounds = (per_round + share - 1) / share;
