@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import h2_zx_pack, h2_zx_unpack, rel_err
 from oracle import np_oracle as NO
 from tspgnn import _lib
 
@@ -101,7 +101,7 @@ def test_mlp_bf16_two_tasks_with_projection(cuda_device, d, rows):
     P = (rng.randn(d, 4 * d) / np.sqrt(d)).astype(np.float32)
     Ya = torch.empty((rows, d), dtype=torch.bfloat16, device=cuda_device)
     Yb = torch.empty((rows_b, d), dtype=torch.bfloat16, device=cuda_device)
-    Zb = torch.empty((rows_b, 4 * d), dtype=torch.bfloat16, device=cuda_device)
+    Zb = torch.zeros(((rows_b + 15) // 16 * 16, 4 * d), dtype=torch.bfloat16, device=cuda_device)   # blocked by 16 rows
     ta = _lib.MlpTaskB(_lib.ptr(dev_bf16(Xa, cuda_device)), _lib.ptr(mlp_blocks_bf16(la, cuda_device)), _lib.ptr(Ya), rows, 3, 0b111,
                        None, None)
     tb = _lib.MlpTaskB(_lib.ptr(dev_bf16(Xb, cuda_device)), _lib.ptr(mlp_blocks_bf16(lb, cuda_device)), _lib.ptr(Yb), rows_b, 4,
@@ -117,7 +117,7 @@ def test_mlp_bf16_two_tasks_with_projection(cuda_device, d, rows):
     ra, rbb = chain(Xa, la, [True] * 3), chain(Xb, lb, [True, True, True, False])
     assert rel_err(f64(Ya), ra) < BF16_TOL
     assert rel_err(f64(Yb), rbb) < BF16_TOL
-    assert rel_err(f64(Zb), f64(Yb) @ rb(P)) < 2.0 ** -7       # projection of the kernel's own (stored) Y: one rounding
+    assert rel_err(h2_zx_unpack(f64(Zb), rows_b, 1.0), f64(Yb) @ rb(P)) < 2.0 ** -7       # projection of the kernel's own (stored) Y: one rounding
 
 
 def ln_params(rng, d):
@@ -126,10 +126,17 @@ def ln_params(rng, d):
     return ln, {g: (ln[i, 0].astype(np.float64), ln[i, 1].astype(np.float64)) for i, g in enumerate(names)}
 
 
+@pytest.mark.parametrize("c_blocked", [(False, False), (True, True), (False, True)], ids=["rowmajor", "blocked", "rm-to-blocked"])
 @pytest.mark.parametrize("d", [32, 64, 128])
-def test_lnlstm_bf16_gather_and_plain_tasks(cuda_device, d):
-    """Edge-style task (gather-init from bf16 Zx, Kh resident) and vertex-style task (x|h with the [2d,4d] kernel,
-    streamed through LDS at d=128) in one launch."""
+def test_lnlstm_bf16_gather_and_plain_tasks(cuda_device, d, c_blocked):
+    """Edge-style task (gather-init from the blocked bf16 Zx, Kh resident) and vertex-style task (x|h with the [2d,4d]
+    kernel, streamed through LDS at d=128) in one launch; the cell state c row-major or blocked by 16 rows on either side."""
+    def c_dev(c, blocked):
+        return dev(h2_zx_pack(c, 1.0) if blocked else c, cuda_device)
+
+    def c_host(t, rows, blocked):
+        return h2_zx_unpack(t.cpu().numpy(), rows, 1.0) if blocked else t.cpu().numpy()[:rows]
+    cin, cout = c_blocked
     rng = np.random.RandomState(7 + d)
     N, M = 301, 5003
     uv = np.stack([rng.randint(0, N, M), rng.randint(0, N, M)], 1).astype(np.int32)
@@ -141,21 +148,23 @@ def test_lnlstm_bf16_gather_and_plain_tasks(cuda_device, d):
     Kv = (rng.randn(2 * d, 4 * d) / np.sqrt(2 * d)).astype(np.float32)
     ln_v, lnd_v = ln_params(rng, d)
     he_o = torch.empty((M, d), dtype=torch.bfloat16, device=cuda_device)
-    ce_o = torch.empty((M, d), dtype=torch.float32, device=cuda_device)
+    pad = lambda r: (r + 15) // 16 * 16
+    ce_o = torch.zeros((pad(M), d), dtype=torch.float32, device=cuda_device)
     hv_o = torch.empty((N, d), dtype=torch.bfloat16, device=cuda_device)
-    cv_o = torch.empty((N, d), dtype=torch.float32, device=cuda_device)
-    te = _lib.LstmTaskB(None, 0, _lib.ptr(dev_bf16(he, cuda_device)), _lib.ptr(dev(ce, cuda_device)), _lib.ptr(packed_bf16(Kh, cuda_device)),
+    cv_o = torch.zeros((pad(N), d), dtype=torch.float32, device=cuda_device)
+    te = _lib.LstmTaskB(None, 0, _lib.ptr(dev_bf16(he, cuda_device)), _lib.ptr(c_dev(ce, cin)), _lib.ptr(packed_bf16(Kh, cuda_device)),
                         _lib.ptr(dev(ln_e, cuda_device)), _lib.ptr(he_o), _lib.ptr(ce_o), M,
-                        _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev_bf16(Zx, cuda_device)))
-    tv = _lib.LstmTaskB(_lib.ptr(dev_bf16(xv, cuda_device)), d, _lib.ptr(dev_bf16(hv, cuda_device)), _lib.ptr(dev(cv, cuda_device)),
+                        _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev_bf16(h2_zx_pack(rb(Zx), 1.0), cuda_device)),
+                        int(cin), int(cout))
+    tv = _lib.LstmTaskB(_lib.ptr(dev_bf16(xv, cuda_device)), d, _lib.ptr(dev_bf16(hv, cuda_device)), _lib.ptr(c_dev(cv, cin)),
                         _lib.ptr(packed_bf16(Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o), N,
-                        None, None)
+                        None, None, int(cin), int(cout))
     _lib.call_multi("tspgnn_lnlstm_fwd_multi_bf16", [te, tv], d)
     torch.cuda.synchronize()
     z0 = rb(Zx)[uv[:, 0]] + rb(Zx)[uv[:, 1]]
     rh, rc = NO.lnlstm(np.zeros((M, 0)), rb(he), ce.astype(np.float64), rb(Kh), lnd_e, z0=z0)
-    assert rel_err(ce_o.cpu().numpy(), rc) < F32_TOL            # nothing is rounded on the way to c'
+    assert rel_err(c_host(ce_o, M, cout), rc) < F32_TOL            # nothing is rounded on the way to c'
     assert rel_err(f64(he_o), rb(rh)) < 2.0 ** -7
     rh, rc = NO.lnlstm(rb(xv), rb(hv), cv.astype(np.float64), rb(Kv), lnd_v)
-    assert rel_err(cv_o.cpu().numpy(), rc) < F32_TOL
+    assert rel_err(c_host(cv_o, N, cout), rc) < F32_TOL
     assert rel_err(f64(hv_o), rb(rh)) < 2.0 ** -7

@@ -19,6 +19,20 @@ __device__ __forceinline__ bf16x8 ldw8(const __bf16* p) { return *reinterpret_ca
 __device__ __forceinline__ bf16x4 ldw4(const __bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
 __device__ __forceinline__ void stw4(__bf16* p, bf16x4 v) { *reinterpret_cast<bf16x4*>(p) = v; }
 
+// The bf16 projected-message format (Zx between the vertex MLP's projection and the edge cell's gather): [rows padded to 16,
+// 4D] bf16, blocked by 16 rows like the f16x2 path's (h2_tile.h) -- the four bf16 (cols 16t+4g..+3) of row v at
+// (((v/16)*NT4 + t)*4 + g)*64 + (v%16)*4 -- so a gather instruction of 16 consecutive far endpoints reads 512 contiguous
+// bytes instead of 16 rows.  zx_blocked(v, g): offset of (v, t = 0, g); add 256 elements per tile t.
+template <int D>
+__device__ __forceinline__ size_t zx_blocked(unsigned v, int g) {
+    return (size_t)(v >> 4) * (D / 4 * 256) + (unsigned)g * 64u + (v & 15u) * 4u;
+}
+// The same blocking for the fp32 cell state c of the loop's ping-pong buffers (read and written by the cell only).
+template <int D>
+__device__ __forceinline__ size_t c_blocked(unsigned r, int g, bool blocked) {
+    return blocked ? (size_t)(r >> 4) * (D / 16 * 256) + (unsigned)g * 64u + (r & 15u) * 4u : (size_t)r * D + (unsigned)g * 4u;
+}
+
 __device__ __forceinline__ f32x4 widen(bf16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 __device__ __forceinline__ bf16x4 narrow(f32x4 v) { return bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; }
 __device__ __forceinline__ bf16x8 join(bf16x4 lo, bf16x4 hi) {
@@ -213,7 +227,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_bf16_kernel(const MlpTableB t
             }
             if (valid) {
 #pragma unroll
-                for (int t = 0; t < NP; ++t) stw4(proj_out + rc * 4 * D + t * 16 + g * 4, narrow(acc[t]));
+                for (int t = 0; t < NP; ++t) stw4(proj_out + zx_blocked<D>((unsigned)rc, g) + t * 256, narrow(acc[t]));
             }
         }
     }
@@ -244,6 +258,7 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTabl
     const float* __restrict__ ln = tt.task[k].ln;
     __bf16* __restrict__ h_out = reinterpret_cast<__bf16*>(tt.task[k].h_out);
     float* __restrict__ c_out = tt.task[k].c_out;
+    const bool c_in_blk = tt.task[k].c_in_blocked != 0, c_out_blk = tt.task[k].c_out_blocked != 0;
     const int rows = tt.task[k].rows;
     const int2* __restrict__ uv = reinterpret_cast<const int2*>(tt.task[k].uv);
     const __bf16* __restrict__ Zx = reinterpret_cast<const __bf16*>(tt.task[k].Zx);
@@ -272,10 +287,10 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTabl
     auto init_acc = [&](f32x4 (&acc)[NT4], size_t rc) {
         if (uv != nullptr) {
             const int2 ends = uv[rc];
-            const __bf16* zu = Zx + (size_t)ends.x * 4 * D + g * 4;
-            const __bf16* zv = Zx + (size_t)ends.y * 4 * D + g * 4;
+            const __bf16* zu = Zx + zx_blocked<D>((unsigned)ends.x, g);
+            const __bf16* zv = Zx + zx_blocked<D>((unsigned)ends.y, g);
 #pragma unroll
-            for (int t = 0; t < NT4; ++t) acc[t] = widen(ldw4(zu + t * 16)) + widen(ldw4(zv + t * 16));
+            for (int t = 0; t < NT4; ++t) acc[t] = widen(ldw4(zu + t * 256)) + widen(ldw4(zv + t * 256));
         } else {
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -294,13 +309,13 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTabl
     auto cell = [&](f32x4 (&acc)[NT4], size_t rc, bool valid) {
         f32x4 cf[TPG], hn[TPG], nc[TPG];
 #pragma unroll
-        for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + rc * D + g * 4 + t * 16);
+        for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + c_blocked<D>((unsigned)rc, g, c_in_blk) + t * (c_in_blk ? 256 : 16));
         lstm_gates<D, true, true>(acc, cf, lds_ln, g, hn, nc);
         if (valid) {
 #pragma unroll
             for (int t = 0; t < TPG; ++t) {
                 stw4(h_out + rc * D + g * 4 + t * 16, narrow(hn[t]));
-                st4(c_out + rc * D + g * 4 + t * 16, nc[t]);
+                st4(c_out + c_blocked<D>((unsigned)rc, g, c_out_blk) + t * (c_out_blk ? 256 : 16), nc[t]);
             }
         }
     };

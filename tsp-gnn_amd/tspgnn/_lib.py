@@ -114,7 +114,8 @@ class MlpTaskB(ctypes.Structure):
 class LstmTaskB(ctypes.Structure):
     """tspgnn_lstm_task_bf16 (include/tspgnn.h)."""
     _fields_ = [("x", c_void_p), ("dx", c_int), ("h", c_void_p), ("c", c_void_p), ("K", c_void_p), ("ln", c_void_p),
-                ("h_out", c_void_p), ("c_out", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p)]
+                ("h_out", c_void_p), ("c_out", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p),
+                ("c_in_blocked", c_int), ("c_out_blocked", c_int)]
 
 
 class LstmBwdTask(ctypes.Structure):

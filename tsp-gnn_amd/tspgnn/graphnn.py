@@ -247,16 +247,16 @@ class LayerNormBasicLSTMCell(object):
         n = (rows_hi - rows_lo) * 4 * self.d
         return self._packed_x3(key, rows_lo, rows_hi)[:2 * n]
 
-    def task_bf16(self, x, state, out):
-        """tspgnn_lstm_task_bf16: x, h, h_out bf16; c, c_out fp32."""
-        return _lib.LstmTaskB(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c),
-                              _lib.ptr(self._packed_bf16("lstm.x3", 0, self.dx + self.d)), _lib.ptr(self.ln()),
-                              _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None)
-
-    def gather_task_bf16(self, adj, zx, state, out):
-        return _lib.LstmTaskB(None, 0, _lib.ptr(state.h), _lib.ptr(state.c),
-                              _lib.ptr(self._packed_bf16("lstm.kh.x3", self.dx, self.dx + self.d)), _lib.ptr(self.ln()),
-                              _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], _lib.ptr(adj.uv), _lib.ptr(zx))
+    def task_bf16(self, x, h, c, h_out, c_out, adj=None, c_in_blocked=False, c_out_blocked=False):
+        """tspgnn_lstm_task_bf16: x, h, h_out bf16; c, c_out fp32 (blocked by 16 rows when flagged).  With adj, the
+        gather-init form: x is the blocked bf16 Zx of the source rows, K = Kh."""
+        if adj is None:
+            K = self._packed_bf16("lstm.x3", 0, self.dx + self.d)
+            return _lib.LstmTaskB(_lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(K), _lib.ptr(self.ln()),
+                                  _lib.ptr(h_out), _lib.ptr(c_out), h.shape[0], None, None, int(c_in_blocked), int(c_out_blocked))
+        K = self._packed_bf16("lstm.kh.x3", self.dx, self.dx + self.d)
+        return _lib.LstmTaskB(None, 0, _lib.ptr(h), _lib.ptr(c), _lib.ptr(K), _lib.ptr(self.ln()), _lib.ptr(h_out),
+                              _lib.ptr(c_out), h.shape[0], _lib.ptr(adj.uv), _lib.ptr(x), int(c_in_blocked), int(c_out_blocked))
 
     def x3_ok(self):
         """The split-operand cell kernels cover this shape (tspgnn_lnlstm_fwd_multi_x3 / _h2)."""
@@ -657,8 +657,13 @@ class GraphNN(object):
                         raise NotImplementedError("bf16 storage needs square message MLPs of at most 4 layers")
         if T == 0:
             return states
-        buf = [{v: LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) for v, st in states.items()},
-               {v: LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h)) for v, st in states.items()}]
+        # h ping-pongs between two row-major buffers (the message MLPs read it); c, which only the cells touch, between two
+        # buffers blocked by 16 rows (include/tspgnn.h), entering row-major at step 0 and leaving row-major at step T-1
+        f32 = dict(dtype=torch.float32, device=self.store.theta.device)
+        hbuf = [{v: st.h.clone() for v, st in states.items()}, {v: torch.empty_like(st.h) for v, st in states.items()}]
+        cblk = [{v: torch.empty((_pad16(st.c.shape[0]), st.c.shape[1]), **f32) for v, st in states.items()} for _ in (0, 1)]
+        c_first = {v: st.c.contiguous() for v, st in states.items()}
+        c_last = {v: torch.empty_like(st.c) for v, st in states.items()}
 
         def folds(v):   # single gather over a two-ones-per-row matrix behind a message MLP: Zx = msg(y) Kx on source rows
             if not self.fold_adjacency or len(self.loop[v]) != 1:
@@ -668,13 +673,13 @@ class GraphNN(object):
                 return None
             return u if self._RNN_cells[v].dx == self._msg_MLPs[u["msg"]].sizes[-1] == self.var[v] else None
         folded = {v: folds(v) for v in self.var}
-        runs, keep = [], [buf]
+        runs, keep = [], [hbuf, cblk, c_first, c_last]
         for p in (0, 1):
-            src, dst = buf[p], buf[1 - p]
-            mlp_tasks, lstm_tasks, mid, msg_out, zxs = {}, {}, [], {}, {}
+            src, dst = hbuf[p], hbuf[1 - p]
+            mlp_tasks, cell_in, mid, msg_out, zxs = {}, {}, [], {}, {}
             for v in self.var:
                 for i, u in enumerate(self.loop[v]):
-                    y = src[u["var"]].h
+                    y = src[u["var"]]
                     if "msg" in u:
                         mlp = self._msg_MLPs[u["msg"]]
                         d = mlp.sizes[-1]
@@ -682,7 +687,7 @@ class GraphNN(object):
                         pw = po = None
                         if folded[v] is not None:
                             cv = self._RNN_cells[v]
-                            zxs[v] = torch.empty((y.shape[0], 4 * self.var[v]), **bf)
+                            zxs[v] = torch.empty((_pad16(y.shape[0]), 4 * self.var[v]), **bf)
                             pw, po = cv._packed_bf16("lstm.kx", 0, cv.dx), zxs[v]
                         n = mlp.n_square
                         mlp_tasks.setdefault(d, []).append(_lib.MlpTaskB(
@@ -691,10 +696,9 @@ class GraphNN(object):
                         y = out
                     msg_out[(v, i)] = y
             for v, d in self.var.items():
-                cell, st = self._RNN_cells[v], src[v]
-                out = (dst[v].h, dst[v].c)
+                cell = self._RNN_cells[v]
                 if folded[v] is not None:
-                    lstm_tasks.setdefault(d, []).append(cell.gather_task_bf16(mats[folded[v]["mat"]], zxs[v], st, out))
+                    cell_in[v] = (mats[folded[v]["mat"]], zxs[v])
                     continue
                 inputs = []
                 for i, u in enumerate(self.loop[v]):
@@ -708,11 +712,11 @@ class GraphNN(object):
                 if len(inputs) == 1:
                     x = inputs[0]
                 else:
-                    x = torch.empty((st.h.shape[0], cell.dx), **bf)
+                    x = torch.empty((src[v].shape[0], cell.dx), **bf)
                     mid.append((lambda ins, o: torch.cat(ins, dim=1, out=o), (inputs, x)))
-                if x.shape[0] != st.h.shape[0] or x.shape[1] != cell.dx:
-                    raise ValueError("cell input must be [%d,%d], got %s" % (st.h.shape[0], cell.dx, tuple(x.shape)))
-                lstm_tasks.setdefault(d, []).append(cell.task_bf16(x, st, out))
+                if x.shape[0] != src[v].shape[0] or x.shape[1] != cell.dx:
+                    raise ValueError("cell input must be [%d,%d], got %s" % (src[v].shape[0], cell.dx, tuple(x.shape)))
+                cell_in[v] = (None, x)
                 keep.append(x)
             keep += [msg_out, zxs]
             # tasks with a projection go to their own launch: without them the MLP kernel needs a third of the
@@ -721,18 +725,33 @@ class GraphNN(object):
             for d, ts in mlp_tasks.items():
                 for group in ([t for t in ts if not t.proj_w], [t for t in ts if t.proj_w]):
                     mlp_calls += [(_lib.task_array(group[k:k + 4]), d) for k in range(0, len(group), 4)]
-            lstm_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in lstm_tasks.items() for k in range(0, len(ts), 4)]
-            runs.append((mlp_calls, mid, lstm_calls))
+            runs.append((mlp_calls, mid, cell_in))
+
+        cell_calls = {}
+
+        def cells(p, first, last):
+            key = (p, first, last)
+            if key not in cell_calls:
+                tasks = {}
+                for v, d in self.var.items():
+                    adj, x = runs[p][2][v]
+                    c_in = c_first[v] if first else cblk[p][v]
+                    c_out = c_last[v] if last else cblk[1 - p][v]
+                    tasks.setdefault(d, []).append(self._RNN_cells[v].task_bf16(
+                        x, hbuf[p][v], c_in, hbuf[1 - p][v], c_out, adj=adj, c_in_blocked=not first, c_out_blocked=not last))
+                cell_calls[key] = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in tasks.items() for k in range(0, len(ts), 4)]
+            return cell_calls[key]
+        keep.append(cell_calls)
         self._plan_keep = keep
         for t in range(T):
-            mlp_calls, mid, lstm_calls = runs[t & 1]
+            mlp_calls, mid, _ = runs[t & 1]
             for arr, d in mlp_calls:
                 _lib.call_multi("tspgnn_mlp_fwd_multi_bf16", arr, d)
             for fn, args in mid:
                 fn(*args)
-            for arr, d in lstm_calls:
+            for arr, d in cells(t & 1, t == 0, t == T - 1):
                 _lib.call_multi("tspgnn_lnlstm_fwd_multi_bf16", arr, d)
-        return _States(buf[T & 1], keep)
+        return _States({v: LSTMStateTuple(c=c_last[v], h=hbuf[T & 1][v]) for v in states}, keep)
 
     def _split_arith(self, n_rows=None):
         """"h2" / "x3" when the selected split-operand kernels cover this network (widths 32/64, cell inputs in
