@@ -177,6 +177,10 @@ typedef struct tspgnn_cell_mlp_task {
      * ping-pong buffers) is then loaded and stored 1 KiB contiguous per instruction instead of as 16-byte pieces of 16
      * different rows. */
     int state_in_blocked; int state_out_blocked;
+    /* _h2 entry points only (the others require NULL): training forward -- the MLP's hidden activations (outputs of its
+     * layers 0 .. mlp_layers-2, after the ReLU) are also stored, layer l of row r at mlp_acts[l*mlp_acts_stride + r*d],
+     * exactly what tspgnn_mlp_task.acts receives from the plain MLP launch (the backward's tape). */
+    float* mlp_acts; long long mlp_acts_stride;
 } tspgnn_cell_mlp_task;
 int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream);
 

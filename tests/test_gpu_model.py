@@ -201,6 +201,44 @@ def test_gradient_parity_with_autograd_oracle(cuda_device, name, d, T):
           % (name, d, T, worst, worst32))
 
 
+@pytest.mark.parametrize("name,d,T", [("ragged_B6", 64, 4), ("n5_B2", 32, 1), ("n20_B32", 64, 3)])
+def test_training_forward_fused_messages_write_the_same_tape(cuda_device, name, d, T):
+    """The training forward with the message MLPs inside the cell launches (f16x2 default) leaves the tape of the
+    two-launch form: the same device functions run on the same operands, so every saved tensor is bit-identical."""
+    t = pack_tuple(name, 1)
+    params = P.init_params(d, seed=5, perturb=True)
+    tapes = []
+    for fuse in (True, False):   # (the default is the two-launch form)
+        model = tspgnn.build_network(d)
+        sess = tspgnn.Session(model)
+        sess.run(tspgnn.global_variables_initializer())
+        model.store.load(params)
+        gnn = model["gnn"]
+        gnn.fuse_training_messages = fuse
+        EV, W, C = t[0], t[1], t[2]
+        dev = sess.device
+        M, N = EV.shape
+        E0 = torch.randn((M, d), generator=torch.Generator().manual_seed(3)).to(dev)
+        V0 = torch.randn((N, d), generator=torch.Generator().manual_seed(4)).to(dev)
+        states, tape = gnn.forward_train({"EV": EV}, {"V": V0, "E": E0}, T)
+        torch.cuda.synchronize()
+        assert tape.fused == fuse
+        tapes.append(tape)
+    a, b = tapes
+    for name_ in ("H", "C", "X"):
+        for v in getattr(a, name_):
+            assert torch.equal(getattr(a, name_)[v], getattr(b, name_)[v]), (name_, v)
+
+    def rows_of(zx, n):   # blocked projected messages -> row-major, without the padding rows of the last block
+        steps, pad, w = zx.shape
+        return zx.view(steps, pad // 16, w // 16, 4, 16, 4).permute(0, 1, 4, 2, 3, 5).reshape(steps, pad, w)[:, :n]
+    for v in a.ZX:
+        n_src = a.X[v].shape[1]
+        assert torch.equal(rows_of(a.ZX[v], n_src), rows_of(b.ZX[v], n_src)), ("ZX", v)
+    for key in a.acts:
+        assert torch.equal(a.acts[key], b.acts[key]), key
+
+
 def test_train_steps_follow_the_oracle(cuda_device):
     """Three sess.run(train_step) calls (L2 + clip-by-global-norm 0.65 + Adam lr 2e-5) vs the oracle's."""
     t = pack_tuple("ragged_B6", 0)

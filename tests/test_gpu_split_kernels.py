@@ -270,17 +270,25 @@ def test_cell_fused_with_next_step_mlp(cuda_device, arith, d):
     tv = _lib.LstmTask(_lib.ptr(dev(xv, cuda_device)), d, _lib.ptr(dev(hv, cuda_device)), _lib.ptr(dev(cv, cuda_device)),
                        _lib.ptr(packed(arith, Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o), N,
                        None, None, _lib.ptr(dev(zb, cuda_device)), _lib.ptr(dev(deg, cuda_device)))
-    tasks = [_lib.CellMlpTask(te, _lib.ptr(mlp_blocks(arith, le, cuda_device)), 3, 0b111, _lib.ptr(ae_o), None, None),
+    # f16x2 (the training forward): the hidden activations of both MLPs are saved as well; the vertex task's with an
+    # explicit layer stride, the edge task's with the default rows * d
+    acts_e = torch.zeros((2, M, d), **f32) if arith == "h2" else None
+    acts_v = torch.zeros((3, 2, N, d), **f32) if arith == "h2" else None
+    tasks = [_lib.CellMlpTask(te, _lib.ptr(mlp_blocks(arith, le, cuda_device)), 3, 0b111, _lib.ptr(ae_o), None, None, 0, 0,
+                              _lib.ptr(acts_e), 0),
              _lib.CellMlpTask(tv, _lib.ptr(mlp_blocks(arith, lv, cuda_device)), 4, 0b0111, _lib.ptr(yv_o),
-                              _lib.ptr(packed(arith, P, cuda_device)), _lib.ptr(zv_o))]
+                              _lib.ptr(packed(arith, P, cuda_device)), _lib.ptr(zv_o), 0, 0,
+                              _lib.ptr(acts_v[:, 1]) if arith == "h2" else None, 2 * N * d)]
     _lib.call_multi("tspgnn_lnlstm_mlp_fwd_multi_" + arith, tasks, d)
     torch.cuda.synchronize()
     z0 = Zx.astype(np.float64)[uv[:, 0]] + Zx.astype(np.float64)[uv[:, 1]]
     rh, rc = NO.lnlstm(np.zeros((M, 0)), he.astype(np.float64), ce.astype(np.float64), Kh.astype(np.float64), lnd_e, z0=z0)
     assert rel_err(ce_o.cpu().numpy(), rc) < 5e-6 and rel_err(he_o.cpu().numpy(), rh) < 5e-6
     a = rh
-    for W, b in le:
+    for l, (W, b) in enumerate(le):
         a = NO.dense(a, W.astype(np.float64), b.astype(np.float64), True)
+        if arith == "h2" and l < 2:
+            assert rel_err(acts_e[l].cpu().numpy(), a) < 5e-6
     assert rel_err(ae_o.cpu().numpy(), a) < 5e-6
     z0 = deg.astype(np.float64)[:, None] * zb.astype(np.float64)[None]
     rh, rc = NO.lnlstm(xv.astype(np.float64), hv.astype(np.float64), cv.astype(np.float64), Kv.astype(np.float64), lnd_v, z0=z0)
@@ -288,8 +296,23 @@ def test_cell_fused_with_next_step_mlp(cuda_device, arith, d):
     y = rh
     for l, (W, b) in enumerate(lv):
         y = NO.dense(y, W.astype(np.float64), b.astype(np.float64), l < 3)
+        if arith == "h2" and l < 3:
+            assert rel_err(acts_v[l, 1].cpu().numpy(), y) < 5e-6
+    if arith == "h2":
+        assert float(acts_v[:, 0].abs().max()) == 0.0          # the other time slot of the strided buffer is untouched
     assert rel_err(yv_o.cpu().numpy(), y) < 5e-6
     assert rel_err(zx_out(arith, zv_o, N), y @ P.astype(np.float64)) < 5e-6
+
+
+def test_cell_fused_x3_rejects_activation_saving(cuda_device):
+    d, rows = 32, 16
+    f32 = dict(dtype=torch.float32, device=cuda_device)
+    z, ho, co = torch.zeros((rows, 4 * d), **f32), torch.zeros((rows, d), **f32), torch.zeros((rows, d), **f32)
+    t = _lib.LstmTask(_lib.ptr(z), d, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(ho), _lib.ptr(co), rows,
+                      None, None, None, None)
+    task = _lib.CellMlpTask(t, _lib.ptr(z), 2, 0b11, _lib.ptr(z), None, None, 0, 0, _lib.ptr(z), 0)
+    with pytest.raises(_lib.TspgnnError, match="f16x2 feature"):
+        _lib.call_multi("tspgnn_lnlstm_mlp_fwd_multi_x3", [task], d)
 
 
 @pytest.mark.parametrize("arith", ARITHS)

@@ -196,8 +196,9 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const LstmBwdTaskTa
     auto finish = [&](f32x4 (&acc)[NT4], size_t rc, bool valid) {
         f32x4 dco[TPG];
         const size_t o = rc * D + g * 4;
-        lstm_tile_backward<D>(acc, c + o, dh_out ? dh_out + o : nullptr, dc_out_in ? dc_out_in + o : nullptr, dco,
-                              lds_ln, slab, g, rl, valid);
+        f32x4 cf[TPG], dhn[TPG], dcn[TPG];
+        lstm_tile_load<D>(c + o, dh_out ? dh_out + o : nullptr, dc_out_in ? dc_out_in + o : nullptr, cf, dhn, dcn);
+        lstm_tile_backward<D>(acc, cf, dhn, dcn, dco, lds_ln, slab, g, rl, valid);
         if (valid) {
 #pragma unroll
             for (int t = 0; t < NT4; ++t) st4(dz + rc * 4 * D + t * 16 + g * 4, acc[t]);

@@ -92,6 +92,10 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        // c, dh', dc' of the tile: issued here so that their latency hides behind the GEMM
+        const unsigned o = rc * D + g * 4;
+        f32x4 cf[TPG], dhn[TPG], dcn[TPG];
+        lstm_tile_load<D>(c + o, dh_out ? dh_out + o : nullptr, dc_out_in ? dc_out_in + o : nullptr, cf, dhn, dcn);
         {
             const float* xrow = x + (rc * (unsigned)dx + g * 4);
             const float* hrow = h + (rc * D + g * 4);
@@ -105,9 +109,7 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
             }
         }
         f32x4 dco[TPG];
-        const unsigned o = rc * D + g * 4;
-        lstm_tile_backward<D>(acc, c + o, dh_out ? dh_out + o : nullptr, dc_out_in ? dc_out_in + o : nullptr, dco, lds_ln,
-                              slab, g, rl, valid, kH2GateEps);
+        lstm_tile_backward<D, true>(acc, cf, dhn, dcn, dco, lds_ln, slab, g, rl, valid, kH2GateEps);
         if (valid) {
             const f32x2 sc2 = {kH2Scale, kH2Scale};
 #pragma unroll

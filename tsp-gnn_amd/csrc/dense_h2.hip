@@ -241,6 +241,8 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     float* __restrict__ mlp_out = tt.task[k].mlp_out;
     const _Float16* __restrict__ proj_w = reinterpret_cast<const _Float16*>(tt.task[k].proj_w);
     float* __restrict__ proj_out = tt.task[k].proj_out;
+    float* __restrict__ mlp_acts = tt.task[k].mlp_acts;   // training: hidden activations of the MLP, [n_layers-1][stride]
+    const long long acts_stride = tt.task[k].mlp_acts_stride;
     const bool in_blk = tt.task[k].state_in_blocked != 0, out_blk = tt.task[k].state_out_blocked != 0;
     const int in_ts = in_blk ? 256 : 16, out_ts = out_blk ? 256 : 16;   // floats between the 16-column tiles of a state row
     const int tiles_total = (rows + 15) / 16;
@@ -355,6 +357,11 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                     const _Float16* wh = reinterpret_cast<const _Float16*>(lds_mlp + (size_t)l * LAYER_BYTES);
                     const float* bias = reinterpret_cast<const float*>(lds_mlp + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
                     dense_layer_h2<D>(hn, wh, wh + D * D, bias, (relu_mask >> l) & 1u, g, rl);
+                    if (mlp_acts != nullptr && l < n_layers - 1 && valid) {
+                        float* dst = mlp_acts + ((size_t)l * acts_stride + (size_t)rc * D + g * 4);
+#pragma unroll
+                        for (int t = 0; t < TPG; ++t) st4(dst + t * 16, hn[t]);
+                    }
                 }
                 if (valid && mlp_out != nullptr) {
 #pragma unroll
@@ -434,6 +441,11 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                     const _Float16* wh = reinterpret_cast<const _Float16*>(lds_wb + (size_t)l * LAYER_BYTES);
                     const float* bias = reinterpret_cast<const float*>(lds_wb + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
                     dense_layer_h2<D>(hn, wh, wh + D * D, bias, (relu_mask >> l) & 1u, g, rl);
+                    if (mlp_acts != nullptr && l < n_layers - 1 && valid) {
+                        float* dst = mlp_acts + ((size_t)l * acts_stride + (size_t)rc * D + g * 4);
+#pragma unroll
+                        for (int t = 0; t < TPG; ++t) st4(dst + t * 16, hn[t]);
+                    }
                 }
                 if (valid && mlp_out != nullptr) {
 #pragma unroll
@@ -694,7 +706,10 @@ static int cell_mlp_h2(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, vo
         TSPGNN_REQUIRE(tasks[k].mlp_layers == 0 || tasks[k].mlp_wb, "%s: mlp_layers > 0 needs mlp_wb", what);
         TSPGNN_REQUIRE(!tasks[k].proj_w || (tasks[k].proj_out && tasks[k].mlp_layers > 0),
                        "%s: a projection needs proj_out and at least one MLP layer", what);
-        live[n++] = tasks[k];
+        TSPGNN_REQUIRE(tasks[k].mlp_acts_stride >= 0, "%s: mlp_acts_stride=%lld", what, tasks[k].mlp_acts_stride);
+        live[n] = tasks[k];
+        if (live[n].mlp_acts && live[n].mlp_acts_stride == 0) live[n].mlp_acts_stride = (long long)t.rows * d;
+        ++n;
     }
     if (n == 0) return TSPGNN_OK;
     return d == 32 ? launch_cell_h2<32>(live, n, as_stream(stream), what) : launch_cell_h2<64>(live, n, as_stream(stream), what);

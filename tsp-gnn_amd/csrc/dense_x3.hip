@@ -674,6 +674,7 @@ static int cell_mlp_x3(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, vo
         TSPGNN_REQUIRE(t.h && t.c && t.K && t.ln && t.h_out && t.c_out && (t.dx == 0 || t.x), "%s: null pointer", what);
         TSPGNN_REQUIRE(t.h_out != t.h && t.c_out != t.c, "%s: outputs may not alias inputs", what);
         TSPGNN_REQUIRE(!tasks[k].state_in_blocked && !tasks[k].state_out_blocked, "%s: blocked states are an f16x2 feature", what);
+        TSPGNN_REQUIRE(!tasks[k].mlp_acts, "%s: saving the MLP's hidden activations is an f16x2 feature", what);
         TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx), "%s: gather-init mode needs dx == 0 and Zx", what);
         TSPGNN_REQUIRE(!t.zbias || (t.zscale && !t.uv), "%s: zbias needs zscale and excludes gather-init mode", what);
         TSPGNN_REQUIRE(tasks[k].mlp_layers == 0 || tasks[k].mlp_wb, "%s: mlp_layers > 0 needs mlp_wb", what);

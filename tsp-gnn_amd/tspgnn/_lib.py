@@ -102,7 +102,8 @@ class CellMlpTask(ctypes.Structure):
     """tspgnn_cell_mlp_task (include/tspgnn.h): a cell update followed by the MLP that consumes the new h."""
     _fields_ = [("cell", LstmTask), ("mlp_wb", c_void_p), ("mlp_layers", c_int), ("relu_mask", c_uint),
                 ("mlp_out", c_void_p), ("proj_w", c_void_p), ("proj_out", c_void_p),
-                ("state_in_blocked", c_int), ("state_out_blocked", c_int)]
+                ("state_in_blocked", c_int), ("state_out_blocked", c_int),
+                ("mlp_acts", c_void_p), ("mlp_acts_stride", ctypes.c_longlong)]
 
 
 class MlpTaskB(ctypes.Structure):

@@ -469,6 +469,10 @@ class GraphNN(object):
         self.float_dtype = float_dtype
         self.store = store if store is not None else V.get_default_store()
         self.fold_adjacency = True   # (EV y) Kx = EV (y Kx) fast path; False = op-for-op reference order
+        # training forward: message MLPs of step t+1 inside the cell launch of step t (TSPGNN_FUSE_TRAINING=1).  Off by
+        # default: the tape makes the training forward HBM-write-bound, and there the two plain launches at full occupancy
+        # measured 0.2 ms per step FASTER than the fused one (C2: 11.75 vs 11.95 ms)
+        self.fuse_training_messages = os.environ.get("TSPGNN_FUSE_TRAINING", "0") == "1"
         # GEMM arithmetic of the inference forward, all fp32-class in accuracy: "f16x2" = fp16 matrix cores on
         # two-piece splits of the fp32 operands (csrc/dense_h2.hip, the default); "bf16x3" = bf16 matrix cores on
         # exact three-piece splits (csrc/dense_x3.hip); "f32" = fp32 MFMA.  TSPGNN_GEMM in the environment selects
@@ -763,6 +767,24 @@ class GraphNN(object):
                 and all(m.sizes[-1] in (32, 64) for m in self._msg_MLPs.values()):
             return GEMM_ARITH[self.gemm]
         return None
+
+    def _single_consumers(self):
+        """{source variable: (v, i)} when every variable's h feeds exactly one loop entry and that entry has a
+        single-kernel square message MLP of the variable's own width (the wiring the fused cell + message launch
+        covers), else None."""
+        consumers = {u: [] for u in self.var}
+        for v in self.var:
+            for i, u in enumerate(self.loop[v]):
+                if "var" not in u or "fun" in u or "msg" not in u:
+                    return None
+                mlp = self._msg_MLPs[u["msg"]]
+                if mlp._plan[0] != "square" or len(mlp._chunks()) != 1 or mlp.n_square < 1 or mlp._plan[3] \
+                        or mlp.sizes[-1] != self.var[u["var"]]:
+                    return None
+                consumers[u["var"]].append((v, i))
+        if any(len(c) != 1 for c in consumers.values()):
+            return None
+        return {u: c[0] for u, c in consumers.items()}
 
     def _plan_fused(self, states, mats, folded):
         """bf16x3 plan with every message MLP fused behind the cell of its SOURCE variable: the launch that
@@ -1131,23 +1153,28 @@ class GraphNN(object):
                     mlp = self._msg_MLPs[u["msg"]]
                     src = u["var"]
                     tape.acts[(v, i)] = torch.empty((max(mlp.n_square - 1, 1), T, n[src], self.var[src]), **f32)
-        for t in range(T):
-            # ---- A: every message MLP of the step in one launch (per width), outputs straight into the tape
+        def message_dest(v, i, t):
+            """(out, projection) of loop entry (v, i)'s message MLP at step t: outputs straight into the tape."""
+            u = self.loop[v][i]
+            mlp = self._msg_MLPs[u["msg"]]
+            to_tape = tape.folded[v] is not None or (len(self.loop[v]) == 1 and "mat" not in u)
+            out = tape.X[v][t] if to_tape else torch.empty((n[u["var"]], mlp.sizes[-1]), **f32)
+            proj = None
+            if tape.folded[v] is not None:
+                cv = self._RNN_cells[v]
+                proj = (cv._packed_split(arith, "lstm.kx", 0, cv.dx) if arith else cv.kx_packed(), tape.ZX[v][t])
+            return out, proj
+
+        def messages(t):
+            """A: every message MLP of step t in one launch (per width); -> {(v, i): message rows}."""
             msg_out, mlp_tasks = {}, {}
             for v in self.var:
-                single = len(self.loop[v]) == 1
                 for i, u in enumerate(self.loop[v]):
-                    src = u["var"]
-                    y = tape.H[src][t]
+                    y = tape.H[u["var"]][t]
                     if "msg" in u:
                         mlp = self._msg_MLPs[u["msg"]]
                         acts = tape.acts[(v, i)]
-                        to_tape = tape.folded[v] is not None or (single and "mat" not in u)
-                        out = tape.X[v][t] if to_tape else torch.empty((n[src], mlp.sizes[-1]), **f32)
-                        proj = None
-                        if tape.folded[v] is not None:
-                            cv = self._RNN_cells[v]
-                            proj = (cv._packed_split(arith, "lstm.kx", 0, cv.dx) if arith else cv.kx_packed(), tape.ZX[v][t])
+                        out, proj = message_dest(v, i, t)
                         task = mlp.task(y, out, acts[:, t], acts.stride(0), proj=proj, arith=arith)
                         if task is None:
                             if arith:
@@ -1162,7 +1189,10 @@ class GraphNN(object):
             for d, ts in mlp_tasks.items():
                 for k in range(0, len(ts), 4):
                     _lib.call_multi(mlp_fn, ts[k:k + 4], d)
-            # ---- B: adjacency products / vertex-side pre-multiplication
+            return msg_out
+
+        def aggregate(t, msg_out):
+            """B: adjacency products / vertex-side pre-multiplication of step t."""
             for v in self.var:
                 if tape.folded[v] is not None:
                     u = tape.folded[v]
@@ -1183,20 +1213,55 @@ class GraphNN(object):
                     inputs.append(y)
                 if not single:
                     torch.cat(inputs, dim=1, out=tape.X[v][t])
-            # ---- C: every cell of the step in one launch (per width)
-            lstm_tasks = {}
-            for v, d in self.var.items():
-                cell = self._RNN_cells[v]
-                st = LSTMStateTuple(c=tape.C[v][t], h=tape.H[v][t])
-                out = (tape.H[v][t + 1], tape.C[v][t + 1])
-                if tape.folded[v] is not None:
-                    task = cell.gather_task(mats[tape.folded[v]["mat"]], tape.ZX[v][t], st, out, arith=arith)
-                else:
-                    task = cell.task(tape.X[v][t], st, out, arith=arith)
-                lstm_tasks.setdefault(d, []).append(task)
-            for d, ts in lstm_tasks.items():
-                for k in range(0, len(ts), 4):
-                    _lib.call_multi(lstm_fn, ts[k:k + 4], d)
+
+        def cell_task(v, t):
+            cell = self._RNN_cells[v]
+            st = LSTMStateTuple(c=tape.C[v][t], h=tape.H[v][t])
+            out = (tape.H[v][t + 1], tape.C[v][t + 1])
+            if tape.folded[v] is not None:
+                return cell.gather_task(mats[tape.folded[v]["mat"]], tape.ZX[v][t], st, out, arith=arith)
+            return cell.task(tape.X[v][t], st, out, arith=arith)
+
+        # f16x2, opt-in (fuse_training_messages): the message MLPs of step t+1 ride in the cell launch of step t, on the
+        # rows of h' it still holds in registers (tspgnn_lnlstm_mlp_fwd_multi_h2 as in the inference plan, here writing
+        # the tape: states, hidden activations, messages and projected messages of every step)
+        consumers = self._single_consumers() if arith == "h2" and self.fuse_training_messages else None
+        tape.fused = consumers is not None
+        if consumers is not None:
+            msg_out = messages(0) if T > 0 else {}
+            for t in range(T):
+                aggregate(t, msg_out)
+                tasks, nxt = {}, {}
+                for v, d in self.var.items():
+                    task = cell_task(v, t)
+                    if t < T - 1:
+                        cv, ci = consumers[v]
+                        mlp = self._msg_MLPs[self.loop[cv][ci]["msg"]]
+                        acts = tape.acts[(cv, ci)]
+                        out, proj = message_dest(cv, ci, t + 1)
+                        pw, po = proj if proj is not None else (None, None)
+                        k = mlp.n_square
+                        ct = _lib.CellMlpTask(task, _lib.ptr(mlp.wb_packed_split(arith, 0, k - 1, d)), k, mlp.relu_mask(0, k),
+                                              _lib.ptr(out), _lib.ptr(pw), _lib.ptr(po), 0, 0,
+                                              _lib.ptr(acts[:, t + 1]) if k > 1 else None, acts.stride(0))
+                        nxt[(cv, ci)] = out
+                    else:
+                        ct = _lib.CellMlpTask(task, None, 0, 0, None, None, None, 0, 0, None, 0)
+                    tasks.setdefault(d, []).append(ct)
+                for d, ts in tasks.items():
+                    for k in range(0, len(ts), 4):
+                        _lib.call_multi("tspgnn_lnlstm_mlp_fwd_multi_h2", ts[k:k + 4], d)
+                msg_out = nxt
+        else:
+            for t in range(T):
+                aggregate(t, messages(t))
+                # ---- C: every cell of the step in one launch (per width)
+                lstm_tasks = {}
+                for v, d in self.var.items():
+                    lstm_tasks.setdefault(d, []).append(cell_task(v, t))
+                for d, ts in lstm_tasks.items():
+                    for k in range(0, len(ts), 4):
+                        _lib.call_multi(lstm_fn, ts[k:k + 4], d)
         states = {v: LSTMStateTuple(c=tape.C[v][T], h=tape.H[v][T]) for v in self.var}
         return states, tape
 
