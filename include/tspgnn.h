@@ -234,6 +234,8 @@ int tspgnn_csr_rowsum_bf16(const int32_t* rowptr, const int32_t* eid, const void
 typedef struct tspgnn_mlp_task_bf16 {
     const void* X; const void* wb; void* Y; int rows; int n_layers; unsigned relu_mask;
     const void* proj_w; void* proj_out;
+    void* acts; long long acts_stride;   /* optional (training): the stored (bf16) hidden activations, layer l of row r
+                                            at acts[l*acts_stride + r*d] (elements); stride 0 = rows*d */
 } tspgnn_mlp_task_bf16;
 typedef struct tspgnn_lstm_task_bf16 {
     const void* x; int dx; const void* h; const float* c; const void* K; const float* ln;

@@ -127,8 +127,10 @@ def message_passing(params, ev_uv, V0, E0, time_steps, dense=False, EV=None, tra
 
 
 def _rb(x):
-    """Round to bf16 (nearest even) and return in the original dtype."""
-    return x.to(torch.bfloat16).to(x.dtype)
+    """Round to bf16 (nearest even) and return in the original dtype.  Straight-through for autograd: the gradient
+    passes unchanged and in the working precision (a plain .to(bfloat16) round trip would also round the gradient
+    flowing back through it) -- the mixed-precision convention the build's bf16 training follows."""
+    return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
 
 
 def message_passing_bf16(params, ev_uv, V0, E0, time_steps):
@@ -138,7 +140,17 @@ def message_passing_bf16(params, ev_uv, V0, E0, time_steps):
     the variables rounded to bf16, sums accumulate in the working precision; the cell state c, LayerNorm, biases
     and gates are not rounded.  The edge cell is evaluated in the folded form (EV y) Kx = EV (y Kx)."""
     uv = torch.as_tensor(np.asarray(ev_uv), dtype=torch.long)
-    d = V0.shape[1]
+    Vh, Vc = _rb(V0), torch.zeros_like(V0)
+    Eh, Ec = _rb(E0), torch.zeros_like(E0)
+    for t in range(int(time_steps)):
+        Vh, Vc, Eh, Ec = step_bf16(params, uv, Vh, Vc, Eh, Ec)
+    return {"V": (Vh, Vc), "E": (Eh, Ec)}
+
+
+def step_bf16(params, uv, Vh, Vc, Eh, Ec):
+    """One message-passing step of message_passing_bf16 on stored (bf16-valued) h and fp32-class c: -> the next
+    (Vh, Vc, Eh, Ec), h rounded for storage.  uv: long tensor [M,2]."""
+    d = Vh.shape[1]
 
     def mlp_b(x, prefix):
         for i in range(4):
@@ -159,16 +171,12 @@ def message_passing_bf16(params, ev_uv, V0, E0, time_steps):
         return _rb(torch.relu(new_c) * torch.sigmoid(o)), new_c
     KV = _rb(params["TSP/V_cell/layer_norm_basic_lstm_cell/kernel"])
     KE = _rb(params["TSP/E_cell/layer_norm_basic_lstm_cell/kernel"])
-    Vh, Vc = _rb(V0), torch.zeros_like(V0)
-    Eh, Ec = _rb(E0), torch.zeros_like(E0)
-    for t in range(int(time_steps)):
-        y = mlp_b(Eh, "TSP/E_msg_V")
-        vagg = _rb(torch.zeros_like(Vh).index_add(0, uv[:, 0], y).index_add(0, uv[:, 1], y))
-        zx = _rb(mlp_b(Vh, "TSP/V_msg_E") @ KE[:d])
-        nVh, nVc = cell_b(torch.cat([vagg, Vh], dim=1) @ KV, Vc, "V")
-        nEh, nEc = cell_b(zx[uv[:, 0]] + zx[uv[:, 1]] + Eh @ KE[d:], Ec, "E")
-        Vh, Vc, Eh, Ec = nVh, nVc, nEh, nEc
-    return {"V": (Vh, Vc), "E": (Eh, Ec)}
+    y = mlp_b(Eh, "TSP/E_msg_V")
+    vagg = _rb(torch.zeros_like(Vh).index_add(0, uv[:, 0], y).index_add(0, uv[:, 1], y))
+    zx = _rb(mlp_b(Vh, "TSP/V_msg_E") @ KE[:d])
+    nVh, nVc = cell_b(torch.cat([vagg, Vh], dim=1) @ KV, Vc, "V")
+    nEh, nEc = cell_b(zx[uv[:, 0]] + zx[uv[:, 1]] + Eh @ KE[d:], Ec, "E")
+    return nVh, nVc, nEh, nEc
 
 
 def forward(params, batch, time_steps, dense=False, trace=None, bf16=False):
@@ -177,24 +185,36 @@ def forward(params, batch, time_steps, dense=False, trace=None, bf16=False):
     batch: dict with ev_uv int[M,2], W[M], C[M], route_exists[B], n_vertices[B], n_edges[B].
     bf16=True: the message passing in the build's bf16-storage mode (message_passing_bf16).
     """
+    V0, E0 = initial_embeddings(params, batch)
+    if bf16:
+        last = message_passing_bf16(params, batch["ev_uv"], V0, E0, time_steps)
+    else:
+        last = message_passing(params, batch["ev_uv"], V0, E0, time_steps, dense=dense, trace=trace)
+    out = vote_head(params, batch, last["E"][0])
+    out["last_states"] = last
+    return out
+
+
+def initial_embeddings(params, batch):
+    """(V0, E0) of model.py:33-51: V_init / sqrt(d) tiled over the vertices, E_init_MLP([W, C])."""
     some = params["V_init"]
     dtype = some.dtype
     d = some.shape[1]
     W = torch.as_tensor(np.asarray(batch["W"]), dtype=dtype).reshape(-1, 1)
     C = torch.as_tensor(np.asarray(batch["C"]), dtype=dtype).reshape(-1, 1)
-    labels = torch.as_tensor(np.asarray(batch["route_exists"]), dtype=dtype)
-    n_vertices = np.asarray(batch["n_vertices"]).astype(np.int64)
-    n_edges = np.asarray(batch["n_edges"]).astype(np.int64)
-    N = int(n_vertices.sum())
+    N = int(np.asarray(batch["n_vertices"]).astype(np.int64).sum())
     # model.py:43
     E0 = mlp(torch.cat([W, C], dim=1), params, "E_init_MLP")
     # model.py:48-51
     V0 = (params["V_init"] / math.sqrt(float(d))).repeat(N, 1)
-    if bf16:
-        last = message_passing_bf16(params, batch["ev_uv"], V0, E0, time_steps)
-    else:
-        last = message_passing(params, batch["ev_uv"], V0, E0, time_steps, dense=dense, trace=trace)
-    E_n = last["E"][0]
+    return V0, E0
+
+
+def vote_head(params, batch, E_n):
+    """model.py:107-157 from the final edge embeddings: votes, per-problem mean, predictions, metrics, loss."""
+    dtype = E_n.dtype
+    labels = torch.as_tensor(np.asarray(batch["route_exists"]), dtype=dtype)
+    n_edges = np.asarray(batch["n_edges"]).astype(np.int64)
     # model.py:128
     E_vote = mlp(E_n, params, "E_vote").reshape(-1)
     # model.py:134-145: mean of each problem's edge-vote segment
@@ -206,7 +226,6 @@ def forward(params, batch, time_steps, dense=False, trace=None, bf16=False):
     eq = (labels == rp).to(dtype)
     ne = (labels != rp).to(dtype)
     out = {
-        "last_states": last,
         "E_vote": E_vote,
         "logits": logits,
         "predictions": pred,
@@ -223,10 +242,11 @@ def forward(params, batch, time_steps, dense=False, trace=None, bf16=False):
     return out
 
 
-def loss_and_grads(params_np, batch, time_steps, dtype=torch.float64, dense=False):
-    """tf.gradients(loss + 1e-10 * sum l2_loss(var)) (model.py:163-166), unclipped."""
+def loss_and_grads(params_np, batch, time_steps, dtype=torch.float64, dense=False, bf16=False):
+    """tf.gradients(loss + 1e-10 * sum l2_loss(var)) (model.py:163-166), unclipped.  bf16=True: of the bf16-storage
+    forward (message_passing_bf16), roundings passed straight through, gradients w.r.t. the unrounded variables."""
     params = to_torch(params_np, dtype=dtype, requires_grad=True)
-    out = forward(params, batch, time_steps, dense=dense)
+    out = forward(params, batch, time_steps, dense=dense, bf16=bf16)
     vars_cost = sum((p ** 2).sum() / 2 for p in params.values())
     total = out["loss"] + L2NORM_SCALING * vars_cost
     grads = torch.autograd.grad(total, list(params.values()))

@@ -150,6 +150,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_bf16_kernel(const MlpTableB t
     const unsigned relu_mask = tt.task[k].relu_mask;
     const __bf16* __restrict__ proj_w = reinterpret_cast<const __bf16*>(tt.task[k].proj_w);
     __bf16* __restrict__ proj_out = reinterpret_cast<__bf16*>(tt.task[k].proj_out);
+    __bf16* __restrict__ acts = reinterpret_cast<__bf16*>(tt.task[k].acts);   // training: the stored hidden activations
+    const long long acts_stride = tt.task[k].acts_stride;
     const int tiles_total = (rows + 15) / 16;
     int* ticket = reinterpret_cast<int*>(lds);
     unsigned char* lds_w = lds + 16;
@@ -191,6 +193,14 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_bf16_kernel(const MlpTableB t
             }
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) b[kb] = join(narrow(acc[2 * kb]), narrow(acc[2 * kb + 1]));  // stored precision
+            if (acts != nullptr && l < n_layers - 1 && valid) {
+                __bf16* dst = acts + (size_t)l * acts_stride + rbase;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    stw4(dst + (2 * kb) * 16, bf16x4{b[kb][0], b[kb][1], b[kb][2], b[kb][3]});
+                    stw4(dst + (2 * kb + 1) * 16, bf16x4{b[kb][4], b[kb][5], b[kb][6], b[kb][7]});
+                }
+            }
         }
         if (valid) {
 #pragma unroll
@@ -474,7 +484,10 @@ extern "C" int tspgnn_mlp_fwd_multi_bf16(const tspgnn_mlp_task_bf16* tasks, int 
         if (t.rows == 0) continue;
         TSPGNN_REQUIRE(t.X && t.wb && t.Y, "mlp_fwd_bf16: null pointer");
         TSPGNN_REQUIRE(!t.proj_w || t.proj_out, "mlp_fwd_bf16: projection needs proj_out");
-        live[n++] = t;
+        TSPGNN_REQUIRE(t.acts_stride >= 0, "mlp_fwd_bf16: acts_stride=%lld", t.acts_stride);
+        live[n] = t;
+        if (live[n].acts && live[n].acts_stride == 0) live[n].acts_stride = (long long)t.rows * d;
+        ++n;
     }
     if (n == 0) return TSPGNN_OK;
     hipStream_t st = as_stream(stream);

@@ -54,6 +54,49 @@ class _States(dict):
         self._keep = keep
 
 
+class Tape(object):
+    """What GraphNN.forward_train keeps for the backward pass: every step's states H, C ([T+1, rows, d]), cell inputs
+    X (for a folded cell: the message y per SOURCE row, with ZX = y Kx), hidden MLP activations acts
+    ([layers-1, T, rows, d]).  fp32 in the default mode; in the bf16-storage mode H, X, ZX, acts are the bf16 arrays
+    the forward stored (C stays fp32) and the accessors below widen a step -- or a range of steps for the weight
+    gradients -- to the fp32 operands the backward kernels take."""
+
+    @staticmethod
+    def _f32(x):
+        return x if x.dtype == torch.float32 else x.to(torch.float32)
+
+    def h(self, v, t):
+        return self._f32(self.H[v][t])
+
+    def x(self, v, t):
+        return self._f32(self.X[v][t])
+
+    def zx(self, v, t):
+        z = self.ZX[v][t]
+        if z.dtype == torch.float32:
+            return z
+        pad, w = z.shape     # bf16 projected messages, blocked by 16 rows (include/tspgnn.h) -> fp32 row-major
+        return z.view(pad // 16, w // 16, 4, 16, 4).permute(0, 3, 1, 2, 4).reshape(pad, w).to(torch.float32)
+
+    def acts_at(self, key, t):
+        """(hidden activations of step t [layers-1, rows, d], element stride between layers)."""
+        a = self.acts[key]
+        if a.dtype == torch.float32:
+            return a[:, t], a.stride(0)
+        w = a[:, t].to(torch.float32)
+        return w, w.stride(0)
+
+    def h_steps(self, v, t0, t1):
+        return self._f32(self.H[v][t0:t1]).reshape(-1, self.H[v].shape[2])
+
+    def x_steps(self, v, t0, t1):
+        return self._f32(self.X[v][t0:t1]).reshape(-1, self.X[v].shape[2])
+
+    def acts_steps(self, key, layer, t0, t1):
+        a = self.acts[key]
+        return self._f32(a[layer, t0:t1]).reshape(-1, a.shape[3])
+
+
 class DeviceAdjacency(object):
     """A sparse [R, C] matrix resident on the device in CSR, both orientations."""
 
@@ -465,10 +508,11 @@ class GraphNN(object):
         self.Msg_last_activation = Msg_last_activation
         if float_dtype not in (torch.float32, torch.bfloat16):
             raise NotImplementedError("GraphNN: float_dtype must be torch.float32 or torch.bfloat16 (bf16 storage of the "
-                                      "embeddings with fp32 accumulation, inference only)")
+                                      "embeddings with fp32 accumulation)")
         self.float_dtype = float_dtype
         self.store = store if store is not None else V.get_default_store()
         self.fold_adjacency = True   # (EV y) Kx = EV (y Kx) fast path; False = op-for-op reference order
+        self.wgrad_chunk_bytes = 24 * 2 ** 30   # backward: budget for the pre-activation gradients kept per weight-gradient chunk
         # training forward: message MLPs of step t+1 inside the cell launch of step t (TSPGNN_FUSE_TRAINING=1).  Off by
         # default: the tape makes the training forward HBM-write-bound, and there the two plain launches at full occupancy
         # measured 0.2 ms per step FASTER than the fused one (C2: 11.75 vs 11.95 ms)
@@ -1109,13 +1153,19 @@ class GraphNN(object):
         """Same computation as __call__, keeping what the backward pass needs: every step's states,
         cell inputs and hidden MLP activations, each stored [T, rows, width] contiguous so that a
         variable's weight gradient is ONE reduction over all time steps (sized for 288 GB of HBM:
-        ~10 GB at n=40, batch 128, T=32).  Returns (states, tape)."""
+        ~10 GB at n=40, batch 128, T=32).  Returns (states, tape).
+
+        float_dtype=torch.bfloat16 (bf16 storage, BASELINE config 5): the forward is the inference mode's (bf16 h,
+        messages, aggregates, projected messages and hidden activations, bf16 MFMA with fp32 accumulation, fp32 c /
+        LayerNorm / gates) and the tape holds those bf16 arrays -- half the bytes; see backward()."""
         T = int(time_steps)
-        if self.float_dtype != torch.float32:
-            raise NotImplementedError("training runs with float_dtype=torch.float32 (bf16 storage is inference only)")
+        bf16 = self.float_dtype == torch.bfloat16
+        if self.float_dtype not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError("training runs with float_dtype torch.float32 or torch.bfloat16")
         self.check_run(adjacency_matrices, initial_embeddings, T, {})
         device = next(iter(initial_embeddings.values())).device
         f32 = dict(dtype=torch.float32, device=device)
+        stored = dict(dtype=self.float_dtype, device=device)   # what the tape keeps of h, messages, activations
         mats = {}
         for v in self.var:
             for u in self.loop[v]:
@@ -1123,21 +1173,34 @@ class GraphNN(object):
                     raise NotImplementedError("training supports loop entries made of var / msg / mat only")
                 if "mat" in u and u["mat"] not in mats:
                     mats[u["mat"]] = DeviceAdjacency.wrap(adjacency_matrices[u["mat"]], device)
-        tape = type("Tape", (), {})()
+        tape = Tape()
         tape.T, tape.mats = T, mats
         tape.folded = {v: self._folded(v, mats) for v in self.var}
         n = {v: initial_embeddings[v].shape[0] for v in self.var}
-        tape.H = {v: torch.empty((T + 1, n[v], d), **f32) for v, d in self.var.items()}
+        tape.H = {v: torch.empty((T + 1, n[v], d), **stored) for v, d in self.var.items()}
         tape.C = {v: torch.empty((T + 1, n[v], d), **f32) for v, d in self.var.items()}
         # cell inputs; for a folded cell: the message y per SOURCE row and Zx = y Kx instead of the aggregate
         tape.X, tape.ZX = {}, {}
         for v in self.var:
             u = tape.folded[v]
             rows_x = n[v] if u is None else n[u["var"]]
-            tape.X[v] = torch.empty((T, rows_x, self._RNN_cells[v].dx), **f32)
+            tape.X[v] = torch.empty((T, rows_x, self._RNN_cells[v].dx), **stored)
             if u is not None:
-                tape.ZX[v] = torch.empty((T, _pad16(rows_x), 4 * self.var[v]), **f32)
+                tape.ZX[v] = torch.empty((T, _pad16(rows_x), 4 * self.var[v]), **stored)
         tape.acts = {}
+        for v in self.var:
+            tape.H[v][0].copy_(initial_embeddings[v])     # (bf16 storage: rounded here, as the inference mode does)
+            tape.C[v][0].zero_()
+            for i, u in enumerate(self.loop[v]):
+                if "msg" in u:
+                    mlp = self._msg_MLPs[u["msg"]]
+                    src = u["var"]
+                    tape.acts[(v, i)] = torch.empty((max(mlp.n_square - 1, 1), T, n[src], self.var[src]), **stored)
+        tape.fused = False
+        if bf16:
+            tape.arith = "bf16"
+            self._forward_train_bf16(tape, n, T)
+            return {v: LSTMStateTuple(c=tape.C[v][T], h=tape.H[v][T]) for v in self.var}, tape
         # forward GEMMs in the split-operand arithmetic selected by self.gemm (fp32-class accuracy).  With f16x2 the
         # cells' backward recomputes z in the same arithmetic (tspgnn_lnlstm_bwd_multi_h2; the tape's projected
         # messages ZX carry the factor 2^s both sides expect); with bf16x3 the backward is fp32 MFMA.
@@ -1145,14 +1208,7 @@ class GraphNN(object):
         tape.arith = arith
         mlp_fn = "tspgnn_mlp_fwd_multi_" + (arith or "f32")
         lstm_fn = "tspgnn_lnlstm_fwd_multi_" + (arith or "f32")
-        for v in self.var:
-            tape.H[v][0].copy_(initial_embeddings[v])
-            tape.C[v][0].zero_()
-            for i, u in enumerate(self.loop[v]):
-                if "msg" in u:
-                    mlp = self._msg_MLPs[u["msg"]]
-                    src = u["var"]
-                    tape.acts[(v, i)] = torch.empty((max(mlp.n_square - 1, 1), T, n[src], self.var[src]), **f32)
+
         def message_dest(v, i, t):
             """(out, projection) of loop entry (v, i)'s message MLP at step t: outputs straight into the tape."""
             u = self.loop[v][i]
@@ -1265,54 +1321,167 @@ class GraphNN(object):
         states = {v: LSTMStateTuple(c=tape.C[v][T], h=tape.H[v][T]) for v in self.var}
         return states, tape
 
+    def _forward_train_bf16(self, tape, n, T):
+        """The T steps of the bf16-storage forward (three launches per step as in _run_bf16: message MLPs -- the vertex
+        task with its Kx projection --, adjacency products, cells), every output written into the tape."""
+        mats = tape.mats
+        bf = dict(dtype=torch.bfloat16, device=self.store.theta.device)
+        for v in self.var:
+            if self.var[v] not in (32, 64, 128) or self._RNN_cells[v].dx % 32 != 0:
+                raise NotImplementedError("bf16 storage needs widths 32/64/128 and cell inputs in multiples of 32")
+            if tape.folded[v] is not None and ("msg" not in tape.folded[v]
+                                               or self._RNN_cells[v].dx != self._msg_MLPs[tape.folded[v]["msg"]].sizes[-1]
+                                               or self._RNN_cells[v].dx != self.var[v]):
+                raise NotImplementedError("bf16 storage: a folded cell input needs a message MLP of the cell's width")
+            for u in self.loop[v]:
+                if "msg" in u:
+                    m = self._msg_MLPs[u["msg"]]
+                    if m._plan[0] != "square" or m._plan[3] or not (1 <= m.n_square <= 4) or m.input_size != m.sizes[-1]:
+                        raise NotImplementedError("bf16 storage needs square message MLPs of at most 4 layers")
+        for t in range(T):
+            msg_out, plain, with_proj = {}, {}, {}
+            for v in self.var:
+                for i, u in enumerate(self.loop[v]):
+                    y = tape.H[u["var"]][t]
+                    if "msg" in u:
+                        mlp = self._msg_MLPs[u["msg"]]
+                        d = mlp.sizes[-1]
+                        acts = tape.acts[(v, i)]
+                        to_tape = tape.folded[v] is not None or (len(self.loop[v]) == 1 and "mat" not in u)
+                        out = tape.X[v][t] if to_tape else torch.empty((y.shape[0], d), **bf)
+                        pw = po = None
+                        if tape.folded[v] is not None:
+                            cv = self._RNN_cells[v]
+                            pw, po = cv._packed_bf16("lstm.kx", 0, cv.dx), tape.ZX[v][t]
+                        k = mlp.n_square
+                        task = _lib.MlpTaskB(_lib.ptr(y), _lib.ptr(mlp.wb_packed_bf16(0, k - 1, d)), _lib.ptr(out), y.shape[0], k,
+                                             mlp.relu_mask(0, k), _lib.ptr(pw), _lib.ptr(po),
+                                             _lib.ptr(acts[:, t]) if k > 1 else None, acts.stride(0))
+                        (with_proj if pw is not None else plain).setdefault(d, []).append(task)
+                        y = out
+                    msg_out[(v, i)] = y
+            for group in (plain, with_proj):   # (projections in their own launch: see _run_bf16)
+                for d, ts in group.items():
+                    for k in range(0, len(ts), 4):
+                        _lib.call_multi("tspgnn_mlp_fwd_multi_bf16", ts[k:k + 4], d)
+            cells = {}
+            for v, d in self.var.items():
+                cell = self._RNN_cells[v]
+                if tape.folded[v] is not None:
+                    task = cell.task_bf16(tape.ZX[v][t], tape.H[v][t], tape.C[v][t], tape.H[v][t + 1], tape.C[v][t + 1],
+                                          adj=mats[tape.folded[v]["mat"]])
+                else:
+                    single = len(self.loop[v]) == 1
+                    inputs = []
+                    for i, u in enumerate(self.loop[v]):
+                        y = msg_out[(v, i)]
+                        if "mat" in u:
+                            y = mats[u["mat"]].matmul(y, transpose=u.get("transpose?", False),
+                                                      out=tape.X[v][t] if single else None)
+                        elif single and "msg" not in u:
+                            tape.X[v][t].copy_(y)
+                        inputs.append(y)
+                    if not single:
+                        torch.cat(inputs, dim=1, out=tape.X[v][t])
+                    task = cell.task_bf16(tape.X[v][t], tape.H[v][t], tape.C[v][t], tape.H[v][t + 1], tape.C[v][t + 1])
+                cells.setdefault(d, []).append(task)
+            for d, ts in cells.items():
+                for k in range(0, len(ts), 4):
+                    _lib.call_multi("tspgnn_lnlstm_fwd_multi_bf16", ts[k:k + 4], d)
+
     def backward(self, tape, dstates):
         """Back-propagation through time of forward_train.  dstates: {var: (dh, dc)} gradients w.r.t. the
         final states (None = zero).  Parameter gradients are ADDED to the store's flat gradient buffer;
-        returns {var: (d h0, d c0)} (gradients w.r.t. the initial embeddings / cell states)."""
+        returns {var: (d h0, d c0)} (gradients w.r.t. the initial embeddings / cell states).
+
+        bf16-storage tape: gradients are fp32 throughout (the fp32-MFMA backward kernels on the widened tape), taken
+        of the function the forward evaluated -- stored values as they were rounded, GEMM weights rounded to bf16,
+        every rounding passed straight through -- and land on the fp32 master variables."""
+        if getattr(tape, "arith", None) == "bf16":
+            names = [c.base + "/kernel" for c in self._RNN_cells.values()]
+            names += [ln + "/kernel" for m in self._msg_MLPs.values() for ln in m.layer_names]
+            with self.store.rounded_to_bf16(names):
+                return self._backward(tape, dstates)
+        return self._backward(tape, dstates)
+
+    def _backward(self, tape, dstates):
         T, mats = tape.T, tape.mats
         device = self.store.theta.device
         f32 = dict(dtype=torch.float32, device=device)
         n = {v: tape.H[v].shape[1] for v in self.var}
-        DZ = {v: torch.empty((T, n[v], 4 * d), **f32) for v, d in self.var.items()}
+        folded = tape.folded
+        bwd_arith = "h2" if getattr(tape, "arith", None) == "h2" else None   # the cells' backward follows the forward
+        # Weight gradients are one reduction per variable over a CHUNK of time steps: all T when the gradients w.r.t.
+        # the pre-activations of the chunk (4d + the MLP layers' d floats per row and step) fit the budget -- the C2
+        # case, ~6 GB -- else the largest chunk that does (a C5 shard: 84 GB for all 64 steps)
+        per_step = sum(n[v] * 4 * d * 4 for v, d in self.var.items())
+        per_step += sum(self._msg_MLPs[self.loop[v][i]["msg"]].n_square * n[self.loop[v][i]["var"]]
+                        * self.var[self.loop[v][i]["var"]] * 4 for (v, i) in tape.acts)
+        CH = max(1, min(T, int(self.wgrad_chunk_bytes // max(per_step, 1)))) if T > 0 else 1
+        DZ = {v: torch.empty((CH, n[v], 4 * d), **f32) for v, d in self.var.items()}
         DPRE = {}
         for (v, i), acts in tape.acts.items():
             u = self.loop[v][i]
             mlp = self._msg_MLPs[u["msg"]]
-            DPRE[(v, i)] = torch.empty((mlp.n_square, T, n[u["var"]], self.var[u["var"]]), **f32)
+            DPRE[(v, i)] = torch.empty((mlp.n_square, CH, n[u["var"]], self.var[u["var"]]), **f32)
         # LayerNorm-gradient partials of all T steps accumulate here (zeroed); one fold per cell after the loop
         ws = {v: _lib.workspace("tspgnn_lnlstm_bwd_workspace_floats", d, device=device).zero_() for v, d in self.var.items()}
-        folded = tape.folded
-        bwd_arith = "h2" if getattr(tape, "arith", None) == "h2" else None   # the cells' backward follows the forward
-        DZX = {v: torch.empty((T, tape.X[v].shape[1], 4 * self.var[v]), **f32) for v in self.var if folded[v] is not None}
+        DZX = {v: torch.empty((CH, tape.X[v].shape[1], 4 * self.var[v]), **f32) for v in self.var if folded[v] is not None}
+
+        def weight_gradients(t0, t1):
+            """Steps [t0, t1): their dz / dpre sit in slots 0 .. t1-t0-1 of the chunk buffers."""
+            steps = t1 - t0
+            for v, d in self.var.items():
+                cell = self._RNN_cells[v]
+                if folded[v] is not None:
+                    rows_src = steps * tape.X[v].shape[1]
+                    cell.backward_weights_folded(tape.x_steps(v, t0, t1), DZX[v][:steps].view(-1, 4 * d), rows_src,
+                                                 tape.h_steps(v, t0, t1), DZ[v][:steps].view(-1, 4 * d), steps * n[v])
+                else:
+                    cell.backward_weights(tape.x_steps(v, t0, t1), tape.h_steps(v, t0, t1), DZ[v][:steps].view(-1, 4 * d),
+                                          steps * n[v])
+            for (v, i), dpre in DPRE.items():
+                u = self.loop[v][i]
+                mlp = self._msg_MLPs[u["msg"]]
+                src, dsrc = u["var"], self.var[u["var"]]
+                inputs = [tape.h_steps(src, t0, t1)] + [tape.acts_steps((v, i), l, t0, t1) for l in range(mlp.n_square - 1)]
+                mlp.backward_weights(inputs, [dpre[l, :steps].reshape(-1, dsrc) for l in range(mlp.n_square)], steps * n[src])
+
         dH = {v: (dstates.get(v, (None, None))[0]) for v in self.var}
         dC = {v: (dstates.get(v, (None, None))[1]) for v in self.var}
         for t in range(T - 1, -1, -1):
+            k = t % CH      # slot of step t in the chunk buffers (chunks start at multiples of CH)
             ndH = {v: torch.empty((n[v], d), **f32) for v, d in self.var.items()}
             ndC = {v: torch.empty((n[v], d), **f32) for v, d in self.var.items()}
             dX = {v: torch.empty((tape.X[v].shape[1], self._RNN_cells[v].dx), **f32) for v in self.var}
+            keep = []       # widened tape slices stay alive until the step's launches are enqueued
             # ---- 1: every cell's backward (recompute z, LayerNorm / gate gradients) in one launch per width
             tasks = {}
             for v, d in self.var.items():
                 cell = self._RNN_cells[v]
+                h_t, c_t = tape.h(v, t), tape.C[v][t]
                 if folded[v] is not None:
-                    task = cell.gather_backward_task(mats[folded[v]["mat"]], tape.ZX[v][t], tape.H[v][t], tape.C[v][t],
-                                                     dH[v], dC[v], DZ[v][t], ndC[v], ws[v], dh_in=ndH[v], defer=True,
-                                                     arith=bwd_arith)
+                    zx_t = tape.zx(v, t)
+                    keep += [h_t, zx_t]
+                    task = cell.gather_backward_task(mats[folded[v]["mat"]], zx_t, h_t, c_t, dH[v], dC[v], DZ[v][k], ndC[v],
+                                                     ws[v], dh_in=ndH[v], defer=True, arith=bwd_arith)
                 else:
-                    task = cell.backward_task(tape.X[v][t], tape.H[v][t], tape.C[v][t], dH[v], dC[v], DZ[v][t], ndC[v],
-                                              ws[v], defer=True, arith=bwd_arith)
+                    x_t = tape.x(v, t)
+                    keep += [h_t, x_t]
+                    task = cell.backward_task(x_t, h_t, c_t, dH[v], dC[v], DZ[v][k], ndC[v], ws[v], defer=True,
+                                              arith=bwd_arith)
                 tasks.setdefault(d, []).append(task)
             for d, ts in tasks.items():
-                for k in range(0, len(ts), 4):
-                    _lib.call_multi("tspgnn_lnlstm_bwd_multi_" + (bwd_arith or "f32"), ts[k:k + 4], d)
+                for j in range(0, len(ts), 4):
+                    _lib.call_multi("tspgnn_lnlstm_bwd_multi_" + (bwd_arith or "f32"), ts[j:j + 4], d)
             # ---- 2: data gradients of the cell GEMMs; these WRITE dh, the message paths below ACCUMULATE into it
             for v in self.var:
                 cell = self._RNN_cells[v]
                 if folded[v] is not None:   # dX[v] becomes the gradient w.r.t. the message y (source rows)
-                    cell.gather_backward_data(mats[folded[v]["mat"]], DZ[v][t], None if cell.d == 64 else ndH[v],
-                                              DZX[v][t], dX[v])   # (d == 64: dh was formed by the cell launch)
+                    cell.gather_backward_data(mats[folded[v]["mat"]], DZ[v][k], None if cell.d == 64 else ndH[v],
+                                              DZX[v][k], dX[v])   # (d == 64: dh was formed by the cell launch)
                 else:
-                    cell.backward_data(DZ[v][t], dX[v], ndH[v])
+                    cell.backward_data(DZ[v][k], dX[v], ndH[v])
             # ---- 3: adjoint adjacency products, then every message MLP's data gradient in one launch
             mlp_tasks, targets = [], []
             for v in self.var:
@@ -1332,11 +1501,12 @@ class GraphNN(object):
                             dy = adj.matmul(dy, transpose=not u.get("transpose?", False))
                     if "msg" in u:
                         mlp = self._msg_MLPs[u["msg"]]
-                        acts, dpre = tape.acts[(v, i)], DPRE[(v, i)]
-                        task = mlp.backward_task(dy, acts[:, t], acts.stride(0), None, dpre[:, t], dpre.stride(0),
+                        (acts_t, acts_stride), dpre = tape.acts_at((v, i), t), DPRE[(v, i)]
+                        keep.append(acts_t)
+                        task = mlp.backward_task(dy, acts_t, acts_stride, None, dpre[:, k], dpre.stride(0),
                                                  ndH[src], True, gather_uv=gather_uv)
                         if task is None or src in targets:   # several kernels, or a second writer of ndH[src]
-                            mlp.backward_data(dy, acts[:, t], acts.stride(0), None, dpre[:, t], dpre.stride(0), ndH[src],
+                            mlp.backward_data(dy, acts_t, acts_stride, None, dpre[:, k], dpre.stride(0), ndH[src],
                                               accumulate=True)
                         else:
                             mlp_tasks.append((self.var[src], task, dy))
@@ -1347,26 +1517,11 @@ class GraphNN(object):
             for d, task, _ in mlp_tasks:
                 by_d.setdefault(d, []).append(task)
             for d, ts in by_d.items():
-                for k in range(0, len(ts), 4):
-                    _lib.call_multi("tspgnn_mlp_bwd_multi_f32", ts[k:k + 4], d)
+                for j in range(0, len(ts), 4):
+                    _lib.call_multi("tspgnn_mlp_bwd_multi_f32", ts[j:j + 4], d)
             dH, dC = ndH, ndC
-        # weight gradients: one reduction per variable over all T steps
-        for v, d in self.var.items():
-            cell = self._RNN_cells[v]
-            cell.backward_finish(ws[v])      # LayerNorm parameters: the deferred per-step partials
-            if folded[v] is not None:
-                rows_src = T * tape.X[v].shape[1]
-                cell.backward_weights_folded(tape.X[v].view(-1, cell.dx), DZX[v].view(-1, 4 * d), rows_src,
-                                             tape.H[v][:T].reshape(-1, d), DZ[v].view(-1, 4 * d), T * n[v])
-            else:
-                cell.backward_weights(tape.X[v].view(-1, cell.dx), tape.H[v][:T].reshape(-1, d), DZ[v].view(-1, 4 * d),
-                                      T * n[v])
-        for (v, i), dpre in DPRE.items():
-            u = self.loop[v][i]
-            mlp = self._msg_MLPs[u["msg"]]
-            src, dsrc = u["var"], self.var[u["var"]]
-            rows = T * n[src]
-            acts = tape.acts[(v, i)]
-            inputs = [tape.H[src][:T].reshape(-1, dsrc)] + [acts[l].view(-1, dsrc) for l in range(mlp.n_square - 1)]
-            mlp.backward_weights(inputs, [dpre[l].view(-1, dsrc) for l in range(mlp.n_square)], rows)
+            if k == 0:      # the chunk [t, t + CH) is complete
+                weight_gradients(t, min(t + CH, T))
+        for v in self.var:
+            self._RNN_cells[v].backward_finish(ws[v])      # LayerNorm parameters: the deferred per-step partials
         return {v: (dH[v], dC[v]) for v in self.var}

@@ -90,7 +90,8 @@ class Network(dict):
 
 def build_network(d, store=None, float_dtype=torch.float32):
     """model.py:9-170.  ``float_dtype=torch.bfloat16`` (the reference GraphNN's own float_dtype argument,
-    graphnn.py:18) stores the embeddings as bf16 with fp32 accumulation (BASELINE config 5, inference only)."""
+    graphnn.py:18) stores the embeddings as bf16 with fp32 accumulation (BASELINE config 5); training in that mode is
+    mixed precision: bf16 tape, fp32 gradients and fp32 master variables (GraphNN.backward)."""
     d = int(d)
     store = store if store is not None else V.reset_default_store()
     GNN = Network()
@@ -363,9 +364,10 @@ class Session(object):
         return results[0] if single else results
 
     # ------------------------------------------------------------------ training (model.py:160-167)
-    def loss_and_grads(self, feed):
+    def loss_and_grads(self, feed, keep_tape=False):
         """Forward + backward of ``loss`` (the L2 term is added by the optimiser kernel).  Leaves the
-        gradient of the local mean loss in ``store.grad``; returns the forward outputs."""
+        gradient of the local mean loss in ``store.grad``; returns the forward outputs (``keep_tape``: plus the
+        message passing's tape under "tape", for inspection -- it holds every step's states)."""
         self._require_gpu("a training step")
         m, d, st = self.model, self.model.d, _lib.current_stream()
         b = feed if isinstance(feed, DeviceBatch) else self.prepare(feed)
@@ -380,7 +382,7 @@ class Session(object):
         # vote head: three relu Dense(d) + Dense(1) (model.py:107-115,128), keeping the hidden activations
         mv = m.E_vote_MLP
         n_sq = mv.n_square
-        EhT = last["E"].h
+        EhT = last["E"].h.to(torch.float32)      # (bf16 storage: widened once; the vote head is fp32)
         Y3 = torch.empty((b.M, d), **f32)
         acts = torch.empty((max(n_sq - 1, 1), b.M, d), **f32)
         mv.forward_saving(EhT, Y3, acts, acts.stride(0))
@@ -420,7 +422,10 @@ class Session(object):
             ws = _lib.workspace("tspgnn_wcolsum_workspace_floats", b.N, d, device=self.device)
             _lib.call("tspgnn_wcolsum_f32", _lib.ptr(dV0), None, b.N, d, 1.0 / math.sqrt(float(d)),
                       _lib.ptr(store.grad_view("V_init")), None, _lib.ptr(ws), st)
-        return {"last_states": last, "E_vote": vote, "logits": logits, "predictions": pred, "stats": stats, "batch": b}
+        out = {"last_states": last, "E_vote": vote, "logits": logits, "predictions": pred, "stats": stats, "batch": b}
+        if keep_tape:
+            out["tape"] = tape
+        return out
 
     # The data-parallel step.  The loss is a mean over the GLOBAL batch (model.py:157), so rank r's
     # gradient of its local mean counts with weight B_r / B.  Everything that must cross ranks rides in ONE bucket:

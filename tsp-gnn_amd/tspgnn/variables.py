@@ -7,6 +7,7 @@ All variables live in ONE flat fp32 device buffer (``theta``) in declaration ord
 pairs) as contiguous slices without repacking, and (b) gradient all-reduce, global-norm clip
 and Adam each run on one flat buffer.
 """
+import contextlib
 import math
 from collections import OrderedDict
 
@@ -109,6 +110,23 @@ class VariableStore(object):
             self._packed[key] = (self.version, t)
             return t
         return ent[1]
+
+    @contextlib.contextmanager
+    def rounded_to_bf16(self, names):
+        """Inside the block ``theta`` is a copy in which the listed variables are rounded to bf16 (nearest even) -- the
+        GEMM weights the bf16-storage forward multiplied with -- and the packed-weight cache is a fresh one; the fp32
+        master weights, their cache and the gradient buffer are untouched (mixed-precision training: the backward
+        differentiates the function the forward evaluated, the optimiser updates the fp32 variables)."""
+        saved = (self.theta, self._packed, self.version)
+        theta = self.theta.clone()
+        for name in names:
+            off, n = self._offsets[name]
+            theta[off:off + n] = theta[off:off + n].to(torch.bfloat16).to(torch.float32)
+        self.theta, self._packed, self.version = theta, {}, self.version + 1
+        try:
+            yield self
+        finally:
+            self.theta, self._packed, self.version = saved
 
     def view(self, name):
         off, n = self._offsets[name]
