@@ -198,7 +198,8 @@ int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_task
  *              buffer of ceil(rows/16)*16 rows x 4d floats.  It only ever feeds the z of an f16x2 cell (Zx of
  *              gather-init mode): producer tiles store 1 KiB contiguous, and the edges' gathers find consecutive
  *              vertices in one 64-byte segment;
- *   lstm task: K packed [dx+d, 4d]; Zx in the projected-message format above; zbias unscaled.
+ *   lstm task: K packed [dx+d, 4d]; Zx in the projected-message format above; zbias unscaled; c may be NULL = the
+ *     zero cell state (LSTM_initial_states' default at the first step of a run): nothing is read for it.
  *     The cell normalises the scaled z with epsilon 2^2s * 1e-12, which reproduces the gates of the unscaled z
  *     bit for bit (power-of-two scaling commutes with rounding).
  */

@@ -348,7 +348,8 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 f32x4 acc[NT4], cf[TPG];
                 init_acc(acc, rc);
 #pragma unroll
-                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts);
+                for (int t = 0; t < TPG; ++t)
+                    cf[t] = c != nullptr ? ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
                 kloop(acc, rc, 0, 0, KBT);
                 cell(acc, cf, rc, valid, hn);
             }
@@ -388,7 +389,8 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 f32x4 acc[NT4], cf[TPG];
                 init_acc(acc, rc);
 #pragma unroll
-                for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts);
+                for (int t = 0; t < TPG; ++t)
+                    cf[t] = c != nullptr ? ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
                 // The [x | h] operand rows of up to four k-blocks are fetched before the K staging is waited for: every
                 // wavefront of the workgroup is in the same phase here, nobody hides a global round trip per k-block.
                 constexpr int KBP = 4;
@@ -698,7 +700,8 @@ static int cell_mlp_h2(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, vo
         TSPGNN_REQUIRE(tasks[k].mlp_layers >= 0 && tasks[k].mlp_layers <= 4, "%s: mlp_layers=%d must be in 0..4", what,
                        tasks[k].mlp_layers);
         if (t.rows == 0) continue;
-        TSPGNN_REQUIRE(t.h && t.c && t.K && t.ln && t.h_out && t.c_out && (t.dx == 0 || t.x), "%s: null pointer", what);
+        // (c == NULL: the zero cell state of a run's first step, nothing is read)
+        TSPGNN_REQUIRE(t.h && t.K && t.ln && t.h_out && t.c_out && (t.dx == 0 || t.x), "%s: null pointer", what);
         // (h_out == h and c_out == c are fine: a tile reads its own rows of h and c, and only those, before it writes
         // them -- the in-place update keeps the states' footprint at one copy, inside the Infinity Cache)
         TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx), "%s: gather-init mode needs dx == 0 and Zx", what);

@@ -106,6 +106,14 @@ class DeviceAdjacency(object):
         self.csr = csr      # (rowptr[R+1], col[nnz], val[nnz] or None)   rows of the matrix
         self.csr_t = csr_t  # same for the transpose
         self.uv = uv        # int32 [R,2] if the matrix is 0/1 with exactly two ones per row
+        self._degrees = {}
+
+    def row_degrees(self, transpose=False):
+        """Stored entries per row (of the transpose) as fp32, computed once per matrix."""
+        if transpose not in self._degrees:
+            rowptr = (self.csr_t if transpose else self.csr)[0]
+            self._degrees[transpose] = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
+        return self._degrees[transpose]
 
     @staticmethod
     def from_sparse_ev(ev, device):
@@ -662,20 +670,21 @@ class GraphNN(object):
                     if isinstance(a, (SparseEV, DeviceAdjacency)):
                         raise NotImplementedError("a matrix appended as a cell input must be dense")
                     dense_mats[m] = torch.as_tensor(a, dtype=torch.float32).to(device).contiguous()
-        states = {}
-        for v, init in initial_embeddings.items():
-            h0 = init.to(self.float_dtype).contiguous()      # embeddings in the storage type; the cell state stays fp32
-            c0 = torch.zeros(h0.shape, dtype=torch.float32, device=h0.device) if v not in LSTM_initial_states \
-                else LSTM_initial_states[v].to(torch.float32).contiguous()
-            states[v] = LSTMStateTuple(c=c0, h=h0)
-        if self.float_dtype == torch.bfloat16:
-            return self._run_bf16(states, mats, dense_mats, int(time_steps))
-        folded = {v: self._folded(v, mats) for v in self.var}
         T = int(time_steps)
-        if T > 0:
-            plan = self._plan_fused(states, mats, folded)
+        h0 = {v: init.to(self.float_dtype).contiguous() for v, init in initial_embeddings.items()}   # storage type
+        c0 = {v: LSTM_initial_states[v].to(torch.float32).contiguous() if v in LSTM_initial_states else None for v in h0}
+        folded = {v: self._folded(v, mats) for v in self.var}
+        if T > 0 and self.float_dtype == torch.float32:
+            # (the fused plan reads the caller's embeddings in place and takes "no initial cell state" as such: no copies,
+            # no zero fill)
+            plan = self._plan_fused({v: LSTMStateTuple(c=c0[v], h=h0[v]) for v in h0}, mats, folded)
             if plan is not None:
                 return _States(plan(T), self._plan_keep)
+        states = {v: LSTMStateTuple(c=torch.zeros(h0[v].shape, dtype=torch.float32, device=h0[v].device) if c0[v] is None
+                                    else c0[v], h=h0[v]) for v in h0}     # the cell state stays fp32
+        if self.float_dtype == torch.bfloat16:
+            return self._run_bf16(states, mats, dense_mats, T)
+        if T > 0:
             plan = self._plan(states, mats, folded)
             if plan is not None:
                 for t in range(T):
@@ -859,21 +868,17 @@ class GraphNN(object):
         blocked = {v: arith == "h2" and folded[v] is not None for v in self.var}
         rows_of = {v: st.h.shape[0] for v, st in states.items()}
 
-        def state_buffers(init):
+        def state_buffers():
             out = {}
             for v, st in states.items():
-                if blocked[v]:
-                    hb = torch.empty((_pad16(rows_of[v]), st.h.shape[1]), **f32)
-                    cb = torch.empty((_pad16(rows_of[v]), st.c.shape[1]), **f32)
-                    if init:
-                        hb[:rows_of[v]].copy_(st.h)
-                        cb[:rows_of[v]].copy_(st.c)
-                    out[v] = LSTMStateTuple(c=cb, h=hb)
-                else:
-                    out[v] = LSTMStateTuple(c=st.c.clone(), h=st.h.clone()) if init else \
-                        LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h))
+                rows = _pad16(rows_of[v]) if blocked[v] else rows_of[v]
+                out[v] = LSTMStateTuple(c=torch.empty((rows, st.h.shape[1]), **f32), h=torch.empty((rows, st.h.shape[1]), **f32))
             return out
-        buf = [state_buffers(True), state_buffers(False)]
+        # ping-pong buffers of the loop; the FIRST step reads the caller's states in place (row-major; c None = the zero
+        # cell state, which the f16x2 kernels take as a null pointer: nothing is read), so nothing is copied or filled
+        buf = [state_buffers(), state_buffers()]
+        first_state = {v: LSTMStateTuple(c=st.c if st.c is not None or arith == "h2" else torch.zeros_like(st.h), h=st.h)
+                       for v, st in states.items()}
         pushed = {v: self._pushable(v, mats, folded) for v in self.var}
         # message outputs / projected messages, double-buffered by step parity (a launch reads one set and
         # writes the other)
@@ -887,7 +892,7 @@ class GraphNN(object):
                         zxs[p][v] = torch.empty((_pad16(rows), 4 * self.var[v]), **f32)   # (fused plan: f16x2 / x3 only)
                     else:
                         mo[p][(v, i)] = torch.empty((rows, width), **f32)
-        keep = [buf, mo, zxs]
+        keep = [buf, mo, zxs, first_state]
 
         def message(v, i, p):
             """(wb, n_layers, relu_mask, out, proj_w, proj_out) of loop entry (v, i) writing parity-p buffers."""
@@ -909,7 +914,7 @@ class GraphNN(object):
             for v, d in self.var.items():
                 cell = self._RNN_cells[v]
                 n_v = rows_of[v]
-                st = LSTMStateTuple(c=src[v].c[:n_v], h=src[v].h[:n_v])
+                st = first_state[v] if first else LSTMStateTuple(c=src[v].c[:n_v], h=src[v].h[:n_v])
                 out = (dst[v].h, dst[v].c)
                 if folded[v] is not None:
                     t = cell.gather_task(mats[folded[v]["mat"]], zxs[p][v], st, out, arith=arith)
@@ -934,9 +939,7 @@ class GraphNN(object):
                     if pushed[v]:
                         u0 = self.loop[v][0]
                         kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], arith=arith)
-                        rowptr = (mats[u0["mat"]].csr_t if u0.get("transpose?", False) else mats[u0["mat"]].csr)[0]
-                        deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
-                        keep.append(deg)
+                        deg = mats[u0["mat"]].row_degrees(bool(u0.get("transpose?", False)))
                         t = cell.pushed_task(x, st, out, kp, zb, deg)
                     else:
                         t = cell.task(x, st, out, arith=arith)
@@ -957,7 +960,7 @@ class GraphNN(object):
         for v in self.var:
             for i, u in enumerate(self.loop[v]):
                 wb, n, mask, mout, pw, po = message(v, i, 0)
-                y = buf[0][u["var"]].h[:rows_of[u["var"]]]
+                y = first_state[u["var"]].h
                 if mout is None:
                     mout = torch.empty((y.shape[0], self._msg_MLPs[u["msg"]].sizes[-1]), **f32)
                     keep.append(mout)
@@ -1056,10 +1059,8 @@ class GraphNN(object):
                 if pushed[v]:
                     u0 = self.loop[v][0]
                     kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], arith=arith)
-                    rowptr = (mats[u0["mat"]].csr_t if u0.get("transpose?", False) else mats[u0["mat"]].csr)[0]
-                    deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
+                    deg = mats[u0["mat"]].row_degrees(bool(u0.get("transpose?", False)))
                     lstm_tasks.setdefault(d, []).append(cell.pushed_task(x, st, out, kp, zb, deg))
-                    keep.append(deg)
                 else:
                     lstm_tasks.setdefault(d, []).append(cell.task(x, st, out, arith=arith))
                 keep.append(x)
