@@ -225,9 +225,10 @@ int tspgnn_lnlstm_mlp_fwd_multi_h2(const tspgnn_cell_mlp_task* tasks, int n_task
  *     values (cols 16t+4g..+3) of row v at element (((v/16)*(4d/16) + t)*4 + g)*64 + (v%16)*4.
  *   lstm task: x, h, h_out bf16 row-major, Zx in the blocked format above; c, c_out, ln fp32; K = bf16 packed
  *     kernel[dx+d,4d] (Kh[d,4d] in gather-init mode, uv != NULL); a kernel larger than LDS is streamed in k-block
- *     chunks.  d in {32, 64, 128}.  c_in_blocked / c_out_blocked: c / c_out is stored [rows padded to 16, d]
- *     blocked by 16 rows (element (((r/16)*(d/16) + t)*4 + g)*64 + (r%16)*4 for cols 16t+4g..+3) instead of
- *     row-major -- for the ping-pong state buffers inside a T-step loop, which only this kernel reads.
+ *     chunks.  d in {32, 64, 128}.  state_in_blocked / state_out_blocked: h and c / h_out and c_out are stored
+ *     [rows padded to 16, d] blocked by 16 rows (element (((r/16)*(d/16) + t)*4 + g)*64 + (r%16)*4 for cols
+ *     16t+4g..+3) instead of row-major -- for the ping-pong state buffers inside a T-step loop, which only this
+ *     kernel and the message MLP (mlp task: x_blocked) read.
  */
 int tspgnn_gather2_sum_bf16(const int32_t* ev_uv, const void* X, void* Y, int M, int N, int d, void* stream);
 int tspgnn_csr_rowsum_bf16(const int32_t* rowptr, const int32_t* eid, const void* X, void* Y, int N, int M, int d,
@@ -237,12 +238,13 @@ typedef struct tspgnn_mlp_task_bf16 {
     const void* proj_w; void* proj_out;
     void* acts; long long acts_stride;   /* optional (training): the stored (bf16) hidden activations, layer l of row r
                                             at acts[l*acts_stride + r*d] (elements); stride 0 = rows*d */
+    int x_blocked;                       /* X is a loop state h stored blocked by 16 rows (see the lstm task) */
 } tspgnn_mlp_task_bf16;
 typedef struct tspgnn_lstm_task_bf16 {
     const void* x; int dx; const void* h; const float* c; const void* K; const float* ln;
     void* h_out; float* c_out; int rows;
     const int32_t* uv; const void* Zx;
-    int c_in_blocked; int c_out_blocked;
+    int state_in_blocked; int state_out_blocked;
 } tspgnn_lstm_task_bf16;
 int tspgnn_mlp_fwd_multi_bf16(const tspgnn_mlp_task_bf16* tasks, int n_tasks, int d, void* stream);
 int tspgnn_lnlstm_fwd_multi_bf16(const tspgnn_lstm_task_bf16* tasks, int n_tasks, int d, void* stream);

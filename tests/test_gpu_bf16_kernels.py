@@ -102,19 +102,25 @@ def test_mlp_bf16_two_tasks_with_projection(cuda_device, d, rows):
     Ya = torch.empty((rows, d), dtype=torch.bfloat16, device=cuda_device)
     Yb = torch.empty((rows_b, d), dtype=torch.bfloat16, device=cuda_device)
     Zb = torch.zeros(((rows_b + 15) // 16 * 16, 4 * d), dtype=torch.bfloat16, device=cuda_device)   # blocked by 16 rows
-    ta = _lib.MlpTaskB(_lib.ptr(dev_bf16(Xa, cuda_device)), _lib.ptr(mlp_blocks_bf16(la, cuda_device)), _lib.ptr(Ya), rows, 3, 0b111,
-                       None, None)
+    # task a: X handed over BLOCKED by 16 rows (a loop state between two steps) and the hidden activations saved (training)
+    acts_a = torch.zeros((2, rows, d), dtype=torch.bfloat16, device=cuda_device)
+    ta = _lib.MlpTaskB(_lib.ptr(dev_bf16(h2_zx_pack(rb(Xa), 1.0), cuda_device)), _lib.ptr(mlp_blocks_bf16(la, cuda_device)), _lib.ptr(Ya),
+                       rows, 3, 0b111, None, None, _lib.ptr(acts_a), 0, 1)
     tb = _lib.MlpTaskB(_lib.ptr(dev_bf16(Xb, cuda_device)), _lib.ptr(mlp_blocks_bf16(lb, cuda_device)), _lib.ptr(Yb), rows_b, 4,
                        0b0111, _lib.ptr(packed_bf16(P, cuda_device)), _lib.ptr(Zb))
     _lib.call_multi("tspgnn_mlp_fwd_multi_bf16", [ta, tb], d)
     torch.cuda.synchronize()
 
+    hidden = []
+
     def chain(x, layers, relus):
         x = rb(x)
         for (W, b), r in zip(layers, relus):
             x = rb(NO.dense(x, rb(W), b.astype(np.float64), r))
+            hidden.append(x)
         return x
     ra, rbb = chain(Xa, la, [True] * 3), chain(Xb, lb, [True, True, True, False])
+    assert rel_err(f64(acts_a[0]), hidden[0]) < BF16_TOL and rel_err(f64(acts_a[1]), hidden[1]) < BF16_TOL
     assert rel_err(f64(Ya), ra) < BF16_TOL
     assert rel_err(f64(Yb), rbb) < BF16_TOL
     assert rel_err(h2_zx_unpack(f64(Zb), rows_b, 1.0), f64(Yb) @ rb(P)) < 2.0 ** -7       # projection of the kernel's own (stored) Y: one rounding
@@ -130,9 +136,15 @@ def ln_params(rng, d):
 @pytest.mark.parametrize("d", [32, 64, 128])
 def test_lnlstm_bf16_gather_and_plain_tasks(cuda_device, d, c_blocked):
     """Edge-style task (gather-init from the blocked bf16 Zx, Kh resident) and vertex-style task (x|h with the [2d,4d]
-    kernel, streamed through LDS at d=128) in one launch; the cell state c row-major or blocked by 16 rows on either side."""
+    kernel, streamed through LDS at d=128) in one launch; the states h, c row-major or blocked by 16 rows on either side."""
     def c_dev(c, blocked):
         return dev(h2_zx_pack(c, 1.0) if blocked else c, cuda_device)
+
+    def h_dev(h, blocked):
+        return dev_bf16(h2_zx_pack(rb(h), 1.0) if blocked else h, cuda_device)
+
+    def h_host(t, rows, blocked):
+        return h2_zx_unpack(f64(t), rows, 1.0) if blocked else f64(t)[:rows]
 
     def c_host(t, rows, blocked):
         return h2_zx_unpack(t.cpu().numpy(), rows, 1.0) if blocked else t.cpu().numpy()[:rows]
@@ -147,16 +159,16 @@ def test_lnlstm_bf16_gather_and_plain_tasks(cuda_device, d, c_blocked):
     xv, hv, cv = rng.randn(N, d), rng.randn(N, d), rng.randn(N, d).astype(np.float32)
     Kv = (rng.randn(2 * d, 4 * d) / np.sqrt(2 * d)).astype(np.float32)
     ln_v, lnd_v = ln_params(rng, d)
-    he_o = torch.empty((M, d), dtype=torch.bfloat16, device=cuda_device)
+    he_o = torch.zeros(((M + 15) // 16 * 16, d), dtype=torch.bfloat16, device=cuda_device)
     pad = lambda r: (r + 15) // 16 * 16
     ce_o = torch.zeros((pad(M), d), dtype=torch.float32, device=cuda_device)
-    hv_o = torch.empty((N, d), dtype=torch.bfloat16, device=cuda_device)
+    hv_o = torch.zeros((pad(N), d), dtype=torch.bfloat16, device=cuda_device)
     cv_o = torch.zeros((pad(N), d), dtype=torch.float32, device=cuda_device)
-    te = _lib.LstmTaskB(None, 0, _lib.ptr(dev_bf16(he, cuda_device)), _lib.ptr(c_dev(ce, cin)), _lib.ptr(packed_bf16(Kh, cuda_device)),
+    te = _lib.LstmTaskB(None, 0, _lib.ptr(h_dev(he, cin)), _lib.ptr(c_dev(ce, cin)), _lib.ptr(packed_bf16(Kh, cuda_device)),
                         _lib.ptr(dev(ln_e, cuda_device)), _lib.ptr(he_o), _lib.ptr(ce_o), M,
                         _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev_bf16(h2_zx_pack(rb(Zx), 1.0), cuda_device)),
                         int(cin), int(cout))
-    tv = _lib.LstmTaskB(_lib.ptr(dev_bf16(xv, cuda_device)), d, _lib.ptr(dev_bf16(hv, cuda_device)), _lib.ptr(c_dev(cv, cin)),
+    tv = _lib.LstmTaskB(_lib.ptr(dev_bf16(xv, cuda_device)), d, _lib.ptr(h_dev(hv, cin)), _lib.ptr(c_dev(cv, cin)),
                         _lib.ptr(packed_bf16(Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o), N,
                         None, None, int(cin), int(cout))
     _lib.call_multi("tspgnn_lnlstm_fwd_multi_bf16", [te, tv], d)
@@ -164,7 +176,7 @@ def test_lnlstm_bf16_gather_and_plain_tasks(cuda_device, d, c_blocked):
     z0 = rb(Zx)[uv[:, 0]] + rb(Zx)[uv[:, 1]]
     rh, rc = NO.lnlstm(np.zeros((M, 0)), rb(he), ce.astype(np.float64), rb(Kh), lnd_e, z0=z0)
     assert rel_err(c_host(ce_o, M, cout), rc) < F32_TOL            # nothing is rounded on the way to c'
-    assert rel_err(f64(he_o), rb(rh)) < 2.0 ** -7
+    assert rel_err(h_host(he_o, M, cout), rb(rh)) < 2.0 ** -7
     rh, rc = NO.lnlstm(rb(xv), rb(hv), cv.astype(np.float64), rb(Kv), lnd_v)
     assert rel_err(c_host(cv_o, N, cout), rc) < F32_TOL
-    assert rel_err(f64(hv_o), rb(rh)) < 2.0 ** -7
+    assert rel_err(h_host(hv_o, N, cout), rb(rh)) < 2.0 ** -7

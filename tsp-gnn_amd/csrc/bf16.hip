@@ -42,6 +42,10 @@ __device__ __forceinline__ bf16x8 join(bf16x4 lo, bf16x4 hi) {
 __device__ __forceinline__ bf16x8 row_operand(const __bf16* row_g, int kb) {
     return join(ldw4(row_g + kb * 32), ldw4(row_g + kb * 32 + 16));
 }
+// the same from a row stored BLOCKED by 16 rows (c_blocked's element offsets: 256 elements between the 16-column tiles)
+__device__ __forceinline__ bf16x8 row_operand(const __bf16* row_g, int kb, bool blocked) {
+    return blocked ? join(ldw4(row_g + kb * 512), ldw4(row_g + kb * 512 + 256)) : row_operand(row_g, kb);
+}
 
 constexpr int kMaxTasksB = 4;
 
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_bf16_kernel(const MlpTableB t
     const unsigned relu_mask = tt.task[k].relu_mask;
     const __bf16* __restrict__ proj_w = reinterpret_cast<const __bf16*>(tt.task[k].proj_w);
     __bf16* __restrict__ proj_out = reinterpret_cast<__bf16*>(tt.task[k].proj_out);
+    const bool x_blk = tt.task[k].x_blocked != 0;
     __bf16* __restrict__ acts = reinterpret_cast<__bf16*>(tt.task[k].acts);   // training: the stored hidden activations
     const long long acts_stride = tt.task[k].acts_stride;
     const int tiles_total = (rows + 15) / 16;
@@ -170,9 +175,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_bf16_kernel(const MlpTableB t
         const int row = tile * 16 + rl;
         const bool valid = row < rows;
         const size_t rbase = (size_t)(valid ? row : rows - 1) * D + g * 4;
+        const __bf16* xr = X + c_blocked<D>((unsigned)(valid ? row : rows - 1), g, x_blk);
         bf16x8 b[KB];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) b[kb] = row_operand(X + rbase, kb);
+        for (int kb = 0; kb < KB; ++kb) b[kb] = row_operand(xr, kb, x_blk);
         f32x4 acc[NT];
         for (int l = 0; l < n_layers; ++l) {
             const __bf16* wl = reinterpret_cast<const __bf16*>(lds_w + (size_t)l * LAYER_BYTES);
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTabl
     const float* __restrict__ ln = tt.task[k].ln;
     __bf16* __restrict__ h_out = reinterpret_cast<__bf16*>(tt.task[k].h_out);
     float* __restrict__ c_out = tt.task[k].c_out;
-    const bool c_in_blk = tt.task[k].c_in_blocked != 0, c_out_blk = tt.task[k].c_out_blocked != 0;
+    const bool c_in_blk = tt.task[k].state_in_blocked != 0, c_out_blk = tt.task[k].state_out_blocked != 0;   // h and c alike
     const int rows = tt.task[k].rows;
     const int2* __restrict__ uv = reinterpret_cast<const int2*>(tt.task[k].uv);
     const __bf16* __restrict__ Zx = reinterpret_cast<const __bf16*>(tt.task[k].Zx);
@@ -308,9 +314,9 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTabl
     };
     auto kloop = [&](f32x4 (&acc)[NT4], size_t rc, int kb_base, int kb0, int kb1) {
         const __bf16* xrow = x + rc * dx + g * 4;
-        const __bf16* hrow = h + rc * D + g * 4;
+        const __bf16* hrow = h + c_blocked<D>((unsigned)rc, g, c_in_blk);
         for (int kb = kb0; kb < kb1; ++kb) {
-            const bf16x8 bv = kb < KBX ? row_operand(xrow, kb) : row_operand(hrow, kb - KBX);
+            const bf16x8 bv = kb < KBX ? row_operand(xrow, kb) : row_operand(hrow, kb - KBX, c_in_blk);
             const __bf16* base = lds_w + ((size_t)((kb - kb_base) * 4 + g) * NT4 * 16 + rl) * 8;
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] = MFMA_BF16(ldw8(base + t * 128), bv, acc[t]);
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTabl
         if (valid) {
 #pragma unroll
             for (int t = 0; t < TPG; ++t) {
-                stw4(h_out + rc * D + g * 4 + t * 16, narrow(hn[t]));
+                stw4(h_out + c_blocked<D>((unsigned)rc, g, c_out_blk) + t * (c_out_blk ? 256 : 16), narrow(hn[t]));
                 st4(c_out + c_blocked<D>((unsigned)rc, g, c_out_blk) + t * (c_out_blk ? 256 : 16), nc[t]);
             }
         }

@@ -259,7 +259,6 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     unsigned char* lds_wb = ldsb + (10 * D + 4) * sizeof(float);
     _Float16* lds_w = reinterpret_cast<_Float16*>(lds_wb);
     const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4, wave = tid >> 6;
-    const int nw = blockDim.x >> 6;
     // LayerNorm parameters, rows [g_i, b_i, g_j, b_j, g_f, b_f, g_o, b_o, g_s, b_s]: the gates i, f, o feed sigmoids
     // only, so their gamma / beta are stored times -log2(e) with the forget bias folded into b_f (lstm_gates<D, true>)
     for (int i = tid; i < 10 * D; i += blockDim.x) {

@@ -110,14 +110,14 @@ class MlpTaskB(ctypes.Structure):
     """tspgnn_mlp_task_bf16 (include/tspgnn.h)."""
     _fields_ = [("X", c_void_p), ("wb", c_void_p), ("Y", c_void_p), ("rows", c_int), ("n_layers", c_int),
                 ("relu_mask", c_uint), ("proj_w", c_void_p), ("proj_out", c_void_p),
-                ("acts", c_void_p), ("acts_stride", ctypes.c_longlong)]
+                ("acts", c_void_p), ("acts_stride", ctypes.c_longlong), ("x_blocked", c_int)]
 
 
 class LstmTaskB(ctypes.Structure):
     """tspgnn_lstm_task_bf16 (include/tspgnn.h)."""
     _fields_ = [("x", c_void_p), ("dx", c_int), ("h", c_void_p), ("c", c_void_p), ("K", c_void_p), ("ln", c_void_p),
                 ("h_out", c_void_p), ("c_out", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p),
-                ("c_in_blocked", c_int), ("c_out_blocked", c_int)]
+                ("state_in_blocked", c_int), ("state_out_blocked", c_int)]
 
 
 class LstmBwdTask(ctypes.Structure):

@@ -298,16 +298,18 @@ class LayerNormBasicLSTMCell(object):
         n = (rows_hi - rows_lo) * 4 * self.d
         return self._packed_x3(key, rows_lo, rows_hi)[:2 * n]
 
-    def task_bf16(self, x, h, c, h_out, c_out, adj=None, c_in_blocked=False, c_out_blocked=False):
-        """tspgnn_lstm_task_bf16: x, h, h_out bf16; c, c_out fp32 (blocked by 16 rows when flagged).  With adj, the
-        gather-init form: x is the blocked bf16 Zx of the source rows, K = Kh."""
+    def task_bf16(self, x, h, c, h_out, c_out, rows, adj=None, state_in_blocked=False, state_out_blocked=False):
+        """tspgnn_lstm_task_bf16 over ``rows`` rows: x, h, h_out bf16; c, c_out fp32; the states blocked by 16 rows when
+        flagged (padded buffers).  With adj, the gather-init form: x is the blocked bf16 Zx of the source rows, K = Kh."""
         if adj is None:
             K = self._packed_bf16("lstm.x3", 0, self.dx + self.d)
             return _lib.LstmTaskB(_lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(K), _lib.ptr(self.ln()),
-                                  _lib.ptr(h_out), _lib.ptr(c_out), h.shape[0], None, None, int(c_in_blocked), int(c_out_blocked))
+                                  _lib.ptr(h_out), _lib.ptr(c_out), rows, None, None, int(state_in_blocked),
+                                  int(state_out_blocked))
         K = self._packed_bf16("lstm.kh.x3", self.dx, self.dx + self.d)
         return _lib.LstmTaskB(None, 0, _lib.ptr(h), _lib.ptr(c), _lib.ptr(K), _lib.ptr(self.ln()), _lib.ptr(h_out),
-                              _lib.ptr(c_out), h.shape[0], _lib.ptr(adj.uv), _lib.ptr(x), int(c_in_blocked), int(c_out_blocked))
+                              _lib.ptr(c_out), rows, _lib.ptr(adj.uv), _lib.ptr(x), int(state_in_blocked),
+                              int(state_out_blocked))
 
     def x3_ok(self):
         """The split-operand cell kernels cover this shape (tspgnn_lnlstm_fwd_multi_x3 / _h2)."""
@@ -714,13 +716,19 @@ class GraphNN(object):
                         raise NotImplementedError("bf16 storage needs square message MLPs of at most 4 layers")
         if T == 0:
             return states
-        # h ping-pongs between two row-major buffers (the message MLPs read it); c, which only the cells touch, between two
-        # buffers blocked by 16 rows (include/tspgnn.h), entering row-major at step 0 and leaving row-major at step T-1
+        # Between the steps the states live in two ping-pong buffers BLOCKED by 16 rows (include/tspgnn.h: the lstm
+        # task's state_*_blocked, the mlp task's x_blocked) -- only the loop's own launches read them, and a tile is then
+        # loaded and stored in contiguous runs instead of as pieces of 16 rows.  The first step reads the caller's
+        # row-major states in place, the last one writes row-major results.  An h that a loop entry uses WITHOUT a message
+        # MLP (it goes to an aggregation or straight into a cell input) stays row-major.
         f32 = dict(dtype=torch.float32, device=self.store.theta.device)
-        hbuf = [{v: st.h.clone() for v, st in states.items()}, {v: torch.empty_like(st.h) for v, st in states.items()}]
-        cblk = [{v: torch.empty((_pad16(st.c.shape[0]), st.c.shape[1]), **f32) for v, st in states.items()} for _ in (0, 1)]
-        c_first = {v: st.c.contiguous() for v, st in states.items()}
-        c_last = {v: torch.empty_like(st.c) for v, st in states.items()}
+        blocked = {v: all("msg" in u for w in self.var for u in self.loop[w] if u["var"] == v) for v in self.var}
+
+        def buffers(dtype):
+            return [{v: torch.empty((_pad16(st.h.shape[0]) if blocked[v] else st.h.shape[0], st.h.shape[1]),
+                                    dtype=dtype, device=st.h.device) for v, st in states.items()} for _ in (0, 1)]
+        hbuf, cbuf = buffers(torch.bfloat16), buffers(torch.float32)
+        last = {v: LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h)) for v, st in states.items()}
 
         def folds(v):   # single gather over a two-ones-per-row matrix behind a message MLP: Zx = msg(y) Kx on source rows
             if not self.fold_adjacency or len(self.loop[v]) != 1:
@@ -730,85 +738,89 @@ class GraphNN(object):
                 return None
             return u if self._RNN_cells[v].dx == self._msg_MLPs[u["msg"]].sizes[-1] == self.var[v] else None
         folded = {v: folds(v) for v in self.var}
-        runs, keep = [], [hbuf, cblk, c_first, c_last]
-        for p in (0, 1):
-            src, dst = hbuf[p], hbuf[1 - p]
-            mlp_tasks, cell_in, mid, msg_out, zxs = {}, {}, [], {}, {}
+        keep = [hbuf, cbuf, last, states]
+        built = {}
+
+        def step_launches(p, first, final):
+            """(message-MLP launches, adjacency products, cell launches) of a step reading parity-p buffers."""
+            key = (p, first, final)
+            if key in built:
+                return built[key]
+            h_in = {v: states[v].h if first else hbuf[p][v] for v in self.var}
+            c_in = {v: states[v].c if first else cbuf[p][v] for v in self.var}
+            h_out = {v: last[v].h if final else hbuf[1 - p][v] for v in self.var}
+            c_out = {v: last[v].c if final else cbuf[1 - p][v] for v in self.var}
+            blk_in = {v: blocked[v] and not first for v in self.var}
+            blk_out = {v: blocked[v] and not final for v in self.var}
+            mlp_tasks, mid, msg_out, zxs, cell_tasks = {}, [], {}, {}, {}
             for v in self.var:
                 for i, u in enumerate(self.loop[v]):
-                    y = src[u["var"]]
+                    src = u["var"]
+                    y = h_in[src]
                     if "msg" in u:
                         mlp = self._msg_MLPs[u["msg"]]
                         d = mlp.sizes[-1]
-                        out = torch.empty((y.shape[0], d), **bf)
+                        rows = states[src].h.shape[0]
+                        out = torch.empty((rows, d), **bf)
                         pw = po = None
                         if folded[v] is not None:
                             cv = self._RNN_cells[v]
-                            zxs[v] = torch.empty((_pad16(y.shape[0]), 4 * self.var[v]), **bf)
+                            zxs[v] = torch.empty((_pad16(rows), 4 * self.var[v]), **bf)
                             pw, po = cv._packed_bf16("lstm.kx", 0, cv.dx), zxs[v]
                         n = mlp.n_square
                         mlp_tasks.setdefault(d, []).append(_lib.MlpTaskB(
-                            _lib.ptr(y), _lib.ptr(mlp.wb_packed_bf16(0, n - 1, d)), _lib.ptr(out), y.shape[0], n,
-                            mlp.relu_mask(0, n), _lib.ptr(pw), _lib.ptr(po)))
+                            _lib.ptr(y), _lib.ptr(mlp.wb_packed_bf16(0, n - 1, d)), _lib.ptr(out), rows, n,
+                            mlp.relu_mask(0, n), _lib.ptr(pw), _lib.ptr(po), None, 0, int(blk_in[src])))
                         y = out
                     msg_out[(v, i)] = y
             for v, d in self.var.items():
                 cell = self._RNN_cells[v]
+                rows = states[v].h.shape[0]
                 if folded[v] is not None:
-                    cell_in[v] = (mats[folded[v]["mat"]], zxs[v])
-                    continue
-                inputs = []
-                for i, u in enumerate(self.loop[v]):
-                    y = msg_out[(v, i)]
-                    if "mat" in u:
-                        adj, tr = mats[u["mat"]], u.get("transpose?", False)
-                        o = torch.empty((adj.shape[1] if tr else adj.shape[0], y.shape[1]), **bf)
-                        mid.append((adj.matmul, (y, tr, o)))
-                        y = o
-                    inputs.append(y)
-                if len(inputs) == 1:
-                    x = inputs[0]
+                    adj, x = mats[folded[v]["mat"]], zxs[v]
                 else:
-                    x = torch.empty((src[v].shape[0], cell.dx), **bf)
-                    mid.append((lambda ins, o: torch.cat(ins, dim=1, out=o), (inputs, x)))
-                if x.shape[0] != src[v].shape[0] or x.shape[1] != cell.dx:
-                    raise ValueError("cell input must be [%d,%d], got %s" % (src[v].shape[0], cell.dx, tuple(x.shape)))
-                cell_in[v] = (None, x)
-                keep.append(x)
-            keep += [msg_out, zxs]
+                    inputs = []
+                    for i, u in enumerate(self.loop[v]):
+                        y = msg_out[(v, i)]
+                        if "mat" in u:
+                            adj_, tr = mats[u["mat"]], u.get("transpose?", False)
+                            o = torch.empty((adj_.shape[1] if tr else adj_.shape[0], y.shape[1]), **bf)
+                            mid.append((adj_.matmul, (y, tr, o)))
+                            y = o
+                        inputs.append(y)
+                    if len(inputs) == 1:
+                        x = inputs[0]
+                    else:
+                        x = torch.empty((rows, cell.dx), **bf)
+                        mid.append((lambda ins, o: torch.cat(ins, dim=1, out=o), (inputs, x)))
+                    if x.shape[0] != rows or x.shape[1] != cell.dx:
+                        raise ValueError("cell input must be [%d,%d], got %s" % (rows, cell.dx, tuple(x.shape)))
+                    adj = None
+                    keep.append(x)
+                cell_tasks.setdefault(d, []).append(cell.task_bf16(
+                    x, h_in[v], c_in[v], h_out[v], c_out[v], rows, adj=adj, state_in_blocked=blk_in[v],
+                    state_out_blocked=blk_out[v]))
+            keep.extend([msg_out, zxs])
             # tasks with a projection go to their own launch: without them the MLP kernel needs a third of the
             # registers (the projection's 4d accumulators) and the big edge task runs at twice the occupancy
             mlp_calls = []
             for d, ts in mlp_tasks.items():
                 for group in ([t for t in ts if not t.proj_w], [t for t in ts if t.proj_w]):
                     mlp_calls += [(_lib.task_array(group[k:k + 4]), d) for k in range(0, len(group), 4)]
-            runs.append((mlp_calls, mid, cell_in))
-
-        cell_calls = {}
-
-        def cells(p, first, last):
-            key = (p, first, last)
-            if key not in cell_calls:
-                tasks = {}
-                for v, d in self.var.items():
-                    adj, x = runs[p][2][v]
-                    c_in = c_first[v] if first else cblk[p][v]
-                    c_out = c_last[v] if last else cblk[1 - p][v]
-                    tasks.setdefault(d, []).append(self._RNN_cells[v].task_bf16(
-                        x, hbuf[p][v], c_in, hbuf[1 - p][v], c_out, adj=adj, c_in_blocked=not first, c_out_blocked=not last))
-                cell_calls[key] = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in tasks.items() for k in range(0, len(ts), 4)]
-            return cell_calls[key]
-        keep.append(cell_calls)
+            cell_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in cell_tasks.items() for k in range(0, len(ts), 4)]
+            built[key] = (mlp_calls, mid, cell_calls)
+            return built[key]
+        keep.append(built)
         self._plan_keep = keep
         for t in range(T):
-            mlp_calls, mid, _ = runs[t & 1]
+            mlp_calls, mid, cell_calls = step_launches(t & 1, t == 0, t == T - 1)
             for arr, d in mlp_calls:
                 _lib.call_multi("tspgnn_mlp_fwd_multi_bf16", arr, d)
             for fn, args in mid:
                 fn(*args)
-            for arr, d in cells(t & 1, t == 0, t == T - 1):
+            for arr, d in cell_calls:
                 _lib.call_multi("tspgnn_lnlstm_fwd_multi_bf16", arr, d)
-        return _States({v: LSTMStateTuple(c=c_last[v], h=hbuf[T & 1][v]) for v in states}, keep)
+        return _States(last, keep)
 
     def _split_arith(self, n_rows=None):
         """"h2" / "x3" when the selected split-operand kernels cover this network (widths 32/64, cell inputs in
@@ -1369,7 +1381,7 @@ class GraphNN(object):
             for v, d in self.var.items():
                 cell = self._RNN_cells[v]
                 if tape.folded[v] is not None:
-                    task = cell.task_bf16(tape.ZX[v][t], tape.H[v][t], tape.C[v][t], tape.H[v][t + 1], tape.C[v][t + 1],
+                    task = cell.task_bf16(tape.ZX[v][t], tape.H[v][t], tape.C[v][t], tape.H[v][t + 1], tape.C[v][t + 1], n[v],
                                           adj=mats[tape.folded[v]["mat"]])
                 else:
                     single = len(self.loop[v]) == 1
@@ -1384,7 +1396,7 @@ class GraphNN(object):
                         inputs.append(y)
                     if not single:
                         torch.cat(inputs, dim=1, out=tape.X[v][t])
-                    task = cell.task_bf16(tape.X[v][t], tape.H[v][t], tape.C[v][t], tape.H[v][t + 1], tape.C[v][t + 1])
+                    task = cell.task_bf16(tape.X[v][t], tape.H[v][t], tape.C[v][t], tape.H[v][t + 1], tape.C[v][t + 1], n[v])
                 cells.setdefault(d, []).append(task)
             for d, ts in cells.items():
                 for k in range(0, len(ts), 4):
