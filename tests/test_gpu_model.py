@@ -360,14 +360,16 @@ def test_c5_shape_d128_n200(cuda_device):
     assert rel_err(hip["last_states"]["V"].h, ref["last_states"]["V"][0].numpy()) < REL_TOL
 
 
-def test_captured_training_step_matches_eager(cuda_device):
+@pytest.mark.parametrize("float_dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16-storage"])
+def test_captured_training_step_matches_eager(cuda_device, float_dtype):
     """capture_train_step (two HIP graphs around the all-reduce) must walk the same trajectory as eager
-    train_step: identical weights after 3 steps, bit for bit (same kernels, same order)."""
+    train_step: identical weights after 3 steps, bit for bit (same kernels, same order) -- in the bf16-storage mode too,
+    whose backward swaps a rounded copy of the variables in and out inside the captured region."""
     t = pack_tuple("ragged_B6", 1)
     params = P.init_params(64, seed=9, perturb=True)
     finals = []
     for captured in (False, True):
-        model = tspgnn.build_network(64)
+        model = tspgnn.build_network(64, float_dtype=float_dtype)
         sess = tspgnn.Session(model)
         sess.run(tspgnn.global_variables_initializer())
         model.store.load(params)
