@@ -339,6 +339,9 @@ typedef struct tspgnn_lstm_bwd_task {
                                              the caller before the first launch) and leave ln_grad alone; one
                                              tspgnn_lnlstm_bwd_finish_f32 after the last time step folds them -- one
                                              reduction per cell instead of one per time step */
+    const float* zbias; const float* zscale; /* _h2 entry point only (the others require NULL): the forward's z started at
+                                             zscale[row] * zbias[4d] (tspgnn_lstm_task: a bias folded through a row-sum
+                                             aggregation); the recomputation of z starts there too */
 } tspgnn_lstm_bwd_task;   /* fields as the arguments of tspgnn_lnlstm_bwd_f32 / tspgnn_lnlstm_gather_bwd_f32 */
 
 typedef struct tspgnn_mlp_bwd_task {

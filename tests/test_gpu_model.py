@@ -217,6 +217,7 @@ def test_training_forward_fused_messages_write_the_same_tape(cuda_device, name, 
         model.store.load(params)
         gnn = model["gnn"]
         gnn.fuse_training_messages = fuse
+        gnn.push_training = False           # (the fused form keeps the whole message MLP on the edge rows)
         EV, W, C = t[0], t[1], t[2]
         dev = sess.device
         M, N = EV.shape
@@ -692,6 +693,37 @@ def test_bf16_storage_train_steps(cuda_device):
         ref, got = p[k] - params[k], now[k].astype(np.float64) - params[k]
         big = np.abs(ref) > 0.5 * np.abs(ref).max()
         assert np.all(np.sign(ref[big]) == np.sign(got[big])), k
+
+
+@pytest.mark.parametrize("name,d,T", [("ragged_B6", 64, 4), ("n20_B32", 64, 5)])
+def test_pushed_training_gradients_equal_the_plain_form(cuda_device, name, d, T):
+    """Training with the message MLP's last linear layer pushed through the row-sum into the vertex cell (the default,
+    f16x2) against the plain form: same loss, same gradients up to the order of the fp32 sums -- including the three
+    variables whose gradients the pushed form assembles from d(W Kx) and d(b Kx)."""
+    t = pack_tuple(name, 1)
+    params = P.init_params(d, seed=8, perturb=True)
+    grads = []
+    for push in (True, False):
+        model = tspgnn.build_network(d)
+        sess = tspgnn.Session(model)
+        sess.run(tspgnn.global_variables_initializer())
+        model.store.load(params)
+        model["gnn"].push_training = push
+        EV, W, C, route_exists, n_vertices, n_edges = t
+        feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+                model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+        out = sess.loss_and_grads(feed, keep_tape=True)
+        torch.cuda.synchronize()
+        assert out["tape"].pushed["V"] == push and not out["tape"].pushed["E"]
+        grads.append((float(out["stats"][0].item()), model.store.grad_dict()))
+    (loss_p, gp), (loss_u, gu) = grads
+    assert abs(loss_p - loss_u) < 1e-6
+    gscale = max(np.abs(gu[k]).max() for k in gu)
+    for k in gu:
+        scale = max(np.abs(gu[k]).max(), 1e-3 * gscale)
+        # (two fp32 evaluation orders of a batch whose +-dev instance pairs nearly cancel in the mean: a few 1e-5; each
+        # form separately meets the oracle bar in test_gradient_parity_with_autograd_oracle)
+        assert np.abs(gp[k] - gu[k]).max() / scale < 1e-4, k
 
 
 def test_weight_gradient_chunks_agree(cuda_device):

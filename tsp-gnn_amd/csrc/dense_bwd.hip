@@ -818,6 +818,7 @@ extern "C" int tspgnn_lnlstm_bwd_multi_f32(const tspgnn_lstm_bwd_task* tasks, in
                        "lnlstm_bwd: null pointer");
         TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx && (d == 32 || d == 64)),
                        "lnlstm_bwd: gather-init mode needs dx == 0, Zx and d in {32,64}");
+        TSPGNN_REQUIRE(!t.zbias, "lnlstm_bwd: a bias-init z is an f16x2 feature (tspgnn_lnlstm_bwd_multi_h2)");
         live[n++] = t;
     }
     if (n == 0) return TSPGNN_OK;

@@ -51,6 +51,8 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
     const float* __restrict__ Zx = tt.task[k].Zx;
     const _Float16* __restrict__ KT = reinterpret_cast<const _Float16*>(tt.task[k].KT);
     float* __restrict__ dxh = tt.task[k].dxh;
+    const float* __restrict__ zbias = tt.task[k].zbias;
+    const float* __restrict__ zscale = tt.task[k].zscale;
     constexpr int NT4 = D / 4, TPG = D / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     const int KBX = dx >> 5, KBT = (dx + D) >> 5;
@@ -88,6 +90,10 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
             for (int t = 0; t < NT4; ++t) acc[t] = ld4(zu + t * 256);
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] += ld4(zv + t * 256);
+        } else if (zbias != nullptr) {  // the forward's bias-init: z starts at 2^s * zscale[row] * zbias
+            const float sc = zscale[rc] * kH2Scale;
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] = ld4(zbias + t * 16 + g * 4) * sc;
         } else {
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -243,6 +249,7 @@ extern "C" int tspgnn_lnlstm_bwd_multi_h2(const tspgnn_lstm_bwd_task* tasks, int
                        "lnlstm_bwd_h2: null pointer");
         TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx), "lnlstm_bwd_h2: gather-init mode needs dx == 0 and Zx");
         TSPGNN_REQUIRE(!t.KT || (t.dxh && t.dx == 0), "lnlstm_bwd_h2: the fused data gradient needs dxh and dx == 0");
+        TSPGNN_REQUIRE(!t.zbias || (t.zscale && !t.uv), "lnlstm_bwd_h2: zbias needs zscale and excludes gather-init mode");
         live[n++] = t;
     }
     if (n == 0) return TSPGNN_OK;

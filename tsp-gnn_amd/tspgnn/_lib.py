@@ -125,7 +125,7 @@ class LstmBwdTask(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("dx", c_int), ("h", c_void_p), ("c", c_void_p), ("K", c_void_p), ("ln", c_void_p),
                 ("dh_out", c_void_p), ("dc_out", c_void_p), ("dz", c_void_p), ("dc_in", c_void_p), ("ln_grad", c_void_p),
                 ("workspace", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p),
-                ("KT", c_void_p), ("dxh", c_void_p), ("defer_reduce", c_int)]
+                ("KT", c_void_p), ("dxh", c_void_p), ("defer_reduce", c_int), ("zbias", c_void_p), ("zscale", c_void_p)]
 
 
 class MlpBwdTask(ctypes.Structure):

@@ -339,35 +339,97 @@ class LayerNormBasicLSTMCell(object):
                              _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0],
                              _lib.ptr(adj.uv), _lib.ptr(zx), None, None)
 
-    def pushed_bias_pack(self, mlp, arith=None):
-        """For a cell whose input is a row-sum aggregation of ``mlp``'s output: the message MLP's last
-        (linear) layer W,b pushed through the aggregation and through Kx:
-            (sum_e (a_e W + b)) Kx = (sum_e a_e) (W Kx) + degree (b Kx)
-        Returns (pack([W Kx ; Kh]), b Kx): the cell then takes the row-sum of the LAST HIDDEN activation as
-        its input and starts z at degree * (b Kx).  One Dense(d) layer less on every edge row per step."""
+    def pushed_kernel(self, mlp):
+        """(K' = [W Kx ; Kh] as fp32 [dx+d, 4d], b Kx as [1, 4d], pack(K'^T) for the data gradient) of the message MLP's
+        last (linear) layer W, b pushed through a row-sum aggregation and through Kx:
+            (sum_e (a_e W + b)) Kx = (sum_e a_e) (W Kx) + degree (b Kx)."""
         d, dx = self.d, self.dx
         last = mlp.layer_names[-1]
 
         def build(out):
             W, b = self.store.view(last + "/kernel"), self.store.view(last + "/bias")
             if out is None:
-                kp = torch.empty(SPLIT_BYTES[arith] * (dx + d) * 4 * d, dtype=torch.uint8, device=W.device) if arith \
-                    else torch.empty((dx + d, 4 * d), dtype=torch.float32, device=W.device)
-                out = (kp, torch.empty((1, 4 * d), dtype=torch.float32, device=W.device))
-            kp, zb = out
+                out = (torch.empty((dx + d, 4 * d), dtype=torch.float32, device=W.device),
+                       torch.empty((1, 4 * d), dtype=torch.float32, device=W.device),
+                       torch.empty((dx + d, 4 * d), dtype=torch.float32, device=W.device))
+            kfull, zb, kt = out
             st = _lib.current_stream()
-            kfull = torch.empty((dx + d, 4 * d), dtype=torch.float32, device=W.device)
             kfull[dx:].copy_(self.kernel()[dx:])
             _lib.call("tspgnn_linear_f32", _lib.ptr(W), dx, _lib.ptr(self.kx_packed()), None, 0, _lib.ptr(kfull[:dx]),
                       4 * d, 0, W.shape[0], st)
             _lib.call("tspgnn_linear_f32", _lib.ptr(b.view(1, -1)), dx, _lib.ptr(self.kx_packed()), None, 0, _lib.ptr(zb),
                       4 * d, 0, 1, st)
+            _lib.call("tspgnn_pack_weights_f32", _lib.ptr(kfull), _lib.ptr(kt), 4 * d, dx + d, 1, st)
+            return (kfull, zb, kt)
+        return self.store.packed(("lstm.pushed.kernel", self.base, last), build)
+
+    def pushed_bias_pack(self, mlp, arith=None):
+        """For a cell whose input is a row-sum aggregation of ``mlp``'s output: (pack(K'), b Kx) of pushed_kernel in the
+        packing of ``arith``.  The cell then takes the row-sum of the LAST HIDDEN activation as its input and starts z
+        at degree * (b Kx).  One Dense(d) layer less on every edge row per step."""
+        d, dx = self.d, self.dx
+        last = mlp.layer_names[-1]
+
+        def build(out):
+            kfull, zb, _ = self.pushed_kernel(mlp)
+            if out is None:
+                out = torch.empty(SPLIT_BYTES[arith] * (dx + d) * 4 * d, dtype=torch.uint8, device=kfull.device) if arith \
+                    else torch.empty((dx + d, 4 * d), dtype=torch.float32, device=kfull.device)
+            st = _lib.current_stream()
             if arith:
-                _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(kfull), _lib.ptr(kp), dx + d, 4 * d, st)
+                _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(kfull), _lib.ptr(out), dx + d, 4 * d, st)
             else:
-                _lib.call("tspgnn_pack_weights_f32", _lib.ptr(kfull), _lib.ptr(kp), dx + d, 4 * d, 0, st)
-            return (kp, zb)
-        return self.store.packed(("lstm.pushed." + (arith or "f32"), self.base, last), build)
+                _lib.call("tspgnn_pack_weights_f32", _lib.ptr(kfull), _lib.ptr(out), dx + d, 4 * d, 0, st)
+            return out
+        return self.store.packed(("lstm.pushed." + (arith or "f32"), self.base, last), build), self.pushed_kernel(mlp)[1]
+
+    def pushed_backward_task(self, x, h, c, dh_out, dc_out, dz, dc_in, ws, kp, zb, deg, defer=False):
+        """Backward task (tspgnn_lnlstm_bwd_multi_h2) of pushed_task: K = pushed_bias_pack's f16x2 K', z restarts at
+        deg * zb."""
+        return _lib.LstmBwdTask(_lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(kp), _lib.ptr(self.ln()),
+                                _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in), _lib.ptr(self.ln_grad()),
+                                _lib.ptr(ws), h.shape[0], None, None, None, None, 1 if defer else 0, _lib.ptr(zb), _lib.ptr(deg))
+
+    def pushed_backward_data(self, mlp, dz, dx_out, dh_in):
+        """[d(aggregate) | dh] = dz K'^T."""
+        _lib.call("tspgnn_linear_f32", _lib.ptr(dz), 4 * self.d, _lib.ptr(self.pushed_kernel(mlp)[2]), _lib.ptr(dx_out),
+                  self.dx, _lib.ptr(dh_in), self.d, 0, dz.shape[0], _lib.current_stream())
+
+    def pushed_backward_weights(self, agg_all, h_all, dz_all, rows, deg_all, g_wkx, g_zb):
+        """Over rows = steps * rows_per_step: g_wkx[dx,4d] += agg^T dz (gradient w.r.t. the product W Kx), dKh += h^T dz,
+        g_zb[4d] += sum_r deg[r] dz[r] (gradient w.r.t. b Kx); pushed_backward_finish turns the first and the last
+        into the gradients of W, b and Kx."""
+        gK = self.store.grad_view(self.base + "/kernel")
+        st = _lib.current_stream()
+        ws = _lib.workspace("tspgnn_wgrad_workspace_floats", rows, max(self.dx, self.d), 4 * self.d, device=dz_all.device)
+        _lib.call("tspgnn_wgrad_f32", _lib.ptr(agg_all), _lib.ptr(dz_all), rows, self.dx, 4 * self.d, _lib.ptr(g_wkx), None,
+                  _lib.ptr(ws), st)
+        _lib.call("tspgnn_wgrad_f32", _lib.ptr(h_all), _lib.ptr(dz_all), rows, self.d, 4 * self.d, _lib.ptr(gK[self.dx:]), None,
+                  _lib.ptr(ws), st)
+        ws = _lib.workspace("tspgnn_wcolsum_workspace_floats", rows, 4 * self.d, device=dz_all.device)
+        _lib.call("tspgnn_wcolsum_f32", _lib.ptr(dz_all), _lib.ptr(deg_all), rows, 4 * self.d, 1.0, _lib.ptr(g_zb), None,
+                  _lib.ptr(ws), st)
+
+    def pushed_backward_finish(self, mlp, g_wkx, g_zb):
+        """With P = W Kx and q = b Kx:  dW += dP Kx^T,  db += dq Kx^T,  dKx += W^T dP + b^T dq  (once per training step,
+        on [dx, 4d]-sized operands)."""
+        d, dx, st = self.d, self.dx, _lib.current_stream()
+        last = mlp.layer_names[-1]
+        W, b = self.store.view(last + "/kernel"), self.store.view(last + "/bias")
+        f32 = dict(dtype=torch.float32, device=W.device)
+        dW, db = torch.empty((W.shape[0], dx), **f32), torch.empty((1, dx), **f32)
+        _lib.call("tspgnn_linear_f32", _lib.ptr(g_wkx), 4 * d, _lib.ptr(self.kx_t_packed()), _lib.ptr(dW), dx, None, 0, 0,
+                  g_wkx.shape[0], st)
+        _lib.call("tspgnn_linear_f32", _lib.ptr(g_zb), 4 * d, _lib.ptr(self.kx_t_packed()), _lib.ptr(db), dx, None, 0, 0, 1, st)
+        self.store.grad_view(last + "/kernel").add_(dW)
+        self.store.grad_view(last + "/bias").add_(db.view(-1))
+        packed = torch.empty_like(g_wkx)
+        _lib.call("tspgnn_pack_weights_f32", _lib.ptr(g_wkx), _lib.ptr(packed), g_wkx.shape[0], 4 * d, 0, st)
+        wt = W.t().contiguous()
+        dkx = torch.empty((dx, 4 * d), **f32)
+        _lib.call("tspgnn_linear_f32", _lib.ptr(wt), wt.shape[1], _lib.ptr(packed), None, 0, _lib.ptr(dkx), 4 * d, 0, dx, st)
+        dkx.addcmul_(b.view(-1, 1), g_zb.view(1, -1))
+        self.store.grad_view(self.base + "/kernel")[:dx].add_(dkx)
 
     def pushed_task(self, x, state, out, kp, zb, deg):
         """Cell task whose kernel operand is pushed_bias_pack's K' (either packing) and z starts at deg * zb."""
@@ -522,6 +584,9 @@ class GraphNN(object):
         self.float_dtype = float_dtype
         self.store = store if store is not None else V.get_default_store()
         self.fold_adjacency = True   # (EV y) Kx = EV (y Kx) fast path; False = op-for-op reference order
+        # training (f16x2): a message MLP's last linear layer pushed through the row-sum into the receiving cell, as in the
+        # inference plan (one Dense layer less per edge row in the forward, the backward and the weight gradients)
+        self.push_training = os.environ.get("TSPGNN_PUSH_TRAINING", "1") != "0"
         self.wgrad_chunk_bytes = 24 * 2 ** 30   # backward: budget for the pre-activation gradients kept per weight-gradient chunk
         # training forward: message MLPs of step t+1 inside the cell launch of step t (TSPGNN_FUSE_TRAINING=1).  Off by
         # default: the tape makes the training forward HBM-write-bound, and there the two plain launches at full occupancy
@@ -1212,6 +1277,7 @@ class GraphNN(object):
         tape.fused = False
         if bf16:
             tape.arith = "bf16"
+            tape.pushed = {v: False for v in self.var}
             self._forward_train_bf16(tape, n, T)
             return {v: LSTMStateTuple(c=tape.C[v][T], h=tape.H[v][T]) for v in self.var}, tape
         # forward GEMMs in the split-operand arithmetic selected by self.gemm (fp32-class accuracy).  With f16x2 the
@@ -1221,6 +1287,10 @@ class GraphNN(object):
         tape.arith = arith
         mlp_fn = "tspgnn_mlp_fwd_multi_" + (arith or "f32")
         lstm_fn = "tspgnn_lnlstm_fwd_multi_" + (arith or "f32")
+        # pushed cells (f16x2): the tape's X[v] holds the row-sum of the message MLP's LAST HIDDEN activation and the cell
+        # runs with K' = [W Kx ; Kh], z starting at degree * (b Kx) (LayerNormBasicLSTMCell.pushed_kernel)
+        tape.pushed = {v: bool(arith == "h2" and self.push_training and not self.fuse_training_messages
+                               and self._pushable(v, mats, tape.folded)) for v in self.var}
 
         def message_dest(v, i, t):
             """(out, projection) of loop entry (v, i)'s message MLP at step t: outputs straight into the tape."""
@@ -1243,6 +1313,13 @@ class GraphNN(object):
                     if "msg" in u:
                         mlp = self._msg_MLPs[u["msg"]]
                         acts = tape.acts[(v, i)]
+                        if tape.pushed[v]:      # all but the last layer; its output is the last saved activation
+                            k = mlp.n_square - 1
+                            out = acts[k - 1, t]
+                            mlp_tasks.setdefault(mlp.sizes[-1], []).append(
+                                mlp.prefix_task(y, out, k, arith=arith, acts=acts[:, t], acts_stride=acts.stride(0)))
+                            msg_out[(v, i)] = out
+                            continue
                         out, proj = message_dest(v, i, t)
                         task = mlp.task(y, out, acts[:, t], acts.stride(0), proj=proj, arith=arith)
                         if task is None:
@@ -1289,6 +1366,11 @@ class GraphNN(object):
             out = (tape.H[v][t + 1], tape.C[v][t + 1])
             if tape.folded[v] is not None:
                 return cell.gather_task(mats[tape.folded[v]["mat"]], tape.ZX[v][t], st, out, arith=arith)
+            if tape.pushed[v]:
+                u0 = self.loop[v][0]
+                kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], arith=arith)
+                return cell.pushed_task(tape.X[v][t], st, out, kp, zb,
+                                        mats[u0["mat"]].row_degrees(bool(u0.get("transpose?", False))))
             return cell.task(tape.X[v][t], st, out, arith=arith)
 
         # f16x2, opt-in (fuse_training_messages): the message MLPs of step t+1 ride in the cell launch of step t, on the
@@ -1427,6 +1509,7 @@ class GraphNN(object):
         # Weight gradients are one reduction per variable over a CHUNK of time steps: all T when the gradients w.r.t.
         # the pre-activations of the chunk (4d + the MLP layers' d floats per row and step) fit the budget -- the C2
         # case, ~6 GB -- else the largest chunk that does (a C5 shard: 84 GB for all 64 steps)
+        pushed = getattr(tape, "pushed", None) or {v: False for v in self.var}
         per_step = sum(n[v] * 4 * d * 4 for v, d in self.var.items())
         per_step += sum(self._msg_MLPs[self.loop[v][i]["msg"]].n_square * n[self.loop[v][i]["var"]]
                         * self.var[self.loop[v][i]["var"]] * 4 for (v, i) in tape.acts)
@@ -1436,17 +1519,29 @@ class GraphNN(object):
         for (v, i), acts in tape.acts.items():
             u = self.loop[v][i]
             mlp = self._msg_MLPs[u["msg"]]
-            DPRE[(v, i)] = torch.empty((mlp.n_square, CH, n[u["var"]], self.var[u["var"]]), **f32)
+            DPRE[(v, i)] = torch.empty((mlp.n_square - (1 if pushed[v] else 0), CH, n[u["var"]], self.var[u["var"]]), **f32)
         # LayerNorm-gradient partials of all T steps accumulate here (zeroed); one fold per cell after the loop
         ws = {v: _lib.workspace("tspgnn_lnlstm_bwd_workspace_floats", d, device=device).zero_() for v, d in self.var.items()}
         DZX = {v: torch.empty((CH, tape.X[v].shape[1], 4 * self.var[v]), **f32) for v in self.var if folded[v] is not None}
+
+        # pushed cells: gradients w.r.t. the products W Kx [dx, 4d] and b Kx [4d], split into dW, db, dKx after the loop
+        push = {}
+        for v, d in self.var.items():
+            if pushed[v]:
+                u0 = self.loop[v][0]
+                deg = mats[u0["mat"]].row_degrees(bool(u0.get("transpose?", False)))
+                push[v] = dict(mlp=self._msg_MLPs[u0["msg"]], deg=deg, deg_steps=deg.repeat(CH),
+                               g_wkx=torch.zeros((self._RNN_cells[v].dx, 4 * d), **f32), g_zb=torch.zeros((1, 4 * d), **f32))
 
         def weight_gradients(t0, t1):
             """Steps [t0, t1): their dz / dpre sit in slots 0 .. t1-t0-1 of the chunk buffers."""
             steps = t1 - t0
             for v, d in self.var.items():
                 cell = self._RNN_cells[v]
-                if folded[v] is not None:
+                if pushed[v]:
+                    cell.pushed_backward_weights(tape.x_steps(v, t0, t1), tape.h_steps(v, t0, t1), DZ[v][:steps].view(-1, 4 * d),
+                                                 steps * n[v], push[v]["deg_steps"], push[v]["g_wkx"], push[v]["g_zb"])
+                elif folded[v] is not None:
                     rows_src = steps * tape.X[v].shape[1]
                     cell.backward_weights_folded(tape.x_steps(v, t0, t1), DZX[v][:steps].view(-1, 4 * d), rows_src,
                                                  tape.h_steps(v, t0, t1), DZ[v][:steps].view(-1, 4 * d), steps * n[v])
@@ -1457,8 +1552,10 @@ class GraphNN(object):
                 u = self.loop[v][i]
                 mlp = self._msg_MLPs[u["msg"]]
                 src, dsrc = u["var"], self.var[u["var"]]
-                inputs = [tape.h_steps(src, t0, t1)] + [tape.acts_steps((v, i), l, t0, t1) for l in range(mlp.n_square - 1)]
-                mlp.backward_weights(inputs, [dpre[l, :steps].reshape(-1, dsrc) for l in range(mlp.n_square)], steps * n[src])
+                layers = dpre.shape[0]      # (a pushed entry's last layer has its gradient formed on the receiving side)
+                inputs = [tape.h_steps(src, t0, t1)] + [tape.acts_steps((v, i), l, t0, t1) for l in range(layers - 1)]
+                mlp.backward_weights(inputs, [dpre[l, :steps].reshape(-1, dsrc) for l in range(layers)], steps * n[src],
+                                     n_layers=layers)
 
         dH = {v: (dstates.get(v, (None, None))[0]) for v in self.var}
         dC = {v: (dstates.get(v, (None, None))[1]) for v in self.var}
@@ -1478,6 +1575,10 @@ class GraphNN(object):
                     keep += [h_t, zx_t]
                     task = cell.gather_backward_task(mats[folded[v]["mat"]], zx_t, h_t, c_t, dH[v], dC[v], DZ[v][k], ndC[v],
                                                      ws[v], dh_in=ndH[v], defer=True, arith=bwd_arith)
+                elif pushed[v]:
+                    kp, zb = cell.pushed_bias_pack(push[v]["mlp"], arith="h2")
+                    task = cell.pushed_backward_task(tape.x(v, t), h_t, c_t, dH[v], dC[v], DZ[v][k], ndC[v], ws[v], kp, zb,
+                                                     push[v]["deg"], defer=True)
                 else:
                     x_t = tape.x(v, t)
                     keep += [h_t, x_t]
@@ -1493,6 +1594,8 @@ class GraphNN(object):
                 if folded[v] is not None:   # dX[v] becomes the gradient w.r.t. the message y (source rows)
                     cell.gather_backward_data(mats[folded[v]["mat"]], DZ[v][k], None if cell.d == 64 else ndH[v],
                                               DZX[v][k], dX[v])   # (d == 64: dh was formed by the cell launch)
+                elif pushed[v]:             # dX[v] becomes the gradient w.r.t. the aggregated last hidden activation
+                    cell.pushed_backward_data(push[v]["mlp"], DZ[v][k], dX[v], ndH[v])
                 else:
                     cell.backward_data(DZ[v][k], dX[v], ndH[v])
             # ---- 3: adjoint adjacency products, then every message MLP's data gradient in one launch
@@ -1516,6 +1619,14 @@ class GraphNN(object):
                         mlp = self._msg_MLPs[u["msg"]]
                         (acts_t, acts_stride), dpre = tape.acts_at((v, i), t), DPRE[(v, i)]
                         keep.append(acts_t)
+                        if pushed[v]:   # the chain ends at the last hidden activation (a relu layer: masked by its output)
+                            task = mlp.backward_prefix_task(dpre.shape[0], dy, acts_t, acts_stride, acts_t[dpre.shape[0] - 1],
+                                                            dpre[:, k], dpre.stride(0), ndH[src], True, gather_uv=gather_uv)
+                            if task is None or src in targets:
+                                raise NotImplementedError("pushed training needs the message MLP's backward in one launch")
+                            mlp_tasks.append((self.var[src], task, dy))
+                            targets.append(src)
+                            continue
                         task = mlp.backward_task(dy, acts_t, acts_stride, None, dpre[:, k], dpre.stride(0),
                                                  ndH[src], True, gather_uv=gather_uv)
                         if task is None or src in targets:   # several kernels, or a second writer of ndH[src]
@@ -1537,4 +1648,6 @@ class GraphNN(object):
                 weight_gradients(t, min(t + CH, T))
         for v in self.var:
             self._RNN_cells[v].backward_finish(ws[v])      # LayerNorm parameters: the deferred per-step partials
+            if pushed[v]:
+                self._RNN_cells[v].pushed_backward_finish(push[v]["mlp"], push[v]["g_wkx"], push[v]["g_zb"])
         return {v: (dH[v], dC[v]) for v in self.var}

@@ -179,13 +179,14 @@ class Mlp(object):
         return _lib.MlpTask(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(out), _lib.ptr(acts),
                             acts_stride, x.shape[0], n_sq, self.relu_mask(0, n_sq), _lib.ptr(pw), _lib.ptr(po))
 
-    def prefix_task(self, x, out, n_layers, arith=None):
-        """Task running only the first ``n_layers`` square layers (the rest is folded elsewhere)."""
+    def prefix_task(self, x, out, n_layers, arith=None, acts=None, acts_stride=0):
+        """Task running only the first ``n_layers`` square layers (the rest is folded elsewhere); ``acts``: the hidden
+        activations of those layers (all but the last, which is ``out``) are saved as by task()."""
         kind, d, n_sq, head = self._plan
         if kind != "square" or head or len(self._chunks()) != 1 or not (1 <= n_layers <= n_sq):
             return None
         wb = self.wb_packed_split(arith, 0, n_layers - 1, d) if arith else self.wb_packed(0, n_layers - 1, d)
-        return _lib.MlpTask(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(out), None, 0,
+        return _lib.MlpTask(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(out), _lib.ptr(acts) if n_layers > 1 else None, acts_stride,
                             x.shape[0], n_layers, self.relu_mask(0, n_layers), None, None)
 
     def _chunks(self):
@@ -236,17 +237,28 @@ class Mlp(object):
                                dY.shape[0] if gather_uv is None else gather_uv.shape[0], n_sq, self.relu_mask(0, n_sq),
                                _lib.ptr(gather_uv))
 
+    def backward_prefix_task(self, n_layers, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, gather_uv=None):
+        """backward_task for the first ``n_layers`` square layers only (the rest was pushed elsewhere); ``y_out`` = the
+        prefix's output (read when its last layer has relu)."""
+        kind, d, n_sq, head = self._plan
+        if len(self._chunks()) != 1 or not (1 <= n_layers <= n_sq):
+            return None
+        return _lib.MlpBwdTask(_lib.ptr(dY), _lib.ptr(self.wt_packed(0, n_layers - 1, d)), _lib.ptr(acts), acts_stride,
+                               _lib.ptr(y_out), _lib.ptr(dpre), dpre_stride, _lib.ptr(dX), 1 if accumulate else 0,
+                               dY.shape[0] if gather_uv is None else gather_uv.shape[0], n_layers,
+                               self.relu_mask(0, n_layers), _lib.ptr(gather_uv))
+
     def backward_task_fuses_gather(self, dY):
         """backward_task(..., gather_uv=...) is available: one kernel covers the chain and dY is a plain fp32 array."""
         return len(self._chunks()) == 1 and dY.dtype == torch.float32 and dY.is_contiguous()
 
-    def backward_weights(self, layer_inputs, layer_dpre, rows):
-        """dW_l += X_l^T dPre_l, db_l += colsum(dPre_l) for the square layers; ``rows`` may span all
-        time steps (inputs / dpre are [T*rows_per_step, d] contiguous)."""
+    def backward_weights(self, layer_inputs, layer_dpre, rows, n_layers=None):
+        """dW_l += X_l^T dPre_l, db_l += colsum(dPre_l) for the square layers (the first ``n_layers`` of them); ``rows``
+        may span all time steps (inputs / dpre are [T*rows_per_step, d] contiguous)."""
         kind, d, n_sq, head = self._plan
         ws = _lib.workspace("tspgnn_wgrad_workspace_floats", rows, d, d, device=layer_dpre[0].device)
         st = _lib.current_stream()
-        for l in range(n_sq):
+        for l in range(n_sq if n_layers is None else n_layers):
             name = self.layer_names[l]
             _lib.call("tspgnn_wgrad_f32", _lib.ptr(layer_inputs[l]), _lib.ptr(layer_dpre[l]), rows, d, d,
                       _lib.ptr(self.store.grad_view(name + "/kernel")), _lib.ptr(self.store.grad_view(name + "/bias")),
