@@ -20,6 +20,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (dense_bwd.hip).
 void reduce_partials(const float* partial, int n_chunks, long long stride, float* out, int n, float scale,
                      int accumulate, hipStream_t st);
+// The same with a second output segment of the same chunking (b: partial_b / stride_b / out_b / n_b; out_b == NULL: none)
+// in the one launch.
+void reduce_partials2(const float* partial, int n_chunks, long long stride, float* out, int n, const float* partial_b,
+                      long long stride_b, float* out_b, int n_b, float scale, int accumulate, hipStream_t st);
 
 #define TSPGNN_REQUIRE(cond, ...) \
     do {                          \

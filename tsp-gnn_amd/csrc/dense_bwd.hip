@@ -292,36 +292,60 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_kernel(const LstmBwdTaskTa
 // Thread (i, slice) first sums the chunks c = slice, slice+S, ... (S = blockDim.y slices, loads of
 // different slices in flight together, each coalesced over i), then the slices are folded through LDS
 // in a fixed order: deterministic, and parallel enough for n = 4096 outputs x 2048 chunks.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n_chunks,
-                                                              long long stride, float* __restrict__ out, int n,
-                                                              float scale, int accumulate) {
+struct ReduceSeg {
+    const float* partial; long long stride; float* out; int n; int blocks;   // blocks: workgroups this segment owns
+};
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceSeg a, const ReduceSeg b, int n_chunks, float scale,
+                                                              int accumulate) {
     // The chunk partials are folded in float64: a gradient that is a small difference of large per-graph
     // contributions (labels 0/1 pull in opposite directions) would otherwise lose its digits HERE, in the one
     // place where thousands of fp32 partials of either sign meet; n_chunks * n adds, free on this chip.
     __shared__ double red[256];
+    const bool second = (int)blockIdx.x >= a.blocks;      // (a second output segment of the same chunking rides along:
+    const ReduceSeg& sg = second ? b : a;                 //  a weight gradient's bias row -- one launch instead of two)
+    const int blk = second ? blockIdx.x - a.blocks : blockIdx.x;
     const int S = blockDim.y;  // slices; blockDim.x * S == 256
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blk * blockDim.x + threadIdx.x;
     double s = 0.0;
-    if (i < n) {
-        for (int c = threadIdx.y; c < n_chunks; c += S) s += (double)partial[(size_t)c * stride + i];
+    if (i < sg.n) {
+        // four independent running sums (loads of four chunks in flight per thread), folded in a fixed order
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int c = threadIdx.y;
+        for (; c + 3 * S < n_chunks; c += 4 * S) {
+            const float p0 = sg.partial[(size_t)c * sg.stride + i], p1 = sg.partial[(size_t)(c + S) * sg.stride + i];
+            const float p2 = sg.partial[(size_t)(c + 2 * S) * sg.stride + i], p3 = sg.partial[(size_t)(c + 3 * S) * sg.stride + i];
+            s0 += (double)p0;
+            s1 += (double)p1;
+            s2 += (double)p2;
+            s3 += (double)p3;
+        }
+        for (; c < n_chunks; c += S) s0 += (double)sg.partial[(size_t)c * sg.stride + i];
+        s = (s0 + s1) + (s2 + s3);
     }
     red[threadIdx.y * blockDim.x + threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.y == 0 && i < n) {
+    if (threadIdx.y == 0 && i < sg.n) {
         double t = red[threadIdx.x];
         for (int k = 1; k < S; ++k) t += red[k * blockDim.x + threadIdx.x];
         t *= (double)scale;
-        out[i] = (float)(accumulate ? t + (double)out[i] : t);
+        sg.out[i] = (float)(accumulate ? t + (double)sg.out[i] : t);
     }
+}
+
+void reduce_partials2(const float* partial, int n_chunks, long long stride, float* out, int n, const float* partial_b,
+                      long long stride_b, float* out_b, int n_b, float scale, int accumulate, hipStream_t st) {
+    // many chunks: 16 outputs x 16 slices per workgroup; few chunks: 256 outputs x 1 slice
+    const int S = n_chunks >= 64 ? 16 : (n_chunks >= 8 ? 4 : 1);
+    const dim3 block(256 / S, S);
+    const ReduceSeg a = {partial, stride, out, n, (int)((n + block.x - 1) / block.x)};
+    const ReduceSeg b = {partial_b, stride_b, out_b, n_b, out_b != nullptr ? (int)((n_b + block.x - 1) / block.x) : 0};
+    reduce_partials_kernel<<<a.blocks + b.blocks, block, 0, st>>>(a, b, n_chunks, scale, accumulate);
 }
 
 void reduce_partials(const float* partial, int n_chunks, long long stride, float* out, int n, float scale,
                      int accumulate, hipStream_t st) {
-    // many chunks: 16 outputs x 16 slices per workgroup; few chunks: 256 outputs x 1 slice
-    const int S = n_chunks >= 64 ? 16 : (n_chunks >= 8 ? 4 : 1);
-    const dim3 block(256 / S, S);
-    reduce_partials_kernel<<<(n + block.x - 1) / block.x, block, 0, st>>>(partial, n_chunks, stride, out, n, scale,
-                                                                          accumulate);
+    reduce_partials2(partial, n_chunks, stride, out, n, nullptr, 0, nullptr, 0, scale, accumulate, st);
 }
 
 // ------------------------------------------------------------------------------------ MLP backward (data)
@@ -929,11 +953,6 @@ extern "C" int tspgnn_wgrad_f32(const float* X, const float* dY, long long rows,
 #undef TSPGNN_WG
     if (rc) return rc;
     const int n = kin * nout;
-    reduce_partials(P, nc, n, dW, n, 1.0f, 1, st);
-    if ((rc = launched("tspgnn_wgrad_f32(reduce)"))) return rc;
-    if (db) {
-        reduce_partials(Pb, nc, nout, db, nout, 1.0f, 1, st);
-        rc = launched("tspgnn_wgrad_f32(reduce bias)");
-    }
-    return rc;
+    reduce_partials2(P, nc, n, dW, n, Pb, nout, db, db ? nout : 0, 1.0f, 1, st);   // (the bias row in the same launch)
+    return launched("tspgnn_wgrad_f32(reduce)");
 }

@@ -286,13 +286,8 @@ extern "C" int tspgnn_wcolsum_f32(const float* X, const float* wt, long long row
                                                  d / 4, cr);
     int rc = launched("tspgnn_wcolsum_f32");
     if (rc) return rc;
-    reduce_partials(workspace, nc, d, out, d, scale, 1, st);
-    if ((rc = launched("tspgnn_wcolsum_f32(reduce)"))) return rc;
-    if (out_wsum) {
-        reduce_partials(Pw, nc, 1, out_wsum, 1, scale, 1, st);
-        rc = launched("tspgnn_wcolsum_f32(reduce w)");
-    }
-    return rc;
+    reduce_partials2(workspace, nc, d, out, d, Pw, 1, out_wsum, out_wsum ? 1 : 0, scale, 1, st);
+    return launched("tspgnn_wcolsum_f32(reduce)");
 }
 
 static int einit_np(int d) {
