@@ -258,7 +258,8 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     int* ticket = reinterpret_cast<int*>(lds_ln + 10 * D);
     unsigned char* lds_wb = ldsb + (10 * D + 4) * sizeof(float);
     _Float16* lds_w = reinterpret_cast<_Float16*>(lds_wb);
-    const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int rl = lane & 15, g = lane >> 4;   // (re-derived per tile inside the loops: see opaque_lane)
     // LayerNorm parameters, rows [g_i, b_i, g_j, b_j, g_f, b_f, g_o, b_o, g_s, b_s]: the gates i, f, o feed sigmoids
     // only, so their gamma / beta are stored times -log2(e) with the forget bias folded into b_f (lstm_gates<D, true>)
     for (int i = tid; i < 10 * D; i += blockDim.x) {
@@ -339,6 +340,12 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
             if (lane == 0) tile = atomicAdd(ticket, 1);
             tile = __builtin_amdgcn_readfirstlane(tile);
             if (tile >= t_end) break;
+            {   // the lane's coordinates in the tile, recomputed (two VALU instructions) instead of kept: as loop invariants
+                // they and what is derived from them were SPILLED to scratch, a reload on every tile's critical path
+                const int l = opaque_lane();
+                rl = l & 15;
+                g = l >> 4;
+            }
             const int row = tile * 16 + rl;
             const bool valid = row < rows;
             const unsigned rc = (unsigned)(valid ? row : rows - 1);
@@ -378,6 +385,11 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         const int lw = tt.lock_tiles[k];
         const int rounds = (tiles_total + lw - 1) / lw;
         for (int r = my_blk; r < rounds; r += my_grid) {
+            {
+                const int l = opaque_lane();
+                rl = l & 15;
+                g = l >> 4;
+            }
             const int tile = r * lw + wave;
             const bool live = wave < lw && tile < tiles_total;
             const int row = tile * 16 + rl;

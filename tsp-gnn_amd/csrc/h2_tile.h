@@ -55,6 +55,14 @@ __device__ __forceinline__ unsigned h2_state_row(unsigned r, int g, bool blocked
     return blocked ? (r >> 4) * (unsigned)(D / 16 * 256) + (unsigned)g * 64u + (r & 15u) * 4u : r * (unsigned)D + (unsigned)g * 4u;
 }
 
+// The lane id (0..63) through an asm the optimiser cannot hoist out of a loop or fold with another copy: quantities derived
+// from it inside a loop body are recomputed per iteration rather than carried -- and spilled -- across iterations.
+__device__ __forceinline__ int opaque_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 __device__ __forceinline__ f16x8 ldw(const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); }
 
 // acc[t] += W-block(kb, all NT tiles) x B for one 32-feature k-block; wh / wl = the two pieces of the packed matrix
