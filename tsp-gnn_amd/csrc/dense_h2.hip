@@ -399,9 +399,6 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
             {
                 f32x4 acc[NT4], cf[TPG];
                 init_acc(acc, rc);
-#pragma unroll
-                for (int t = 0; t < TPG; ++t)
-                    cf[t] = c != nullptr ? ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
                 // The [x | h] operand rows of up to four k-blocks are fetched before the K staging is waited for: every
                 // wavefront of the workgroup is in the same phase here, nobody hides a global round trip per k-block.
                 constexpr int KBP = 4;
@@ -445,6 +442,11 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                     h2_copy_to_lds(lds_wb, mlp_wb, n_layers * LAYER_BYTES, tid, blockDim.x);
                     if (proj_w != nullptr && together) h2_copy_to_lds(lds_proj, proj_w, 2 * D * 4 * D * 2, tid, blockDim.x);
                 }
+                // (the row of c is fetched only now: held across the GEMM next to the preloaded operands it was spilled --
+                // behind a wait for every load in flight; the four gate LayerNorms that precede its first use cover it)
+#pragma unroll
+                for (int t = 0; t < TPG; ++t)
+                    cf[t] = c != nullptr ? ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
                 cell(acc, cf, rc, valid, hn);
             }
             if (n_layers > 0) {
