@@ -1,0 +1,119 @@
+// Device-side building blocks of the f16x2 kernels (dense_h2.hip: forward; dense_bwd_h2.hip: backward): the two-piece
+// fp16 split of an fp32 operand, the k-block MFMA step over packed weights, LDS staging.  See dense_h2.hip for the
+// arithmetic and its range conventions.
+#pragma once
+#include "common.h"
+#include "mfma_tile.h"
+
+namespace tspgnn {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+constexpr int kH2ScaleLog2 = TSPGNN_H2_WEIGHT_SCALE_LOG2;
+constexpr float kH2Scale = (float)(1 << kH2ScaleLog2);
+constexpr float kH2InvScale = 1.0f / kH2Scale;
+constexpr float kH2GateEps = 1e-12f * kH2Scale * kH2Scale;  // LayerNorm epsilon of a z scaled by 2^s
+constexpr float kNegLog2e = -1.4426950408889634f;
+
+// x = hi + lo to 2^-24 relative: two v_cvt_pk_f16_f32 and two v_fma_mix_f32 (x - float(hi), the fp16 operand widened
+// inside the instruction) per pair of values.
+__device__ __forceinline__ void split2(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2 v = {x[i], x[i + 1]};
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x[i]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x[i + 1]));
+        const f32x2 r = {r0, r1};
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        hi[i] = h[0];
+        hi[i + 1] = h[1];
+        lo[i] = l[0];
+        lo[i + 1] = l[1];
+    }
+}
+
+// The projected messages Zx = 2^s (y Kx) between an f16x2 projection (producer, vertex rows) and an f16x2 cell in
+// gather-init mode (consumer, edge rows) are stored BLOCKED by 16 source rows: the float4 (columns 16t + 4g .. +3) of
+// row v lives at  (((v / 16) * (D/4) + t) * 4 + g) * 64 + (v % 16) * 4  floats.  The producer's 16-row tile then stores
+// 1 KiB contiguous per instruction, and the consumer -- lane (rl, g) gathers row v_rl, and consecutive edges of a graph
+// have consecutive far endpoints -- finds the four lanes of a load quad in ONE 64-byte segment instead of in four
+// different 1 KB rows (the L1 looks up a line per distinct segment of a quad: 64 -> ~20 cycles per gather instruction).
+// Rows are padded to a multiple of 16.  h2_zx_row(v, g): offset of (v, t = 0, g); add 256 floats per tile t.
+template <int D>
+__device__ __forceinline__ unsigned h2_zx_row(unsigned v, int g) {
+    return (v >> 4) * (unsigned)(D / 4 * 256) + (unsigned)g * 64u + (v & 15u) * 4u;
+}
+
+// The same blocking for a [rows, D] state array (h, c of the T-step loop's ping-pong buffers): offset of (r, t = 0, g)
+// and the stride between tiles t, row-major when `blocked` is false.
+template <int D>
+__device__ __forceinline__ unsigned h2_state_row(unsigned r, int g, bool blocked) {
+    return blocked ? (r >> 4) * (unsigned)(D / 16 * 256) + (unsigned)g * 64u + (r & 15u) * 4u : r * (unsigned)D + (unsigned)g * 4u;
+}
+
+// The lane id (0..63) through an asm the optimiser cannot hoist out of a loop or fold with another copy: quantities derived
+// from it inside a loop body are recomputed per iteration rather than carried -- and spilled -- across iterations.
+__device__ __forceinline__ int opaque_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+__device__ __forceinline__ f16x8 ldw(const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); }
+
+// acc[t] += W-block(kb, all NT tiles) x B for one 32-feature k-block; wh / wl = the two pieces of the packed matrix
+// (LDS), (bh, bl) = split2 of the lane's eight B values.  The fragments of tile t+1 are fetched while the three
+// (dependent) MFMAs of tile t run.
+#ifndef H2_PF
+#define H2_PF 1   // fragment pairs in flight ahead of the MFMAs (2 and 3 measured slower: registers)
+#endif
+#ifndef H2_LN_SWAP
+#define H2_LN_SWAP 1
+#endif
+template <int NT>
+__device__ __forceinline__ void kblock_h2(f32x4 (&acc)[NT], const _Float16* wh, const _Float16* wl, int kb, int g, int jl,
+                                          const f16x8& bh, const f16x8& bl) {
+    const int off = ((kb * 4 + g) * NT * 16 + jl) * 8;
+    // The fragments of the next PF tiles are in flight while the three MFMAs of this one run (the compiler interleaves
+    // the MFMA chains of neighbouring tiles on top of that).
+    constexpr int PF = H2_PF < NT ? H2_PF : NT;
+    f16x8 ah[PF + 1], al[PF + 1];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        ah[p] = ldw(wh + off + p * 128);
+        al[p] = ldw(wl + off + p * 128);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t + PF < NT) {
+            ah[(t + PF) % (PF + 1)] = ldw(wh + off + (t + PF) * 128);
+            al[(t + PF) % (PF + 1)] = ldw(wl + off + (t + PF) * 128);
+        }
+        const f16x8 a_h = ah[t % (PF + 1)], a_l = al[t % (PF + 1)];
+        f32x4 c = acc[t];
+        c = MFMA_F16(a_l, bh, c);  // smallest terms first
+        c = MFMA_F16(a_h, bl, c);
+        c = MFMA_F16(a_h, bh, c);
+        acc[t] = c;
+    }
+}
+
+// bytes -> LDS, 16 bytes per lane, straight from global memory (global_load_lds_dwordx4); the LDS address of a lane is
+// the wavefront's base + lane*16.  Callers follow up with h2_stage_wait() + a barrier.
+__device__ __forceinline__ void h2_copy_to_lds(void* dst, const void* __restrict__ src, int nbytes, int tid, int nthreads) {
+    const int lane = tid & 63, n16 = nbytes >> 4;
+    const char* s = reinterpret_cast<const char*>(src);
+    char* d = reinterpret_cast<char*>(dst);
+    for (int idx = tid; idx - lane < n16; idx += nthreads) {
+        if (idx < n16)
+            __builtin_amdgcn_global_load_lds(s + (size_t)idx * 16,
+                                             (__attribute__((address_space(3))) void*)(d + (size_t)(idx - lane) * 16), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void h2_stage_wait() { __builtin_amdgcn_s_waitcnt(0); }
+
+}  // namespace tspgnn
