@@ -58,10 +58,25 @@ def _worker(rank, world, port, bounds, q):
     theta0 = store.theta.clone()
     if rank != 0:
         store.theta.add_(1.0)          # a replica that drifted: the broadcast restores rank 0's variables
+    else:
+        # rank 0 alone restored a checkpoint with optimiser slots (util.load_weights creates them there only): every
+        # rank must still issue the same collectives, and end up with rank 0's moments and step count
+        sess._ensure_adam()
+        sess._adam["m"].fill_(3.0); sess._adam["v"].fill_(5.0); sess._adam["t"].fill_(7); sess._adam["step"] = 7
     sess.broadcast_variables(0)
+    slots_ok = (float(sess._adam["m"].min()) == 3.0 and float(sess._adam["v"].max()) == 5.0
+                and int(sess._adam["t"]) == 7 and sess._adam["step"] == 7)
+    # an assignment of the variables after the first sync (store.load on rank 0) triggers a new broadcast
+    sess._sync_replicas_once()         # nothing changed: no collective on any rank
+    store.load({"V_init": np.full((1, d), float(rank + 2), dtype=np.float32)})
+    sess._sync_replicas_once()
+    resynced = float(store.view("V_init").min()) == 2.0 and float(store.view("V_init").max()) == 2.0
+    store.load({"V_init": theta0[store.offset("V_init"):store.offset("V_init") + d].numpy()})
+    sess._sync_replicas_once()
     means = sess.allreduce_host_sums(np.array([float(hi - lo), 1.0]))
     if rank == world - 1:
-        q.put((store.grad_dict(), stats.numpy().copy(), bool(torch.equal(store.theta, theta0)), means))
+        q.put((store.grad_dict(), stats.numpy().copy(),
+               bool(torch.equal(store.theta, theta0)) and slots_ok and resynced, means))
     dist.barrier()
     dist.destroy_process_group()
 

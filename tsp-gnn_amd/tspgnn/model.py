@@ -30,6 +30,7 @@ from .mlp import Mlp
 LEARNING_RATE = 2e-5          # model.py:13
 L2NORM_SCALING = 1e-10        # model.py:14
 GLOBAL_NORM_CLIP = 0.65       # model.py:15
+STAT_FETCHES = ("loss", "acc", "TP", "FP", "TN", "FN")
 
 
 class Placeholder(object):
@@ -185,6 +186,7 @@ class Session(object):
         self._adam = None
         self.process_group = process_group
         self._replicas_synced = False
+        self._synced_assignments = -1
 
     @property
     def world_size(self):
@@ -268,12 +270,15 @@ class Session(object):
         b.seg = torch.from_numpy(np.concatenate([[0], np.cumsum(n_edges)]).astype(np.int32)).to(self.device)
         return b
 
-    def forward(self, feed):
-        """Runs model.py:33-157 on the device; returns a dict of device tensors.  In a data-parallel session the
-        statistics are reduced over the ranks (8 floats, one all-reduce); ``forward_device`` stays rank-local."""
+    def forward(self, feed, global_stats=False):
+        """Runs model.py:33-157 on the device; returns a dict of device tensors.  Rank-local by default, like the
+        reference's inference path (no cross-process coupling: ranks may evaluate different numbers of batches, as
+        binary_search.get_cost does).  ``global_stats=True`` is a COLLECTIVE call: every rank of a data-parallel
+        session must make it, and loss / acc / TP / FP / TN / FN become those of the global batch (8 floats, one
+        all-reduce)."""
         b = feed if isinstance(feed, DeviceBatch) else self.prepare(feed)
         out = self.forward_device(b)
-        if self.world_size > 1:
+        if global_stats and self.world_size > 1:
             self._reduce_stats_only(out["stats"], b.B)
         return out
 
@@ -344,7 +349,9 @@ class Session(object):
             if "train_step" in names:
                 out = self.train_step(feed_dict)
             else:
-                out = self.forward(feed_dict)
+                # a statistic of the batch is a statistic of the GLOBAL batch in a data-parallel session (collective:
+                # every rank fetches it, as run_batch does); predictions / last_states alone stay rank-local
+                out = self.forward(feed_dict, global_stats=any(n in STAT_FETCHES for n in names))
         results = []
         stats = None
         for f in flist:
@@ -488,22 +495,31 @@ class Session(object):
         return t.cpu().numpy()
 
     def broadcast_variables(self, src=0):
-        """Replicas start identical: theta (and the optimiser slots, if any) from rank ``src`` to every rank."""
+        """Replicas start identical: theta AND the optimiser slots (m, v, step counter) from rank ``src`` to every
+        rank.  Every rank issues the same four broadcasts whether or not it already holds optimiser state (a
+        checkpoint restored on rank 0 only creates the slots there), so the collective sequence never depends on
+        the rank."""
         if self.world_size == 1:
+            self._synced_assignments = self.store.assignments
             return
         import torch.distributed as dist
+        self._ensure_adam()
         group_src = src if self.process_group is None else dist.get_global_rank(self.process_group, src)
         dist.broadcast(self.store.theta, src=group_src, group=self.process_group)
-        if self._adam is not None:
-            for k in ("m", "v", "t"):
-                dist.broadcast(self._adam[k], src=group_src, group=self.process_group)
+        for k in ("m", "v", "t"):
+            dist.broadcast(self._adam[k], src=group_src, group=self.process_group)
+        self._adam["step"] = int(self._adam["t"].item())   # host mirror (save_weights' beta powers)
         self.store.touch()
         self._replicas_synced = True
+        self._synced_assignments = self.store.assignments
 
     def _sync_replicas_once(self):
-        if not self._replicas_synced:
+        """Broadcast before the first training step and again after every outside assignment of the variables
+        (initialiser, load_weights / store.load) -- those happen on every rank or on rank 0 only, and either way the
+        replicas must leave this call identical.  Collective when it fires: assignments must be made (or not made)
+        at the same points of the program on every rank, like the training steps themselves."""
+        if not self._replicas_synced or self._synced_assignments != self.store.assignments:
             self.broadcast_variables(0)
-            self._replicas_synced = True
 
     def apply_gradients(self):
         """g += 1e-10*theta; clip_by_global_norm(0.65); Adam(lr=2e-5) -- one fused pass over theta."""

@@ -46,6 +46,8 @@ class VariableStore(object):
         self.theta = None
         self.device = None
         self.version = 0      # bumped whenever theta changes; keys the packed-weight cache
+        self.assignments = 0  # bumped when theta is ASSIGNED from outside (initialise / restore): a data-parallel
+                              # Session re-broadcasts from rank 0 before its next training step
         self._packed = {}
         self.grad = None      # flat gradient buffer, same layout as theta (allocated on first use)
 
@@ -95,6 +97,7 @@ class VariableStore(object):
             off, n = self._offsets[name]
             host[off:off + n] = init(shape, gen).reshape(-1).to(torch.float32)
         self.theta.copy_(host)
+        self.assignments += 1
         self.touch()
 
     def touch(self):
@@ -178,6 +181,7 @@ class VariableStore(object):
                 raise ValueError("shape mismatch for %s: expected %s" % (name, self._decl[name][0]))
             host[off:off + n] = torch.from_numpy(arr.copy())
         self.theta.copy_(host)
+        self.assignments += 1
         self.touch()
 
     def state_dict(self):
