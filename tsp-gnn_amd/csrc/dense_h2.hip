@@ -30,7 +30,61 @@
 #include "h2_tile.h"
 #include "mfma_tile.h"
 
+#ifndef H2_PIPE
+#define H2_PIPE 0   // 1: the edge task software-pipelined across tiles (measured slower; kept for A/B builds)
+#endif
+
+#ifndef H2_NT_STATE
+#define H2_NT_STATE 0   // A/B: non-temporal stores for the states h', c' of the edge task
+#endif
+#ifndef H2_NT_MSG
+#define H2_NT_MSG 0     // A/B: non-temporal stores for the messages
+#endif
+#ifndef H2_PIPE_C
+#define H2_PIPE_C 0     // A/B (pipelined loop): the row of c prefetched with h behind the previous tile's MLP
+#endif
+#ifndef H2_NT_LOADS
+#define H2_NT_LOADS 0   // A/B: the streamed state rows (h, c: read once) loaded non-temporally, so that they do not displace
+#endif                  // the projected-message rows the gathers re-read from the CU's 32 KB L1
+#ifndef H2_TRACE
+#define H2_TRACE 0   // development builds: per-phase cycle sums of the edge task's tile loop (tools/h2_trace.py)
+#endif
+
 namespace tspgnn {
+
+template <bool NT>
+__device__ __forceinline__ f32x4 ld4x(const float* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    else return ld4(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st4x(float* p, f32x4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+    else st4(p, v);
+}
+
+#if H2_TRACE
+__device__ unsigned long long h2_trace_buf[16 * 8];   // [wavefront][phase] of workgroup H2_TRACE_BLOCK, summed over its tiles
+#ifndef H2_TRACE_BLOCK
+#define H2_TRACE_BLOCK 8
+#endif
+#define TR_DECL unsigned long long tr_prev = __builtin_readcyclecounter(), tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TR(i)                                                        \
+    do {                                                             \
+        const unsigned long long tr_now = __builtin_readcyclecounter(); \
+        tr_acc[i] += tr_now - tr_prev;                               \
+        tr_prev = tr_now;                                            \
+    } while (0)
+#define TR_FLUSH                                                                                  \
+    do {                                                                                          \
+        if (blockIdx.x == H2_TRACE_BLOCK && lane == 0)                                            \
+            for (int i = 0; i < 8; ++i) h2_trace_buf[wave * 8 + i] += tr_acc[i];                   \
+    } while (0)
+#else
+#define TR_DECL
+#define TR(i)
+#define TR_FLUSH
+#endif
 
 // Packed weights of a [krows, ncols] matrix: P[piece][kb][g][t][jl][8] (fp16), piece 0 = hi, 1 = lo of 2^s * W,
 //   value = piece(2^s * W[16*(2kb + (j>>2)) + 4g + (j&3)][t*16 + jl]),   KB = krows/32, NT = ncols/16.
@@ -191,6 +245,55 @@ __global__ __launch_bounds__(1024) void mlp_fwd_h2_kernel(const MlpTaskTableH2 t
     }
 }
 
+// The cell arithmetic of mfma_tile.h's lstm_gates<D, true, SWAP> in two stages, one per gate pair, so that a tile's z
+// can be formed -- and normalised -- as (i, j) first and (f, o) second with half the accumulator registers live at a
+// time.  Same operations on the same values in the same order per element: bit-identical to the one-stage form.
+template <int D>
+__device__ __forceinline__ void lstm_gates_ij(f32x4 (&acc)[D / 8], const float* lds_ln, int g, f32x4 (&si)[D / 16],
+                                              f32x4 (&rj)[D / 16], float eps_z) {
+    constexpr int TPG = D / 16;
+    f32x4 gi[TPG], gj[TPG];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        gi[t] = acc[t];
+        gj[t] = acc[TPG + t];
+    }
+    ln_gate<TPG, H2_LN_SWAP != 0>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D, eps_z);
+    ln_gate<TPG, H2_LN_SWAP != 0>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D, eps_z);
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        si[t].lo = sigmoid2_pre(gi[t].lo);
+        si[t].hi = sigmoid2_pre(gi[t].hi);
+        rj[t].lo = relu2(gj[t].lo);
+        rj[t].hi = relu2(gj[t].hi);
+    }
+}
+template <int D>
+__device__ __forceinline__ void lstm_gates_fo(f32x4 (&acc)[D / 8], f32x4 (&cf)[D / 16], const f32x4 (&si)[D / 16],
+                                              const f32x4 (&rj)[D / 16], const float* lds_ln, int g, f32x4 (&hn)[D / 16],
+                                              f32x4 (&nc)[D / 16], float eps_z) {
+    constexpr int TPG = D / 16;
+    f32x4 gf[TPG], go[TPG];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        gf[t] = acc[t];
+        go[t] = acc[TPG + t];
+    }
+    ln_gate<TPG, H2_LN_SWAP != 0>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D, eps_z);
+    ln_gate<TPG, H2_LN_SWAP != 0>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D, eps_z);
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        nc[t].lo = fma2(si[t].lo, rj[t].lo, cf[t].lo * sigmoid2_pre(gf[t].lo));
+        nc[t].hi = fma2(si[t].hi, rj[t].hi, cf[t].hi * sigmoid2_pre(gf[t].hi));
+    }
+    ln_gate<TPG, H2_LN_SWAP != 0>(nc, lds_ln + 8 * D, lds_ln + 9 * D, g, D);
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        hn[t].lo = relu2(nc[t].lo) * sigmoid2_pre(go[t].lo);
+        hn[t].hi = relu2(nc[t].hi) * sigmoid2_pre(go[t].hi);
+    }
+}
+
 // ---------------------------------------------------------------------------------- LN-LSTM (+ MLP) (f16x2)
 // z = 2^s ([x|h] K (+ gather-init / bias-init)), five LayerNorms and the gate arithmetic of dense.hip's cell --
 // optionally followed, on the same 16 rows while h' is still in registers, by the message MLP that consumes h' in the
@@ -302,7 +405,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         const float* hrow = h + h2_state_row<D>(rc, g, in_blk);
         for (int kb = kb0; kb < kb1; ++kb) {
             const float* src = kb < KBX ? xrow + kb * 32 : hrow + (kb - KBX) * 2 * in_ts;
-            const f32x4 lo4 = ld4(src), hi4 = ld4(src + (kb < KBX ? 16 : in_ts));
+            const f32x4 lo4 = ld4x<H2_NT_LOADS != 0>(src), hi4 = ld4x<H2_NT_LOADS != 0>(src + (kb < KBX ? 16 : in_ts));
             float xv[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
             f16x8 bh, bl;
             split2(xv, bh, bl);
@@ -318,8 +421,8 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
             float* cd = c_out + h2_state_row<D>(rc, g, out_blk);
 #pragma unroll
             for (int t = 0; t < TPG; ++t) {
-                st4(hd + t * out_ts, hn[t]);
-                st4(cd + t * out_ts, nc[t]);
+                st4x<H2_NT_STATE != 0>(hd + t * out_ts, hn[t]);
+                st4x<H2_NT_STATE != 0>(cd + t * out_ts, nc[t]);
             }
         }
     };
@@ -335,11 +438,210 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         if (tid == 0) *ticket = t_beg;
         h2_stage_wait();
         __syncthreads();
+#if H2_PIPE
+        if (uv != nullptr && dx == 0) {
+            // Gather-init (edge) tiles, software-pipelined ACROSS tiles.  A tile used to open with a chain of dependent
+            // round trips -- ticket -> endpoints -> projected-message gathers -> state rows -- during which the
+            // wavefront was parked (two fifths of all wave cycles, profiles/r03a_c2_forward_pmc_mfma_baseline.txt), and
+            // three wavefronts per SIMD do not cover it.  Here z is formed in gate pairs, (i, j) then (f, o): with half
+            // the accumulators live, the registers that fall free behind the gate arithmetic take the NEXT tile's loads
+            // -- its endpoints during the second GEMM half, its (i, j) gathers and h rows during the message MLP -- and
+            // the (f, o) gathers and the row of c of the current tile fly behind its first GEMM half.  A tile therefore
+            // starts with its operands in registers.  Arithmetic and summation order per element are unchanged.
+            constexpr int HN = NT4 / 2;
+            auto take = [&]() {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(ticket, 1);
+                return __builtin_amdgcn_readfirstlane(t);
+            };
+            int tile = take();
+            f32x4 zu[HN], zv[HN], hr[TPG];
+#if H2_PIPE_C
+            f32x4 cr[TPG];
+#endif
+            int2 ends;
+            {
+                const int l = opaque_lane();
+                rl = l & 15;
+                g = l >> 4;
+                const unsigned rc0 = (unsigned)min(tile * 16 + rl, rows - 1);
+                ends = uv[rc0];
+                const float* pu = Zx + h2_zx_row<D>((unsigned)ends.x, g);
+                const float* pv = Zx + h2_zx_row<D>((unsigned)ends.y, g);
+                const float* ph = h + h2_state_row<D>(rc0, g, in_blk);
+#pragma unroll
+                for (int t = 0; t < HN; ++t) zu[t] = ld4(pu + t * 256);
+#pragma unroll
+                for (int t = 0; t < HN; ++t) zv[t] = ld4(pv + t * 256);
+#pragma unroll
+                for (int t = 0; t < TPG; ++t) hr[t] = ld4(ph + t * in_ts);
+#if H2_PIPE_C
+#pragma unroll
+                for (int t = 0; t < TPG; ++t)
+                    cr[t] = c != nullptr ? ld4(c + h2_state_row<D>(rc0, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+            }
+            TR_DECL;
+            while (tile < t_end) {
+                TR(0);
+                {
+                    const int l = opaque_lane();
+                    rl = l & 15;
+                    g = l >> 4;
+                }
+                const int row = tile * 16 + rl;
+                const bool valid = row < rows;
+                const unsigned rc = (unsigned)(valid ? row : rows - 1);
+                f32x4 hn[TPG];
+                int tile_next;
+                int2 ends_next;
+                unsigned rc_next;
+                const float *pu_n, *pv_n, *ph_n;
+                {
+                    f32x4 si[TPG], rj[TPG], cf[TPG];
+                    f16x8 bh[KBH], bl[KBH];
+                    {
+                        f32x4 acc[HN];
+#pragma unroll
+                        for (int t = 0; t < HN; ++t) acc[t] = zu[t] + zv[t];
+#pragma unroll
+                        for (int kb = 0; kb < KBH; ++kb) {
+                            float xv[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) xv[j] = hr[2 * kb + (j >> 2)][j & 3];
+                            split2(xv, bh[kb], bl[kb]);
+                        }
+                        // (pinned: the sums and the split free the registers the loads below land in; an empty asm makes each
+                        // value opaque at this point, so neither the optimiser nor the scheduler can sink the arithmetic below
+                        // the loads or hoist the loads above it)
+#pragma unroll
+                        for (int t = 0; t < HN; ++t) asm volatile("" : "+v"(acc[t]));
+#pragma unroll
+                        for (int kb = 0; kb < KBH; ++kb) asm volatile("" : "+v"(bh[kb]), "+v"(bl[kb])::"memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        TR(1);
+                        // second gate pair's gathers and the row of c: in flight behind the first GEMM half
+                        const float* pu = Zx + h2_zx_row<D>((unsigned)ends.x, g) + HN * 256;
+                        const float* pv = Zx + h2_zx_row<D>((unsigned)ends.y, g) + HN * 256;
+#pragma unroll
+                        for (int t = 0; t < HN; ++t) zu[t] = ld4(pu + t * 256);
+#pragma unroll
+                        for (int t = 0; t < HN; ++t) zv[t] = ld4(pv + t * 256);
+#if H2_PIPE_C
+#pragma unroll
+                        for (int t = 0; t < TPG; ++t) cf[t] = cr[t];
+#else
+                        if (c != nullptr) {
+                            const float* pc = c + h2_state_row<D>(rc, g, in_blk);
+#pragma unroll
+                            for (int t = 0; t < TPG; ++t) cf[t] = ld4(pc + t * in_ts);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < TPG; ++t) cf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+#endif
+                        tile_next = take();
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int kb = 0; kb < KBH; ++kb)
+                            kblock_h2_part<NT4, 0, HN>(acc, lds_w, lds_w + chunk_total, kb, g, rl, bh[kb], bl[kb]);
+                        lstm_gates_ij<D>(acc, lds_ln, g, si, rj, kH2GateEps);
+                    }
+                    rc_next = (unsigned)min(tile_next * 16 + rl, rows - 1);   // (clamped: in bounds past the last tile too)
+                    ends_next = uv[rc_next];
+                    // (the sums below wait for the gathers: pinned behind the first pair's work -- instruction selection would
+                    // otherwise place them, and their wait, at the top of the first GEMM half)
+                    __builtin_amdgcn_sched_barrier(0);
+#if H2_TRACE
+#pragma unroll
+                    for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(si[t]), "+v"(rj[t]));
+                    TR(2);
+#endif
+#pragma unroll
+                    for (int t = 0; t < HN; ++t) asm volatile("" : "+v"(zu[t]), "+v"(zv[t]));
+                    TR(3);
+                    {
+                        f32x4 acc[HN], nc[TPG];
+#pragma unroll
+                        for (int t = 0; t < HN; ++t) acc[t] = zu[t] + zv[t];
+#pragma unroll
+                        for (int kb = 0; kb < KBH; ++kb)
+                            kblock_h2_part<NT4, HN, HN>(acc, lds_w, lds_w + chunk_total, kb, g, rl, bh[kb], bl[kb]);
+                        lstm_gates_fo<D>(acc, cf, si, rj, lds_ln, g, hn, nc, kH2GateEps);
+                        // (the next tile's addresses are formed BEFORE the stores: behind the conditional stores the wait for
+                        // the endpoints would be a wait for every outstanding store as well)
+                        pu_n = Zx + h2_zx_row<D>((unsigned)ends_next.x, g);
+                        pv_n = Zx + h2_zx_row<D>((unsigned)ends_next.y, g);
+                        ph_n = h + h2_state_row<D>(rc_next, g, in_blk);
+                        asm volatile("" : "+v"(pu_n), "+v"(pv_n), "+v"(ph_n));
+                        if (valid) {
+                            float* hd = h_out + h2_state_row<D>(rc, g, out_blk);
+                            float* cd = c_out + h2_state_row<D>(rc, g, out_blk);
+#pragma unroll
+                            for (int t = 0; t < TPG; ++t) {
+                                st4x<H2_NT_STATE != 0>(hd + t * out_ts, hn[t]);
+                                st4x<H2_NT_STATE != 0>(cd + t * out_ts, nc[t]);
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#if H2_TRACE
+#pragma unroll
+                for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(hn[t]));
+                TR(4);
+#endif
+                {   // the next tile's first gate pair and h rows: in flight behind the message MLP
+#pragma unroll
+                    for (int t = 0; t < HN; ++t) zu[t] = ld4(pu_n + t * 256);
+#pragma unroll
+                    for (int t = 0; t < HN; ++t) zv[t] = ld4(pv_n + t * 256);
+#pragma unroll
+                    for (int t = 0; t < TPG; ++t) hr[t] = ld4(ph_n + t * in_ts);
+#if H2_PIPE_C
+                    if (c != nullptr) {
+                        const float* pc = c + h2_state_row<D>(rc_next, g, in_blk);
+#pragma unroll
+                        for (int t = 0; t < TPG; ++t) cr[t] = ld4(pc + t * in_ts);
+                    }
+#endif
+                }
+                if (n_layers > 0) {
+                    for (int l = 0; l < n_layers; ++l) {
+                        const _Float16* wh = reinterpret_cast<const _Float16*>(lds_mlp + (size_t)l * LAYER_BYTES);
+                        const float* bias = reinterpret_cast<const float*>(lds_mlp + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
+                        dense_layer_h2<D>(hn, wh, wh + D * D, bias, (relu_mask >> l) & 1u, g, rl);
+                        if (mlp_acts != nullptr && l < n_layers - 1 && valid) {
+                            float* dst = mlp_acts + ((size_t)l * acts_stride + (size_t)rc * D + g * 4);
+#pragma unroll
+                            for (int t = 0; t < TPG; ++t) st4(dst + t * 16, hn[t]);
+                        }
+                    }
+                    if (valid && mlp_out != nullptr) {
+#pragma unroll
+                        for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                    }
+                }
+                tile = tile_next;
+                ends = ends_next;
+#if H2_TRACE
+#pragma unroll
+                for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(hn[t]));
+                TR(5);
+                tr_acc[7] += 1;
+#endif
+            }
+            TR_FLUSH;
+        } else
+#endif
+        {
+        TR_DECL;
         for (;;) {
             int tile = 0;
             if (lane == 0) tile = atomicAdd(ticket, 1);
             tile = __builtin_amdgcn_readfirstlane(tile);
             if (tile >= t_end) break;
+            TR(0);
             {   // the lane's coordinates in the tile, recomputed (two VALU instructions) instead of kept: as loop invariants
                 // they and what is derived from them were SPILLED to scratch, a reload on every tile's critical path
                 const int l = opaque_lane();
@@ -353,11 +655,26 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
             {
                 f32x4 acc[NT4], cf[TPG];
                 init_acc(acc, rc);
+#if H2_TRACE
+#pragma unroll
+                for (int t = 0; t < NT4; ++t) asm volatile("" : "+v"(acc[t]));
+                TR(1);
+#endif
 #pragma unroll
                 for (int t = 0; t < TPG; ++t)
-                    cf[t] = c != nullptr ? ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    cf[t] = c != nullptr ? ld4x<H2_NT_LOADS != 0>(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
                 kloop(acc, rc, 0, 0, KBT);
+#if H2_TRACE
+#pragma unroll
+                for (int t = 0; t < NT4; ++t) asm volatile("" : "+v"(acc[t]));
+                TR(2);
+#endif
                 cell(acc, cf, rc, valid, hn);
+#if H2_TRACE
+#pragma unroll
+                for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(hn[t]));
+                TR(3);
+#endif
             }
             if (n_layers > 0) {
                 for (int l = 0; l < n_layers; ++l) {
@@ -372,9 +689,17 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 }
                 if (valid && mlp_out != nullptr) {
 #pragma unroll
-                    for (int t = 0; t < TPG; ++t) st4(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                    for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
             }
+#if H2_TRACE
+#pragma unroll
+            for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(hn[t]));
+            TR(4);
+            tr_acc[7] += 1;
+#endif
+        }
+        TR_FLUSH;
         }
     } else {
         // lock-step rounds: one tile per wavefront; K (whole or chunk by chunk), then the MLP + the projection
@@ -464,7 +789,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 }
                 if (valid && mlp_out != nullptr) {
 #pragma unroll
-                    for (int t = 0; t < TPG; ++t) st4(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                    for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
                 if (proj_w != nullptr) {  // proj_out = 2^s mlp(h') P, P packed [D, 4D]
                     if (!together) {
@@ -669,6 +994,13 @@ static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
 using namespace tspgnn;
 
 extern "C" float tspgnn_h2_weight_scale(void) { return kH2Scale; }
+
+#if H2_TRACE
+extern "C" int tspgnn_debug_h2_trace(unsigned long long* host_dst) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(tspgnn::h2_trace_buf), sizeof(unsigned long long) * 16 * 8, 0,
+                                    hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int tspgnn_pack_weights_h2(const float* W, void* P, int krows, int ncols, void* stream) {
     TSPGNN_REQUIRE(krows >= 0 && krows % 32 == 0, "pack_weights_h2: krows=%d must be a multiple of 32", krows);

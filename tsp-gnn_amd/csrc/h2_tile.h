@@ -102,6 +102,34 @@ __device__ __forceinline__ void kblock_h2(f32x4 (&acc)[NT], const _Float16* wh, 
     }
 }
 
+// The same for the TN output tiles T0 .. T0+TN-1 of a matrix with NTOT output tiles (a gate pair of the cell's z):
+// per accumulator the same MFMA sequence as kblock_h2<NTOT>, so a GEMM done in column halves is bit-identical.
+template <int NTOT, int T0, int TN>
+__device__ __forceinline__ void kblock_h2_part(f32x4 (&acc)[TN], const _Float16* wh, const _Float16* wl, int kb, int g, int jl,
+                                               const f16x8& bh, const f16x8& bl) {
+    const int off = ((kb * 4 + g) * NTOT * 16 + jl) * 8 + T0 * 128;
+    constexpr int PF = H2_PF < TN ? H2_PF : TN;
+    f16x8 ah[PF + 1], al[PF + 1];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        ah[p] = ldw(wh + off + p * 128);
+        al[p] = ldw(wl + off + p * 128);
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        if (t + PF < TN) {
+            ah[(t + PF) % (PF + 1)] = ldw(wh + off + (t + PF) * 128);
+            al[(t + PF) % (PF + 1)] = ldw(wl + off + (t + PF) * 128);
+        }
+        const f16x8 a_h = ah[t % (PF + 1)], a_l = al[t % (PF + 1)];
+        f32x4 c = acc[t];
+        c = MFMA_F16(a_l, bh, c);
+        c = MFMA_F16(a_h, bl, c);
+        c = MFMA_F16(a_h, bh, c);
+        acc[t] = c;
+    }
+}
+
 // bytes -> LDS, 16 bytes per lane, straight from global memory (global_load_lds_dwordx4); the LDS address of a lane is
 // the wavefront's base + lane*16.  Callers follow up with h2_stage_wait() + a barrier.
 __device__ __forceinline__ void h2_copy_to_lds(void* dst, const void* __restrict__ src, int nbytes, int tid, int nthreads) {
