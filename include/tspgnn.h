@@ -32,7 +32,7 @@ extern "C" {
 #define TSPGNN_EINVAL (-1)      /* bad argument (null pointer, negative size, unsupported d) */
 #define TSPGNN_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
 
-#define TSPGNN_ABI_VERSION 1
+#define TSPGNN_ABI_VERSION 2   /* 2: range_flag in the task structures, pack_weights_h2 / adam_clip_step arguments */
 
 /* ABI version of the loaded library (== TSPGNN_ABI_VERSION of the header it was built from). */
 int tspgnn_version(void);
@@ -132,6 +132,8 @@ typedef struct tspgnn_mlp_task {
     const float* X; const float* wb; float* Y; float* acts; long long acts_stride;
     int rows; int n_layers; unsigned relu_mask;
     const float* proj_w; float* proj_out;  /* optional: proj_out[rows,4d] = Y * P, proj_w = pack_weights(P[d,4d]) */
+    unsigned* range_flag;  /* _h2 entry points only (optional, others ignore it): device word, |= 1 when an activation
+                              left the fp16 range of the f16x2 split (see tspgnn_pack_weights_h2) */
 } tspgnn_mlp_task;   /* fields as the arguments of tspgnn_mlp_fwd_f32 */
 
 typedef struct tspgnn_lstm_task {
@@ -140,6 +142,7 @@ typedef struct tspgnn_lstm_task {
     const int32_t* uv; const float* Zx;   /* gather-init mode when uv != NULL: dx == 0, K = Kh */
     const float* zbias; const float* zscale; /* optional: z starts at zscale[row] * zbias[4d] (a bias folded
                                                 through a row-sum aggregation: degree * (b Kx)) */
+    unsigned* range_flag;                    /* as tspgnn_mlp_task.range_flag */
 } tspgnn_lstm_task;  /* fields as the arguments of tspgnn_lnlstm_fwd_f32 / tspgnn_lnlstm_gather_fwd_f32 */
 
 int tspgnn_mlp_fwd_multi_f32(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream);
@@ -190,8 +193,14 @@ int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_task
  * csrc/dense_h2.hip) -- half the matrix instructions and less than half the split arithmetic of bf16x3; the
  * default arithmetic of the inference forward.  d in {32, 64}.  Operands as for the _x3 functions, except:
  *   tspgnn_pack_weights_h2: W:[krows,ncols] -> P: 2*krows*ncols fp16, piece-major, the pieces of 2^s * W with
- *     s = TSPGNN_H2_WEIGHT_SCALE_LOG2 (keeps the lo piece of a typical weight out of the fp16 subnormals;
- *     |W| < 2^10 required);
+ *     s = TSPGNN_H2_WEIGHT_SCALE_LOG2 (keeps the lo piece of a typical weight out of the fp16 subnormals).
+ *     RANGE: the hi piece is an fp16, so 2^s |W| must stay below 65504 (|W| < 1023.5) -- fp32, the reference's type
+ *     (graphnn.py:18), has no such limit.  absmax_bits (optional device word, caller-zeroed): atomically raised to
+ *     the IEEE bit pattern of max |2^s W| over the matrix (0x7f800000 or above: a non-finite entry).  A caller
+ *     that gets >= the bits of 65504.0f (0x477fe000) must run that network on the _x3 / _f32 entry points, which
+ *     have fp32's range.  Activations: an operand row of a GEMM (h, a message MLP's hidden activation, an aggregate)
+ *     with an entry >= 65504 in magnitude overflows the same way; the kernels detect it where they split the operand
+ *     and set bit 0 of the task's range_flag (then the launch's outputs are not to be used: re-run on _x3 / _f32);
  *   mlp task:  wb = n_layers blocks of { packed[2*d*d] fp16, 2^s * bias[d] float }; Y comes back unscaled;
  *              proj_out = the PROJECTED-MESSAGE FORMAT of this family: 2^s * (Y P), blocked by 16 source rows -- the
  *              float4 (columns 16t + 4g .. 4g+3) of row v at float offset (((v/16) * d/4 + t) * 4 + g) * 64 + (v%16) * 4;
@@ -205,7 +214,7 @@ int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_task
  */
 #define TSPGNN_H2_WEIGHT_SCALE_LOG2 6
 float tspgnn_h2_weight_scale(void);   /* 2^TSPGNN_H2_WEIGHT_SCALE_LOG2 */
-int tspgnn_pack_weights_h2(const float* W, void* P, int krows, int ncols, void* stream);
+int tspgnn_pack_weights_h2(const float* W, void* P, int krows, int ncols, unsigned* absmax_bits, void* stream);
 int tspgnn_mlp_fwd_multi_h2(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream);
 int tspgnn_lnlstm_fwd_multi_h2(const tspgnn_lstm_task* tasks, int n_tasks, int d, void* stream);
 int tspgnn_lnlstm_mlp_fwd_multi_h2(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream);
@@ -413,10 +422,15 @@ long long tspgnn_adam_workspace_floats(void);
  * step_counter != NULL (device int): the counter is incremented to t and lr_t is the BASE rate, corrected on
  * the device -- no host value changes between steps, so the whole training step can be replayed as a HIP graph.
  * In data-parallel training g is the all-reduced (averaged) gradient.
+ * skip_flag (optional device word): when non-zero at execution time the step is NOT applied -- theta, m, v and the
+ * step counter stay as they are, gnorm_out is still written.  It is the range_flag of the step's f16x2 launches: a
+ * gradient computed from an overflowed forward never reaches the variables, the caller repeats the step on the
+ * _x3 / _f32 entry points.
  */
 int tspgnn_adam_clip_step_f32(float* theta, float* g, float* m, float* v, int n, float l2_scale,
                               float clip_norm, float lr_t, float beta1, float beta2, float eps,
-                              float* gnorm_out, float* workspace, int* step_counter, void* stream);
+                              float* gnorm_out, float* workspace, int* step_counter, const unsigned* skip_flag,
+                              void* stream);
 
 /* ------------------------------------------------------------------ host-side batch packing (no GPU work) */
 

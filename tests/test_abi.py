@@ -35,8 +35,39 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert name in decl, "%s bound but not declared in tspgnn.h" % name
 
 
+def test_abi_version_and_struct_layouts_agree(tmp_path):
+    """Header, library and ctypes binding carry the same ABI version, and every task structure has the same size and
+    field offsets in C (gcc on include/tspgnn.h) and in the binding -- a layout change without a version bump would
+    hand the kernels garbage pointers."""
+    import subprocess
+    hv = int(re.search(r"#define\s+TSPGNN_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert hv == _lib.ABI_VERSION == _lib.lib.tspgnn_version()
+    pairs = {"tspgnn_mlp_task": _lib.MlpTask, "tspgnn_lstm_task": _lib.LstmTask, "tspgnn_cell_mlp_task": _lib.CellMlpTask,
+             "tspgnn_mlp_task_bf16": _lib.MlpTaskB, "tspgnn_lstm_task_bf16": _lib.LstmTaskB,
+             "tspgnn_lstm_bwd_task": _lib.LstmBwdTask, "tspgnn_mlp_bwd_task": _lib.MlpBwdTask}
+    src = ["#include <stdio.h>", "#include <stddef.h>", '#include "tspgnn.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        src.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            if fname == "cell":
+                continue
+            src.append('printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
+        src.append('printf("\\n");')
+    src += ["return 0; }"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.dirname(HEADER), str(c), "-o", str(exe)])
+    lines = subprocess.check_output([str(exe)]).decode().strip().splitlines()
+    for line in lines:
+        parts = line.split()
+        cls = pairs[parts[0]]
+        want = [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_ if f != "cell"]
+        assert [int(x) for x in parts[1:]] == want, parts[0]
+
+
 def test_version_and_error_string():
-    assert _lib.lib.tspgnn_version() == 1
+    assert _lib.lib.tspgnn_version() == _lib.ABI_VERSION == 2
     status = _lib.lib.tspgnn_gather2_sum_f32(None, None, None, 4, 4, 3, None)   # d=3: rejected before launch
     assert status == -1
     assert b"multiple of 4" in _lib.lib.tspgnn_last_error()

@@ -159,7 +159,7 @@ def packed_h2(W, device):
     src = dev(W, device)
     out = torch.empty(4 * W.size, dtype=torch.uint8, device=device)
     _KEEP.append(out)
-    _lib.call("tspgnn_pack_weights_h2", _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], None)
+    _lib.call("tspgnn_pack_weights_h2", _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], None, None)
     return out
 
 
@@ -369,7 +369,7 @@ def test_adam_clip_step(cuda_device):
     td, gd, md, vd = (dev(a, cuda_device) for a in (theta, g, m, v))
     gn = empty((1,), cuda_device); wsz = ws("tspgnn_adam_workspace_floats", device=cuda_device)
     _lib.call("tspgnn_adam_clip_step_f32", _lib.ptr(td), _lib.ptr(gd), _lib.ptr(md), _lib.ptr(vd), n, TO.L2NORM_SCALING, TO.CLIP_NORM,
-              float(lr_t), TO.ADAM_B1, TO.ADAM_B2, TO.ADAM_EPS, _lib.ptr(gn), _lib.ptr(wsz), None, None)
+              float(lr_t), TO.ADAM_B1, TO.ADAM_B2, TO.ADAM_EPS, _lib.ptr(gn), _lib.ptr(wsz), None, None, None)
     torch.cuda.synchronize()
     g64 = g.astype(np.float64) + TO.L2NORM_SCALING * theta
     clipped, gnorm = TO.clip_by_global_norm({"a": g64})
@@ -381,7 +381,7 @@ def test_adam_clip_step(cuda_device):
     td2, gd2, md2, vd2 = (dev(a, cuda_device) for a in (theta, g, m, v))
     cnt = torch.full((1,), step - 1, dtype=torch.int32, device=cuda_device); _KEEP.append(cnt)
     _lib.call("tspgnn_adam_clip_step_f32", _lib.ptr(td2), _lib.ptr(gd2), _lib.ptr(md2), _lib.ptr(vd2), n, TO.L2NORM_SCALING, TO.CLIP_NORM,
-              TO.LEARNING_RATE, TO.ADAM_B1, TO.ADAM_B2, TO.ADAM_EPS, _lib.ptr(gn), _lib.ptr(wsz), _lib.ptr(cnt), None)
+              TO.LEARNING_RATE, TO.ADAM_B1, TO.ADAM_B2, TO.ADAM_EPS, _lib.ptr(gn), _lib.ptr(wsz), _lib.ptr(cnt), None, None)
     torch.cuda.synchronize()
     assert int(cnt.item()) == step
     assert np.abs(td2.cpu().numpy() - p["a"]).max() < 2e-6 * np.abs(p["a"]).max()
@@ -391,7 +391,7 @@ def test_adam_clip_step(cuda_device):
     small = (1e-3 * theta).astype(np.float32)
     td3, gd3, md3, vd3 = (dev(a, cuda_device) for a in (small, g, m, v))
     _lib.call("tspgnn_adam_clip_step_f32", _lib.ptr(td3), _lib.ptr(gd3), _lib.ptr(md3), _lib.ptr(vd3), n, TO.L2NORM_SCALING, TO.CLIP_NORM,
-              float(lr_t), TO.ADAM_B1, TO.ADAM_B2, TO.ADAM_EPS, _lib.ptr(gn), _lib.ptr(wsz), None, None)
+              float(lr_t), TO.ADAM_B1, TO.ADAM_B2, TO.ADAM_EPS, _lib.ptr(gn), _lib.ptr(wsz), None, None, None)
     torch.cuda.synchronize()
     g64 = g.astype(np.float64) + TO.L2NORM_SCALING * small
     clipped, _ = TO.clip_by_global_norm({"a": g64})
@@ -425,3 +425,27 @@ def test_mlp_backward_gather_init_equals_explicit_gather(cuda_device, d, rows, n
         torch.cuda.synchronize()
         outs.append((dpre.cpu().numpy(), dX.cpu().numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_adam_skip_flag_leaves_the_variables_alone(cuda_device):
+    """skip_flag != 0 (the f16x2 range flag of the step's forward, include/tspgnn.h): theta, m, v and the device step
+    counter stay bit for bit what they were, the global norm is still reported; flag == 0: the ordinary step."""
+    rng = np.random.RandomState(9)
+    n = 5000
+    theta = rng.randn(n).astype(np.float32); g = (0.01 * rng.randn(n)).astype(np.float32)
+    m = (0.001 * rng.randn(n)).astype(np.float32); v = (1e-4 * rng.rand(n)).astype(np.float32)
+    wsz = ws("tspgnn_adam_workspace_floats", device=cuda_device)
+    res = {}
+    for flagged in (1, 0):
+        td, gd, md, vd = (dev(a, cuda_device) for a in (theta, g, m, v))
+        gn = empty((1,), cuda_device)
+        cnt = torch.full((1,), 4, dtype=torch.int32, device=cuda_device); _KEEP.append(cnt)
+        flag = torch.full((1,), flagged, dtype=torch.int32, device=cuda_device); _KEEP.append(flag)
+        _lib.call("tspgnn_adam_clip_step_f32", _lib.ptr(td), _lib.ptr(gd), _lib.ptr(md), _lib.ptr(vd), n, TO.L2NORM_SCALING,
+                  TO.CLIP_NORM, TO.LEARNING_RATE, TO.ADAM_B1, TO.ADAM_B2, TO.ADAM_EPS, _lib.ptr(gn), _lib.ptr(wsz), _lib.ptr(cnt),
+                  _lib.ptr(flag), None)
+        torch.cuda.synchronize()
+        res[flagged] = (td.cpu().numpy(), md.cpu().numpy(), vd.cpu().numpy(), int(cnt.item()), float(gn.item()))
+    assert np.array_equal(res[1][0], theta) and np.array_equal(res[1][1], m) and np.array_equal(res[1][2], v) and res[1][3] == 4
+    assert res[0][3] == 5 and not np.array_equal(res[0][0], theta)
+    assert res[1][4] == res[0][4] > 0

@@ -60,7 +60,7 @@ def test_pack_weights_is_a_permutation(cuda_device):
 def test_library_is_loaded_in_tree():
     import os
     assert os.path.samefile(os.path.dirname(_lib.LIB_PATH), os.path.dirname(_lib.__file__))
-    assert _lib.lib.tspgnn_version() == 1
+    assert _lib.lib.tspgnn_version() == _lib.ABI_VERSION
 
 
 @pytest.mark.parametrize("d", [32, 64, 128, 20])

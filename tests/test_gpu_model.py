@@ -803,3 +803,103 @@ def test_edge_order_within_a_problem_is_free(cuda_device, gemm):
     assert rel_err(b["predictions"], a["predictions"]) < 2e-6
     assert rel_err(b["last_states"]["E"].h, a["last_states"]["E"].h[perm]) < 5e-6
     assert rel_err(b["last_states"]["V"].c, a["last_states"]["V"].c) < 5e-6
+
+
+# ---------------------------------------------------------------------------------------- f16x2 range guard
+# "No input that is finite in the reference's fp32 path is non-finite here": the default arithmetic (fp16 pieces) has a
+# narrower range than the reference's float32 (graphnn.py:18, model.py:18-27); weights are vetted when packed, activations
+# where the kernels split them, and the batch runs on bf16x3 (fp32's range) instead.
+
+def _oracle_batch(t):
+    return {"ev_uv": t[0].uv, "W": t[1], "C": t[2], "route_exists": t[3], "n_vertices": t[4], "n_edges": t[5]}
+
+
+@pytest.mark.parametrize("which", ["TSP/E_cell/layer_norm_basic_lstm_cell/kernel", "TSP/V_msg_E_MLP_layer_2/kernel",
+                                   "E_vote_MLP_layer_1/kernel"])
+def test_f16x2_falls_back_for_weights_beyond_the_fp16_range(cuda_device, which):
+    """One weight of 2000 (2^6 * 2000 overflows the fp16 hi piece): the packing's guard word vetoes f16x2 before a kernel
+    multiplies with it; predictions and states stay within 1e-5 of the float64 oracle."""
+    d, T = 64, 4
+    t = pack_tuple("ragged_B6", 1)
+    params = P.init_params(d, seed=21, perturb=True)
+    name = [k for k in params if k.endswith(which) or k == which]
+    assert len(name) == 1, (which, sorted(params))
+    params[name[0]] = params[name[0]].copy()
+    params[name[0]][5, 7] = 2000.0
+    model = tspgnn.build_network(d)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    EV, W, C, route_exists, n_vertices, n_edges = t
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    assert model["gnn"].active_arith() == "h2"
+    pred, last, loss = sess.run([model["predictions"], model["last_states"], model["loss"]], feed_dict=feed)
+    assert model["gnn"].active_arith() == "x3"          # latched for these variables ...
+    ref = TO.forward(TO.to_torch(params, torch.float64), _oracle_batch(t), T)
+    assert np.all(np.isfinite(pred)) and rel_err(pred, ref["predictions"].numpy()) < REL_TOL
+    assert rel_err(last["E"].h, ref["last_states"]["E"][0].numpy()) < REL_TOL
+    assert abs(float(loss) - ref["loss"].item()) < REL_TOL
+    model.store.load(P.init_params(d, seed=21, perturb=True))
+    assert model["gnn"].active_arith() == "h2"          # ... and f16x2 is back after the next assignment
+
+
+def test_f16x2_falls_back_for_activations_beyond_the_fp16_range(cuda_device):
+    """A batch whose pushed row-sum exceeds 65504: the E->V message MLP's last hidden layer gets a bias of 3000, so every
+    edge sends ~3000 per unit and a vertex of a 20-vertex graph sums 19 of them (57 000) -- in range --, of a ragged
+    batch's 40-vertex graph 39 (117 000) -- out of range.  run() notices the kernels' flag and repeats the batch on
+    bf16x3; the weights themselves stay eligible for f16x2 (the next batch tries it again)."""
+    d, T = 64, 3
+    params = P.init_params(d, seed=5, perturb=True)
+    key = [k for k in params if k.endswith("E_msg_V_MLP_layer_3/bias")]
+    assert len(key) == 1, sorted(params)
+    params[key[0]] = np.full_like(params[key[0]], 3000.0)
+    rng = np.random.RandomState(0)
+    small = tspgnn.synthetic_batch([20, 20], seed=3)
+    large = tspgnn.synthetic_batch([20, 40], seed=3)
+    model = tspgnn.build_network(d)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    for t, overflow in ((small, False), (large, True), (small, False)):
+        EV, W, C, route_exists, n_vertices, n_edges = t
+        feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+                model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+        # the unguarded forward: finite for the small batch, flagged for the large one
+        sess.forward_device(sess.prepare(feed))
+        assert sess.range_exceeded() == overflow
+        pred, last = sess.run([model["predictions"], model["last_states"]], feed_dict=feed)
+        ref = TO.forward(TO.to_torch(params, torch.float64), _oracle_batch(t), T)
+        assert np.all(np.isfinite(pred)) and np.all(np.isfinite(last["V"].c))
+        assert rel_err(pred, ref["predictions"].numpy()) < REL_TOL
+        assert rel_err(last["V"].h, ref["last_states"]["V"][0].numpy()) < REL_TOL
+        assert rel_err(last["E"].c, ref["last_states"]["E"][1].numpy()) < REL_TOL
+        assert model["gnn"].active_arith() == "h2" and not sess.range_exceeded()
+
+
+def test_training_step_survives_an_activation_overflow(cuda_device):
+    """sess.run(train_step) on the overflowing batch: the optimiser kernel skips the update of the flagged f16x2 attempt
+    on the device, the step is repeated on bf16x3 -- the variables end where a session restricted to bf16x3 puts them."""
+    d, T = 64, 2
+    params = P.init_params(d, seed=6, perturb=True)
+    key = [k for k in params if k.endswith("E_msg_V_MLP_layer_3/bias")][0]
+    params[key] = np.full_like(params[key], 3000.0)
+    t = tspgnn.synthetic_batch([20, 40], seed=4)
+    ends = {}
+    for gemm in ("f16x2", "bf16x3"):
+        model = tspgnn.build_network(d)
+        model["gnn"].gemm = gemm
+        sess = tspgnn.Session(model)
+        sess.run(tspgnn.global_variables_initializer())
+        model.store.load(params)
+        EV, W, C, route_exists, n_vertices, n_edges = t
+        feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+                model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+        for _ in range(2):
+            _, loss = sess.run([model["train_step"], model["loss"]], feed_dict=feed)
+            assert np.isfinite(loss)
+        assert int(sess._adam["t"].item()) == 2 and sess._adam["step"] == 2
+        ends[gemm] = model.store.state_dict()
+    for k in ends["bf16x3"]:
+        assert np.all(np.isfinite(ends["f16x2"][k])), k
+        assert np.array_equal(ends["f16x2"][k], ends["bf16x3"][k]), k

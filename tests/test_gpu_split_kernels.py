@@ -60,7 +60,10 @@ def packed(arith, W, device):
     src = dev(W, device)
     out = torch.empty(PIECES[arith] * W.size * 2, dtype=torch.uint8, device=device)
     _KEEP.append(out)
-    _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], None)
+    if arith == "h2":
+        _lib.call("tspgnn_pack_weights_h2", _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], None, None)
+    else:
+        _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(src), _lib.ptr(out), W.shape[0], W.shape[1], None)
     return out
 
 
@@ -320,3 +323,84 @@ def test_split_kernels_reject_unsupported_width(cuda_device, arith):
     t = _lib.MlpTask(None, None, None, None, 0, 0, 1, 0, None, None)
     with pytest.raises(_lib.TspgnnError):
         _lib.call_multi("tspgnn_mlp_fwd_multi_" + arith, [t], 128)
+
+
+# ---------------------------------------------------------------------------------------- f16x2 range guard
+# fp16 pieces overflow where the reference's fp32 (graphnn.py:18) does not: tspgnn_pack_weights_h2 reports max |2^s W|,
+# the forward kernels raise their task's range_flag when an operand they split reaches 65504 (include/tspgnn.h).
+
+def test_pack_h2_reports_the_largest_scaled_weight(cuda_device):
+    sc = zscale("h2")
+    rng = np.random.RandomState(5)
+    W = (0.3 * rng.randn(64, 256)).astype(np.float32)
+    W[17, 133] = -1500.0     # 2^6 * 1500 = 96000 > 65504: the hi piece is -inf
+    word = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    src = dev(W, cuda_device)
+    out = torch.empty(2 * W.size * 2, dtype=torch.uint8, device=cuda_device)
+    _lib.call("tspgnn_pack_weights_h2", _lib.ptr(src), _lib.ptr(out), 64, 256, _lib.ptr(word), None)
+    torch.cuda.synchronize()
+    assert np.int32(word.item()).view(np.float32) == np.float32(sc * 1500.0)
+    assert word.item() >= 0x477fe000                       # the bits of 65504.0f: out of range
+    # a second, in-range matrix only ever RAISES the word (atomic max), and a fresh word stays below the limit
+    W2 = (0.3 * rng.randn(32, 32)).astype(np.float32)
+    word2 = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    _lib.call("tspgnn_pack_weights_h2", _lib.ptr(dev(W2, cuda_device)), _lib.ptr(out), 32, 32, _lib.ptr(word2), None)
+    _lib.call("tspgnn_pack_weights_h2", _lib.ptr(dev(W2, cuda_device)), _lib.ptr(out), 32, 32, _lib.ptr(word), None)
+    torch.cuda.synchronize()
+    assert np.int32(word2.item()).view(np.float32) == np.float32(sc * np.abs(W2).max()) and word2.item() < 0x46ffe000
+    assert np.int32(word.item()).view(np.float32) == np.float32(sc * 1500.0)
+    Wn = W2.copy(); Wn[3, 3] = np.inf
+    _lib.call("tspgnn_pack_weights_h2", _lib.ptr(dev(Wn, cuda_device)), _lib.ptr(out), 32, 32, _lib.ptr(word2), None)
+    torch.cuda.synchronize()
+    assert word2.item() >= 0x7f800000                      # a non-finite weight sorts above everything
+
+
+@pytest.mark.parametrize("big,hit", [(65000.0, False), (65519.0, False), (65520.0, True), (-7.0e4, True), (3.0e38, True)])
+def test_mlp_h2_flags_an_operand_outside_the_fp16_range(cuda_device, big, hit):
+    """One activation of one row at / beyond the largest value whose hi piece is finite (65504 = fp16 max; 65520 rounds
+    to inf): the launch sets bit 0 of the task's range_flag -- and leaves it alone otherwise."""
+    d, rows, n_layers, mask = 64, 777, 3, 0b111
+    rng = np.random.RandomState(int(abs(big)) % 1000)
+    X = rng.randn(rows, d).astype(np.float32)
+    X[401, 13] = big
+    layers = [((rng.randn(d, d) / np.sqrt(d)).astype(np.float32), (0.1 * rng.randn(d)).astype(np.float32))
+              for _ in range(n_layers)]
+    wb = mlp_blocks("h2", layers, cuda_device)
+    Y = torch.empty((rows, d), dtype=torch.float32, device=cuda_device)
+    flag = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    task = _lib.MlpTask(_lib.ptr(dev(X, cuda_device)), _lib.ptr(wb), _lib.ptr(Y), None, 0, rows, n_layers, mask, None, None,
+                        _lib.ptr(flag))
+    _lib.call_multi("tspgnn_mlp_fwd_multi_h2", [task], d)
+    torch.cuda.synchronize()
+    assert bool(flag.item() & 1) == hit
+    if not hit:   # in range: fp32-class result on the row with the large entry as well
+        x = X.astype(np.float64)
+        for l, (W, b) in enumerate(layers):
+            x = NO.dense(x, W.astype(np.float64), b.astype(np.float64), bool((mask >> l) & 1))
+        assert rel_err(Y.cpu().numpy(), x) < 2e-6
+
+
+def test_cell_h2_flags_an_aggregate_outside_the_fp16_range(cuda_device):
+    """The vertex cell of the pushed form takes the row-SUM of up to n-1 relu activations as its GEMM operand: an entry
+    past 65504 must raise the flag (the cell's x operand), an h past it likewise."""
+    d, rows = 64, 100
+    rng = np.random.RandomState(3)
+    K = (rng.randn(2 * d, 4 * d) / np.sqrt(2 * d)).astype(np.float32)
+    ln = np.concatenate([np.ones(d), np.zeros(d)] * 5).astype(np.float32)
+    for where in ("x", "h", None):
+        x = np.abs(rng.randn(rows, d)).astype(np.float32) * 100
+        h = np.abs(rng.randn(rows, d)).astype(np.float32)
+        if where == "x":
+            x[57, 9] = 1.2e5
+        if where == "h":
+            h[3, 60] = 9.9e4
+        c = rng.randn(rows, d).astype(np.float32)
+        flag = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+        ho = torch.empty((rows, d), dtype=torch.float32, device=cuda_device)
+        co = torch.empty((rows, d), dtype=torch.float32, device=cuda_device)
+        task = _lib.LstmTask(_lib.ptr(dev(x, cuda_device)), d, _lib.ptr(dev(h, cuda_device)), _lib.ptr(dev(c, cuda_device)),
+                             _lib.ptr(packed("h2", K, cuda_device)), _lib.ptr(dev(ln, cuda_device)), _lib.ptr(ho), _lib.ptr(co),
+                             rows, None, None, None, None, _lib.ptr(flag))
+        _lib.call_multi("tspgnn_lnlstm_fwd_multi_h2", [task], d)
+        torch.cuda.synchronize()
+        assert bool(flag.item() & 1) == (where is not None), where

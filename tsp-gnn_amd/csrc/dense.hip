@@ -486,7 +486,7 @@ extern "C" int tspgnn_mlp_fwd_f32(const float* X, const float* wb, float* Y, flo
                                   int rows, int d, int n_layers, unsigned relu_mask, void* stream) {
     if (d == 128 && n_layers > 2 && n_layers <= 4)
         return fail(TSPGNN_EUNSUPPORTED, "mlp_fwd: d=128 holds at most 2 layers in LDS (got %d)", n_layers);
-    const tspgnn_mlp_task t = {X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask, nullptr, nullptr};
+    const tspgnn_mlp_task t = {X, wb, Y, acts, acts_stride, rows, n_layers, relu_mask, nullptr, nullptr, nullptr};
     return tspgnn_mlp_fwd_multi_f32(&t, 1, d, stream);
 }
 
@@ -511,7 +511,7 @@ extern "C" int tspgnn_lnlstm_fwd_multi_f32(const tspgnn_lstm_task* tasks, int n_
 
 extern "C" int tspgnn_lnlstm_fwd_f32(const float* x, int dx, const float* h, const float* c, const float* K,
                                      const float* ln, float* h_out, float* c_out, int rows, int d, void* stream) {
-    const tspgnn_lstm_task t = {x, dx, h, c, K, ln, h_out, c_out, rows, nullptr, nullptr, nullptr, nullptr};
+    const tspgnn_lstm_task t = {x, dx, h, c, K, ln, h_out, c_out, rows, nullptr, nullptr, nullptr, nullptr, nullptr};
     return tspgnn_lnlstm_fwd_multi_f32(&t, 1, d, stream);
 }
 
@@ -520,6 +520,6 @@ extern "C" int tspgnn_lnlstm_gather_fwd_f32(const int32_t* uv, const float* Zx, 
                                             int n_src, int d, void* stream) {
     TSPGNN_REQUIRE(n_src >= 0, "lnlstm_gather_fwd: n_src=%d", n_src);
     TSPGNN_REQUIRE(rows == 0 || (uv && Zx), "lnlstm_gather_fwd: null pointer");
-    const tspgnn_lstm_task t = {nullptr, 0, h, c, Kh, ln, h_out, c_out, rows, uv, Zx, nullptr, nullptr};
+    const tspgnn_lstm_task t = {nullptr, 0, h, c, Kh, ln, h_out, c_out, rows, uv, Zx, nullptr, nullptr, nullptr};
     return tspgnn_lnlstm_fwd_multi_f32(&t, 1, d, stream);
 }

@@ -90,9 +90,10 @@ __device__ unsigned long long h2_trace_buf[16 * 8];   // [wavefront][phase] of w
 //   value = piece(2^s * W[16*(2kb + (j>>2)) + 4g + (j&3)][t*16 + jl]),   KB = krows/32, NT = ncols/16.
 // One ds_read_b128 per (piece, kb, t) and lane: 16 lanes x 16 B contiguous, lane groups a multiple of 256 B apart.
 __global__ __launch_bounds__(256) void pack_weights_h2_kernel(const float* __restrict__ W, _Float16* __restrict__ P,
-                                                              int krows, int ncols) {
+                                                              int krows, int ncols, unsigned* __restrict__ absmax_bits) {
     const int NT = ncols >> 4;
     const int total = krows * ncols;  // per piece
+    unsigned mx = 0u;   // bit pattern of max |2^s W| (non-negative floats order like their bit patterns; NaN sorts above inf)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int j = i & 7, jl = (i >> 3) & 15;
         int rest = i >> 7;
@@ -104,6 +105,16 @@ __global__ __launch_bounds__(256) void pack_weights_h2_kernel(const float* __res
         const _Float16 h = (_Float16)x;
         P[i] = h;
         P[(size_t)total + i] = (_Float16)(x - (float)h);
+        const unsigned b = __float_as_uint(x) & 0x7fffffffu;
+        mx = b > mx ? b : mx;
+    }
+    if (absmax_bits != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)mx, off);
+            mx = o > mx ? o : mx;
+        }
+        if ((threadIdx.x & 63) == 0 && mx != 0u) atomicMax(absmax_bits, mx);
     }
 }
 
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(256) void pack_weights_h2_kernel(const float* __res
 // 2^s * b; the output comes back at its true scale.
 template <int D>
 __device__ __forceinline__ void dense_layer_h2(f32x4 (&a)[D / 16], const _Float16* wh, const _Float16* wl, const float* bias,
-                                               bool relu, int g, int rl) {
+                                               bool relu, int g, int rl, float& wit) {
     constexpr int NT = D / 16, KB = D / 32;
     f32x4 acc[NT];
 #pragma unroll
@@ -122,7 +133,7 @@ __device__ __forceinline__ void dense_layer_h2(f32x4 (&a)[D / 16], const _Float1
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = a[2 * kb + (j >> 2)][j & 3];
         f16x8 bh, bl;
-        split2(x, bh, bl);
+        split2w(x, bh, bl, wit);
         kblock_h2<NT>(acc, wh, wl, kb, g, rl, bh, bl);
     }
     const f32x2 inv = {kH2InvScale, kH2InvScale};
@@ -181,6 +192,7 @@ __global__ __launch_bounds__(1024) void mlp_fwd_h2_kernel(const MlpTaskTableH2 t
     __syncthreads();
 
     const int lane = tid & 63, rl = lane & 15, g = lane >> 4;
+    float wit = 0.f;   // fp16-overflow witness of this wavefront's operand splits (h2_tile.h)
     for (;;) {
         int tile = 0;
         if (lane == 0) tile = atomicAdd(ticket, 1);
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(1024) void mlp_fwd_h2_kernel(const MlpTaskTableH2 t
         for (int l = 0; l < n_layers; ++l) {
             const _Float16* wl = reinterpret_cast<const _Float16*>(lds + (size_t)l * LAYER_BYTES);
             const float* bl = reinterpret_cast<const float*>(lds + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
-            dense_layer_h2<D>(a, wl, wl + D * D, bl, (relu_mask >> l) & 1u, g, rl);
+            dense_layer_h2<D>(a, wl, wl + D * D, bl, (relu_mask >> l) & 1u, g, rl, wit);
             if (acts != nullptr && l < n_layers - 1 && valid) {
                 float* dst = acts + (size_t)l * acts_stride + rbase;
 #pragma unroll
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(1024) void mlp_fwd_h2_kernel(const MlpTaskTableH2 t
                 const f32x4 lo4 = ld4(yr + (2 * kb) * 16), hi4 = ld4(yr + (2 * kb + 1) * 16);
                 float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
                 f16x8 bh, bl;
-                split2(x, bh, bl);
+                split2w(x, bh, bl, wit);
                 kblock_h2<NP>(acc, wp, wp + D * 4 * D, kb, g, rl, bh, bl);
             }
             if (valid) {
@@ -243,6 +255,7 @@ __global__ __launch_bounds__(1024) void mlp_fwd_h2_kernel(const MlpTaskTableH2 t
             }
         }
     }
+    h2_range_report(tt.task[k].range_flag, wit);
 }
 
 // The cell arithmetic of mfma_tile.h's lstm_gates<D, true, SWAP> in two stages, one per gate pair, so that a tile's z
@@ -363,6 +376,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     _Float16* lds_w = reinterpret_cast<_Float16*>(lds_wb);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int rl = lane & 15, g = lane >> 4;   // (re-derived per tile inside the loops: see opaque_lane)
+    float wit = 0.f;                     // fp16-overflow witness of this wavefront's operand splits (h2_tile.h)
     // LayerNorm parameters, rows [g_i, b_i, g_j, b_j, g_f, b_f, g_o, b_o, g_s, b_s]: the gates i, f, o feed sigmoids
     // only, so their gamma / beta are stored times -log2(e) with the forget bias folded into b_f (lstm_gates<D, true>)
     for (int i = tid; i < 10 * D; i += blockDim.x) {
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
             const f32x4 lo4 = ld4x<H2_NT_LOADS != 0>(src), hi4 = ld4x<H2_NT_LOADS != 0>(src + (kb < KBX ? 16 : in_ts));
             float xv[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
             f16x8 bh, bl;
-            split2(xv, bh, bl);
+            split2w(xv, bh, bl, wit);
             kblock_h2<NT4>(acc, lds_w, lds_w + chunk_total, kb - kb_base, g, rl, bh, bl);
         }
     };
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                             float xv[8];
 #pragma unroll
                             for (int j = 0; j < 8; ++j) xv[j] = hr[2 * kb + (j >> 2)][j & 3];
-                            split2(xv, bh[kb], bl[kb]);
+                            split2w(xv, bh[kb], bl[kb], wit);
                         }
                         // (pinned: the sums and the split free the registers the loads below land in; an empty asm makes each
                         // value opaque at this point, so neither the optimiser nor the scheduler can sink the arithmetic below
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                     for (int l = 0; l < n_layers; ++l) {
                         const _Float16* wh = reinterpret_cast<const _Float16*>(lds_mlp + (size_t)l * LAYER_BYTES);
                         const float* bias = reinterpret_cast<const float*>(lds_mlp + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
-                        dense_layer_h2<D>(hn, wh, wh + D * D, bias, (relu_mask >> l) & 1u, g, rl);
+                        dense_layer_h2<D>(hn, wh, wh + D * D, bias, (relu_mask >> l) & 1u, g, rl, wit);
                         if (mlp_acts != nullptr && l < n_layers - 1 && valid) {
                             float* dst = mlp_acts + ((size_t)l * acts_stride + (size_t)rc * D + g * 4);
 #pragma unroll
@@ -680,7 +694,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 for (int l = 0; l < n_layers; ++l) {
                     const _Float16* wh = reinterpret_cast<const _Float16*>(lds_mlp + (size_t)l * LAYER_BYTES);
                     const float* bias = reinterpret_cast<const float*>(lds_mlp + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
-                    dense_layer_h2<D>(hn, wh, wh + D * D, bias, (relu_mask >> l) & 1u, g, rl);
+                    dense_layer_h2<D>(hn, wh, wh + D * D, bias, (relu_mask >> l) & 1u, g, rl, wit);
                     if (mlp_acts != nullptr && l < n_layers - 1 && valid) {
                         float* dst = mlp_acts + ((size_t)l * acts_stride + (size_t)rc * D + g * 4);
 #pragma unroll
@@ -754,7 +768,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                                 const f32x4 lo4 = opr[2 * kb], hi4 = opr[2 * kb + 1];
                                 float xv[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
                                 f16x8 bh, bl;
-                                split2(xv, bh, bl);
+                                split2w(xv, bh, bl, wit);
                                 kblock_h2<NT4>(acc, lds_w, lds_w + chunk_total, kb - kb0, g, rl, bh, bl);
                             }
                         }
@@ -780,7 +794,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 for (int l = 0; l < n_layers; ++l) {
                     const _Float16* wh = reinterpret_cast<const _Float16*>(lds_wb + (size_t)l * LAYER_BYTES);
                     const float* bias = reinterpret_cast<const float*>(lds_wb + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
-                    dense_layer_h2<D>(hn, wh, wh + D * D, bias, (relu_mask >> l) & 1u, g, rl);
+                    dense_layer_h2<D>(hn, wh, wh + D * D, bias, (relu_mask >> l) & 1u, g, rl, wit);
                     if (mlp_acts != nullptr && l < n_layers - 1 && valid) {
                         float* dst = mlp_acts + ((size_t)l * acts_stride + (size_t)rc * D + g * 4);
 #pragma unroll
@@ -808,7 +822,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
 #pragma unroll
                         for (int j = 0; j < 8; ++j) xv[j] = hn[2 * kb + (j >> 2)][j & 3];
                         f16x8 bh, bl;
-                        split2(xv, bh, bl);
+                        split2w(xv, bh, bl, wit);
                         kblock_h2<NT4>(acc, wp, wp + D * 4 * D, kb, g, rl, bh, bl);
                     }
                     if (valid) {
@@ -819,6 +833,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
             }
         }
     }
+    h2_range_report(tk.range_flag, wit);
 }
 
 static int split_blocks_h2(const long long* cost, int n, int grid, int* blk_end) {
@@ -1002,14 +1017,14 @@ extern "C" int tspgnn_debug_h2_trace(unsigned long long* host_dst) {
 }
 #endif
 
-extern "C" int tspgnn_pack_weights_h2(const float* W, void* P, int krows, int ncols, void* stream) {
+extern "C" int tspgnn_pack_weights_h2(const float* W, void* P, int krows, int ncols, unsigned* absmax_bits, void* stream) {
     TSPGNN_REQUIRE(krows >= 0 && krows % 32 == 0, "pack_weights_h2: krows=%d must be a multiple of 32", krows);
     TSPGNN_REQUIRE(ncols > 0 && ncols % 16 == 0, "pack_weights_h2: ncols=%d must be a multiple of 16", ncols);
     if (krows == 0) return TSPGNN_OK;
     TSPGNN_REQUIRE(W && P, "pack_weights_h2: null pointer");
     int grid = (krows * ncols + 255) / 256;
     if (grid > 1024) grid = 1024;
-    pack_weights_h2_kernel<<<grid, 256, 0, as_stream(stream)>>>(W, reinterpret_cast<_Float16*>(P), krows, ncols);
+    pack_weights_h2_kernel<<<grid, 256, 0, as_stream(stream)>>>(W, reinterpret_cast<_Float16*>(P), krows, ncols, absmax_bits);
     return launched("tspgnn_pack_weights_h2");
 }
 

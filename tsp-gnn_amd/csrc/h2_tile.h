@@ -36,6 +36,33 @@ __device__ __forceinline__ void split2(const float (&x)[8], f16x8& hi, f16x8& lo
     }
 }
 
+// The same split, keeping a witness of fp16 overflow: an |x| >= 65520 rounds to hi = +-inf, and then the residual
+// x - hi is -+inf (NaN for a non-finite x, which the maximum ignores: the fp32 reference is non-finite there too).
+// `wit` accumulates max |residual| -- one v_max3_f32 per PAIR of values; h2_range_report() turns an infinite witness
+// into bit 0 of the task's range_flag, once per wavefront.
+__device__ __forceinline__ void split2w(const float (&x)[8], f16x8& hi, f16x8& lo, float& wit) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2 v = {x[i], x[i + 1]};
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x[i]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x[i + 1]));
+        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(wit) : "v"(r0), "v"(r1));
+        const f32x2 r = {r0, r1};
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        hi[i] = h[0];
+        hi[i + 1] = h[1];
+        lo[i] = l[0];
+        lo[i + 1] = l[1];
+    }
+}
+__device__ __forceinline__ void h2_range_report(unsigned* flag, float wit) {
+    if (flag != nullptr && __any(!(wit <= 3.0e38f))) {
+        if ((threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    }
+}
+
 // The projected messages Zx = 2^s (y Kx) between an f16x2 projection (producer, vertex rows) and an f16x2 cell in
 // gather-init mode (consumer, edge rows) are stored BLOCKED by 16 source rows: the float4 (columns 16t + 4g .. +3) of
 // row v lives at  (((v / 16) * (D/4) + t) * 4 + g) * 64 + (v % 16) * 4  floats.  The producer's 16-row tile then stores

@@ -182,9 +182,11 @@ __global__ __launch_bounds__(256) void einit_bwd_kernel(const float2* __restrict
 // g <- g + l2 * theta ; partial sums of g^2 (fixed order per workgroup).
 __global__ __launch_bounds__(256) void l2_sumsq_kernel(float* __restrict__ g, const float* __restrict__ theta,
                                                        float l2, float* __restrict__ partial, int n,
-                                                       int* __restrict__ step_counter) {
+                                                       int* __restrict__ step_counter,
+                                                       const unsigned* __restrict__ skip_flag) {
     __shared__ float red[256];
-    if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) step_counter[0] += 1;  // this optimiser step's index t
+    // this optimiser step's index t (not advanced for a step that is skipped, see adam_clip_kernel)
+    if (step_counter && blockIdx.x == 0 && threadIdx.x == 0 && !(skip_flag && skip_flag[0])) step_counter[0] += 1;
     float s = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float v = fmaf(l2, theta[i], g[i]);
@@ -207,7 +209,9 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ thet
                                                         const float* __restrict__ partial, int n_partial, float clip,
                                                         float lr_t, float b1, float b2, float eps,
                                                         float* __restrict__ state, int n,
-                                                        const int* __restrict__ step_counter) {
+                                                        const int* __restrict__ step_counter,
+                                                        const unsigned* __restrict__ skip_flag) {
+    const bool skip = skip_flag && skip_flag[0];   // the step's forward left the f16x2 range: leave the variables alone
     if (step_counter) {  // lr_t holds the base rate: apply Adam's bias correction for step t on the device
         const float t = (float)step_counter[0];
         lr_t = lr_t * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ thet
     const float gnorm = sqrtf(ss);
     const float scale = clip > 0.f ? clip / fmaxf(gnorm, clip) : 1.0f;
     if (blockIdx.x == 0 && threadIdx.x == 0) state[0] = gnorm;
+    if (skip) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float gi = g[i] * scale;
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -326,17 +331,18 @@ extern "C" long long tspgnn_adam_workspace_floats(void) { return TSPGNN_OPT_PART
 
 extern "C" int tspgnn_adam_clip_step_f32(float* theta, float* g, float* m, float* v, int n, float l2_scale,
                                          float clip_norm, float lr_t, float beta1, float beta2, float eps,
-                                         float* gnorm_out, float* workspace, int* step_counter, void* stream) {
+                                         float* gnorm_out, float* workspace, int* step_counter,
+                                         const unsigned* skip_flag, void* stream) {
     TSPGNN_REQUIRE(n >= 0, "adam_clip_step: n=%d", n);
     if (n == 0) return TSPGNN_OK;
     TSPGNN_REQUIRE(theta && g && m && v && gnorm_out && workspace, "adam_clip_step: null pointer");
     hipStream_t st = as_stream(stream);
     int blocks = (n + 255) / 256;
     if (blocks > TSPGNN_OPT_PARTIALS) blocks = TSPGNN_OPT_PARTIALS;
-    l2_sumsq_kernel<<<blocks, 256, 0, st>>>(g, theta, l2_scale, workspace, n, step_counter);
+    l2_sumsq_kernel<<<blocks, 256, 0, st>>>(g, theta, l2_scale, workspace, n, step_counter, skip_flag);
     int rc = launched("tspgnn_adam_clip_step_f32(l2+norm)");
     if (rc) return rc;
     adam_clip_kernel<<<blocks, 256, 0, st>>>(theta, g, m, v, workspace, blocks, clip_norm, lr_t, beta1, beta2, eps,
-                                             gnorm_out, n, step_counter);
+                                             gnorm_out, n, step_counter, skip_flag);
     return launched("tspgnn_adam_clip_step_f32");
 }

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSPGNN_LIB") or os.path.join(_HERE, "libtspgnn.so")   # (TSPGNN_LIB: A/B builds)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_int, c_uint, c_float, c_void_p, c_char_p, c_longlong = (ctypes.c_int, ctypes.c_uint, ctypes.c_float,
                                                           ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong)
@@ -37,7 +37,7 @@ SIGNATURES = {
     "tspgnn_mlp_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_mlp_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
-    "tspgnn_pack_weights_h2": [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_pack_weights_h2": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "tspgnn_mlp_fwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_fwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_mlp_fwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
@@ -69,7 +69,7 @@ SIGNATURES = {
     "tspgnn_wcolsum_f32": [c_void_p, c_void_p, c_longlong, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "tspgnn_einit_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_adam_clip_step_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
-                                  c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+                                  c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 
 HOST_FUNCTIONS = ("tspgnn_host_pack_instance", "tspgnn_host_route_cost", "tspgnn_host_csr_by_vertex",
@@ -88,14 +88,15 @@ SIZE_QUERIES = {
 class MlpTask(ctypes.Structure):
     """tspgnn_mlp_task (include/tspgnn.h)."""
     _fields_ = [("X", c_void_p), ("wb", c_void_p), ("Y", c_void_p), ("acts", c_void_p), ("acts_stride", c_longlong),
-                ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint), ("proj_w", c_void_p), ("proj_out", c_void_p)]
+                ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint), ("proj_w", c_void_p), ("proj_out", c_void_p),
+                ("range_flag", c_void_p)]
 
 
 class LstmTask(ctypes.Structure):
     """tspgnn_lstm_task (include/tspgnn.h)."""
     _fields_ = [("x", c_void_p), ("dx", c_int), ("h", c_void_p), ("c", c_void_p), ("K", c_void_p), ("ln", c_void_p),
                 ("h_out", c_void_p), ("c_out", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p),
-                ("zbias", c_void_p), ("zscale", c_void_p)]
+                ("zbias", c_void_p), ("zscale", c_void_p), ("range_flag", c_void_p)]
 
 
 class CellMlpTask(ctypes.Structure):

@@ -39,6 +39,16 @@ def _pad16(rows):
     return (int(rows) + 15) // 16 * 16
 
 
+def _pack_split(store, arith, W, out, krows, ncols):
+    """tspgnn_pack_weights_x3 / _h2 of W [krows, ncols] into the byte tensor ``out``; an f16x2 packing also raises the
+    store's range guard word to max |2^s W| (VariableStore.h2_guard)."""
+    if arith == "h2":
+        _lib.call("tspgnn_pack_weights_h2", _lib.ptr(W), _lib.ptr(out), krows, ncols, store.h2_absmax_ptr(),
+                  _lib.current_stream())
+    else:
+        _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(W), _lib.ptr(out), krows, ncols, _lib.current_stream())
+
+
 def _dev_i32(a, device):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
 
@@ -285,8 +295,7 @@ class LayerNormBasicLSTMCell(object):
             K = self.kernel()[rows_lo:rows_hi]
             if out is None:
                 out = torch.empty(SPLIT_BYTES[arith] * K.numel(), dtype=torch.uint8, device=K.device)
-            _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(K), _lib.ptr(out), rows_hi - rows_lo, 4 * self.d,
-                      _lib.current_stream())
+            _pack_split(self.store, arith, K, out, rows_hi - rows_lo, 4 * self.d)
             return out
         return self.store.packed((key + "." + arith, self.base), build)
 
@@ -331,13 +340,17 @@ class LayerNormBasicLSTMCell(object):
         K = self._packed_split(arith, "lstm", 0, self.dx + self.d) if arith else self.kernel_packed()
         return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(K),
                              _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None,
-                             None, None)
+                             None, None, self._flag(arith))
 
     def gather_task(self, adj, zx, state, out, arith=None):
         K = self._packed_split(arith, "lstm.kh", self.dx, self.dx + self.d) if arith else self.kh_packed()
         return _lib.LstmTask(None, 0, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(K),
                              _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0],
-                             _lib.ptr(adj.uv), _lib.ptr(zx), None, None)
+                             _lib.ptr(adj.uv), _lib.ptr(zx), None, None, self._flag(arith))
+
+    def _flag(self, arith):
+        """The range_flag of an f16x2 task (include/tspgnn.h): the store's guard word."""
+        return self.store.h2_flag_ptr() if arith == "h2" else None
 
     def pushed_kernel(self, mlp):
         """(K' = [W Kx ; Kh] as fp32 [dx+d, 4d], b Kx as [1, 4d], pack(K'^T) for the data gradient) of the message MLP's
@@ -377,7 +390,7 @@ class LayerNormBasicLSTMCell(object):
                     else torch.empty((dx + d, 4 * d), dtype=torch.float32, device=kfull.device)
             st = _lib.current_stream()
             if arith:
-                _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(kfull), _lib.ptr(out), dx + d, 4 * d, st)
+                _pack_split(self.store, arith, kfull, out, dx + d, 4 * d)
             else:
                 _lib.call("tspgnn_pack_weights_f32", _lib.ptr(kfull), _lib.ptr(out), dx + d, 4 * d, 0, st)
             return out
@@ -431,10 +444,11 @@ class LayerNormBasicLSTMCell(object):
         dkx.addcmul_(b.view(-1, 1), g_zb.view(1, -1))
         self.store.grad_view(self.base + "/kernel")[:dx].add_(dkx)
 
-    def pushed_task(self, x, state, out, kp, zb, deg):
+    def pushed_task(self, x, state, out, kp, zb, deg, arith=None):
         """Cell task whose kernel operand is pushed_bias_pack's K' (either packing) and z starts at deg * zb."""
         return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(kp), _lib.ptr(self.ln()),
-                             _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None, _lib.ptr(zb), _lib.ptr(deg))
+                             _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None, _lib.ptr(zb), _lib.ptr(deg),
+                             self._flag(arith))
 
     def premultiply(self, y, out=None, scale=None):
         """Zx = y Kx  ([n_src, 4d]); ``scale``: times 2^s for an f16x2 cell, whose z carries that factor."""
@@ -468,8 +482,7 @@ class LayerNormBasicLSTMCell(object):
             KT = self.kernel()[rows_lo:rows_hi].t().contiguous()
             if out is None:
                 out = torch.empty(SPLIT_BYTES["h2"] * KT.numel(), dtype=torch.uint8, device=KT.device)
-            _lib.call("tspgnn_pack_weights_h2", _lib.ptr(KT), _lib.ptr(out), 4 * self.d, rows_hi - rows_lo,
-                      _lib.current_stream())
+            _pack_split(self.store, "h2", KT, out, 4 * self.d, rows_hi - rows_lo)
             return out
         return self.store.packed((key + ".h2", self.base), build)
 
@@ -599,6 +612,8 @@ class GraphNN(object):
         self.gemm = os.environ.get("TSPGNN_GEMM", "f16x2")
         if self.gemm not in GEMM_ARITH:
             raise ValueError("TSPGNN_GEMM must be one of %s, got %r" % (sorted(GEMM_ARITH), self.gemm))
+        self._h2_off_at = None       # store.assignments at which the weights were found outside the f16x2 range
+        self._h2_force_off = False
         self.check_model()
         self._init_parameters()
 
@@ -745,6 +760,8 @@ class GraphNN(object):
             # (the fused plan reads the caller's embeddings in place and takes "no initial cell state" as such: no copies,
             # no zero fill)
             plan = self._plan_fused({v: LSTMStateTuple(c=c0[v], h=h0[v]) for v in h0}, mats, folded)
+            if plan is not None and not self.check_h2_weights():   # (the plan's packings raised the guard: bf16x3 instead)
+                plan = self._plan_fused({v: LSTMStateTuple(c=c0[v], h=h0[v]) for v in h0}, mats, folded)
             if plan is not None:
                 return _States(plan(T), self._plan_keep)
         states = {v: LSTMStateTuple(c=torch.zeros(h0[v].shape, dtype=torch.float32, device=h0[v].device) if c0[v] is None
@@ -753,6 +770,8 @@ class GraphNN(object):
             return self._run_bf16(states, mats, dense_mats, T)
         if T > 0:
             plan = self._plan(states, mats, folded)
+            if plan is not None and not self.check_h2_weights():
+                plan = self._plan(states, mats, folded)
             if plan is not None:
                 for t in range(T):
                     plan[t & 1]()
@@ -895,8 +914,52 @@ class GraphNN(object):
             return None
         if GEMM_ARITH[self.gemm] and all(c.x3_ok() for c in self._RNN_cells.values()) \
                 and all(m.sizes[-1] in (32, 64) for m in self._msg_MLPs.values()):
-            return GEMM_ARITH[self.gemm]
+            return self.active_arith()
         return None
+
+    # ---- f16x2 range guard.  fp16 pieces cannot hold what fp32 -- the reference's type, graphnn.py:18 -- can: a weight
+    # with 2^6 |w| >= 65504 or an activation >= 65504 overflows to inf.  Weights are checked where they are packed (a
+    # device word raised by tspgnn_pack_weights_h2, read here when packings were refreshed); activations where the
+    # kernels split them (the tasks' range_flag, read by Session.run next to the statistics it fetches anyway).  Either
+    # way the network falls back to bf16x3, whose pieces have fp32's exponent range.
+    def active_arith(self):
+        """Suffix of the split-operand entry points in force: "h2" / "x3" / None, after the range guard's say."""
+        arith = GEMM_ARITH[self.gemm]
+        if arith == "h2" and (self._h2_force_off or self._h2_off_at == self.store.assignments):
+            return "x3"
+        return arith
+
+    def forced_off_h2(self):
+        """Context manager: f16x2 disabled inside (Session's re-run of a batch whose activations overflowed)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            prev, self._h2_force_off = self._h2_force_off, True
+            try:
+                yield self
+            finally:
+                self._h2_force_off = prev
+        return cm()
+
+    def check_h2_weights(self):
+        """False if the weights just packed veto f16x2 (the caller rebuilds its launch plan: _split_arith now answers
+        "x3"), True otherwise.  Reads the guard's weight word when packings were enqueued
+        since the last look (one 4-byte device read; skipped while a HIP graph is being captured -- a captured
+        sequence is checked by its replay closure); past HALF the fp16 range the network is latched to bf16x3 until
+        the variables are assigned anew."""
+        store = self.store
+        if GEMM_ARITH[self.gemm] != "h2" or self._h2_force_off or self._h2_off_at == store.assignments:
+            return True    # (not in use, or already vetoed for these variables: the caller's plan stands)
+        if store.h2_packs_pending and store.theta.is_cuda and not torch.cuda.is_current_stream_capturing():
+            guard = store.h2_guard()
+            bits = int(guard[1].item())
+            guard[1:2].zero_()
+            store.h2_packs_pending = 0
+            if bits >= store.H2_WEIGHT_LIMIT_BITS:
+                self._h2_off_at = store.assignments
+                return False
+        return True
 
     def _single_consumers(self):
         """{source variable: (v, i)} when every variable's h feeds exactly one loop entry and that entry has a
@@ -1017,7 +1080,7 @@ class GraphNN(object):
                         u0 = self.loop[v][0]
                         kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], arith=arith)
                         deg = mats[u0["mat"]].row_degrees(bool(u0.get("transpose?", False)))
-                        t = cell.pushed_task(x, st, out, kp, zb, deg)
+                        t = cell.pushed_task(x, st, out, kp, zb, deg, arith=arith)
                     else:
                         t = cell.task(x, st, out, arith=arith)
                 s_in = 1 if blocked[v] and not first else 0
@@ -1043,7 +1106,7 @@ class GraphNN(object):
                     keep.append(mout)
                 pre.setdefault(self._msg_MLPs[u["msg"]].sizes[-1], []).append(
                     _lib.MlpTask(_lib.ptr(y), _lib.ptr(wb), _lib.ptr(mout), None, 0, y.shape[0], n, mask,
-                                 _lib.ptr(pw), _lib.ptr(po)))
+                                 _lib.ptr(pw), _lib.ptr(po), self.store.h2_flag_ptr() if arith == "h2" else None))
         pre_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in pre.items() for k in range(0, len(ts), 4)]
         built = {}
         self._plan_keep = keep
@@ -1137,7 +1200,7 @@ class GraphNN(object):
                     u0 = self.loop[v][0]
                     kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], arith=arith)
                     deg = mats[u0["mat"]].row_degrees(bool(u0.get("transpose?", False)))
-                    lstm_tasks.setdefault(d, []).append(cell.pushed_task(x, st, out, kp, zb, deg))
+                    lstm_tasks.setdefault(d, []).append(cell.pushed_task(x, st, out, kp, zb, deg, arith=arith))
                 else:
                     lstm_tasks.setdefault(d, []).append(cell.task(x, st, out, arith=arith))
                 keep.append(x)
@@ -1284,6 +1347,16 @@ class GraphNN(object):
         # cells' backward recomputes z in the same arithmetic (tspgnn_lnlstm_bwd_multi_h2; the tape's projected
         # messages ZX carry the factor 2^s both sides expect); with bf16x3 the backward is fp32 MFMA.
         arith = self._split_arith({v: initial_embeddings[v].shape[0] for v in self.var})
+        if arith == "h2":
+            # the step's f16x2 packings up front (they are cached for the tasks below), so that the guard can veto them
+            # before any kernel multiplies with them
+            for cell in self._RNN_cells.values():
+                cell._packed_split("h2", "lstm", 0, cell.dx + cell.d)
+            for mlp in self._msg_MLPs.values():
+                if len(mlp._chunks()) == 1:
+                    mlp.wb_packed_split("h2", 0, mlp.n_square - 1, mlp.sizes[-1])
+            if not self.check_h2_weights():
+                arith = self._split_arith({v: initial_embeddings[v].shape[0] for v in self.var})
         tape.arith = arith
         mlp_fn = "tspgnn_mlp_fwd_multi_" + (arith or "f32")
         lstm_fn = "tspgnn_lnlstm_fwd_multi_" + (arith or "f32")
@@ -1370,7 +1443,7 @@ class GraphNN(object):
                 u0 = self.loop[v][0]
                 kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], arith=arith)
                 return cell.pushed_task(tape.X[v][t], st, out, kp, zb,
-                                        mats[u0["mat"]].row_degrees(bool(u0.get("transpose?", False))))
+                                        mats[u0["mat"]].row_degrees(bool(u0.get("transpose?", False))), arith=arith)
             return cell.task(tape.X[v][t], st, out, arith=arith)
 
         # f16x2, opt-in (fuse_training_messages): the message MLPs of step t+1 ride in the cell launch of step t, on the

@@ -118,7 +118,11 @@ class Mlp(object):
             st = _lib.current_stream()
             for j in range(last - first + 1):
                 o, q = j * per_src, j * per
-                _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(src[o:o + d * d]), _lib.ptr(out[q:q + nb * d * d]), d, d, st)
+                if arith == "h2":
+                    _lib.call("tspgnn_pack_weights_h2", _lib.ptr(src[o:o + d * d]), _lib.ptr(out[q:q + nb * d * d]), d, d,
+                              self.store.h2_absmax_ptr(), st)
+                else:
+                    _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(src[o:o + d * d]), _lib.ptr(out[q:q + nb * d * d]), d, d, st)
                 bias = src[o + d * d:o + per_src]
                 if arith == "h2":
                     bias = bias * _lib.lib.tspgnn_h2_weight_scale()
@@ -177,7 +181,8 @@ class Mlp(object):
         pw, po = (proj if proj is not None else (None, None))
         wb = self.wb_packed_split(arith, 0, n_sq - 1, d) if arith else self.wb_packed(0, n_sq - 1, d)
         return _lib.MlpTask(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(out), _lib.ptr(acts),
-                            acts_stride, x.shape[0], n_sq, self.relu_mask(0, n_sq), _lib.ptr(pw), _lib.ptr(po))
+                            acts_stride, x.shape[0], n_sq, self.relu_mask(0, n_sq), _lib.ptr(pw), _lib.ptr(po),
+                            self.store.h2_flag_ptr() if arith == "h2" else None)
 
     def prefix_task(self, x, out, n_layers, arith=None, acts=None, acts_stride=0):
         """Task running only the first ``n_layers`` square layers (the rest is folded elsewhere); ``acts``: the hidden
@@ -187,7 +192,8 @@ class Mlp(object):
             return None
         wb = self.wb_packed_split(arith, 0, n_layers - 1, d) if arith else self.wb_packed(0, n_layers - 1, d)
         return _lib.MlpTask(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(out), _lib.ptr(acts) if n_layers > 1 else None, acts_stride,
-                            x.shape[0], n_layers, self.relu_mask(0, n_layers), None, None)
+                            x.shape[0], n_layers, self.relu_mask(0, n_layers), None, None,
+                            self.store.h2_flag_ptr() if arith == "h2" else None)
 
     def _chunks(self):
         kind, d, n_sq, head = self._plan
@@ -275,7 +281,8 @@ class Mlp(object):
             return self(x)
         out = torch.empty((x.shape[0], d), dtype=torch.float32, device=x.device)
         task = _lib.MlpTask(_lib.ptr(x), _lib.ptr(self.wb_packed_split(arith, 0, n_sq - 1, d)), _lib.ptr(out), None, 0,
-                            x.shape[0], n_sq, self.relu_mask(0, n_sq), None, None)
+                            x.shape[0], n_sq, self.relu_mask(0, n_sq), None, None,
+                            self.store.h2_flag_ptr() if arith == "h2" else None)
         _lib.call_multi("tspgnn_mlp_fwd_multi_" + arith, [task], d)
         if not head:
             return out

@@ -292,15 +292,33 @@ class Session(object):
                   _lib.ptr(V0), b.N, d, st)
         last = m["gnn"]({"EV": b.adj}, {"V": V0, "E": E0}, b.T)               # model.py:118-122
         Eh = last["E"].h.to(torch.float32)                                    # (bf16 storage: widened once)
-        arith = GEMM_ARITH[m["gnn"].gemm]
+        arith = m["gnn"].active_arith()
         vote = (m.E_vote_MLP.forward_split(Eh, arith) if arith else m.E_vote_MLP(Eh)).view(-1)   # model.py:128
+        if arith == "h2" and not m["gnn"].check_h2_weights():     # (the vote head's packing vetoed f16x2: bf16x3)
+            vote = m.E_vote_MLP.forward_split(Eh, m["gnn"].active_arith()).view(-1)
         logits = torch.empty(b.B, dtype=torch.float32, device=self.device)
         _lib.call("tspgnn_segment_mean_f32", _lib.ptr(vote), _lib.ptr(b.seg), _lib.ptr(logits), b.B, st)
         pred = torch.empty(b.B, dtype=torch.float32, device=self.device)
         stats = torch.empty(6, dtype=torch.float32, device=self.device)
         _lib.call("tspgnn_bce_metrics_f32", _lib.ptr(logits), _lib.ptr(b.labels), _lib.ptr(pred), _lib.ptr(stats),
                   b.B, st)
-        return {"last_states": last, "E_vote": vote, "logits": logits, "predictions": pred, "stats": stats}
+        return {"last_states": last, "E_vote": vote, "logits": logits, "predictions": pred, "stats": stats,
+                "range_guard": self.store.h2_guard()}
+
+    # ---- f16x2 range guard (GraphNN.active_arith): the default arithmetic's fp16 pieces overflow where the reference's
+    # fp32 does not.  Weights are vetted when they are packed; an ACTIVATION that leaves the range sets bit 0 of the
+    # guard word on the device, which every synchronous entry point (run) reads next to the values it fetches anyway
+    # and answers by re-running the batch on bf16x3.  forward() / forward_device() / capture_forward() return device
+    # tensors without synchronising: their callers get the word as out["range_guard"] and range_exceeded().
+    def range_exceeded(self, clear=True):
+        """True if an f16x2 launch since the last call flagged an operand outside the fp16 range (synchronises)."""
+        if self.device.type != "cuda":
+            return False
+        guard = self.store.h2_guard()
+        hit = bool(int(guard[0].item()) & 1)
+        if hit and clear:
+            guard[0:1].zero_()
+        return hit
 
     def capture_forward(self, batch):
         """Captures one forward pass over a resident batch into a HIP graph (hipStreamBeginCapture via
@@ -309,7 +327,10 @@ class Session(object):
         kernels; replaying the graph removes the per-launch host cost.  The captured graph reads the
         packed weights that were current at capture time: re-capture after the variables change."""
         b = batch if isinstance(batch, DeviceBatch) else self.prepare(batch)
-        self.forward_device(b)          # warm-up: builds packed-weight caches outside the capture
+        self.forward_device(b)          # warm-up: builds packed-weight caches (and vets their range) outside the capture
+        if self.range_exceeded():       # this batch's activations leave the f16x2 range: capture it on bf16x3
+            with self.model["gnn"].forced_off_h2():
+                return self.capture_forward(b)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(device=self.device)
@@ -327,6 +348,7 @@ class Session(object):
             graph.replay()
             return out
         replay.graph = graph
+        replay.range_exceeded = self.range_exceeded   # (synchronising) did a replay leave the f16x2 range? see run()
         return replay
 
     # ------------------------------------------------------------------ run
@@ -348,10 +370,18 @@ class Session(object):
                 raise ValueError("You must feed a value for placeholder(s) %s" % ", ".join(missing))
             if "train_step" in names:
                 out = self.train_step(feed_dict)
+                if self.range_exceeded():   # (Adam skipped the update on the device: the variables are untouched)
+                    self._adam["step"] -= 1     # the host mirror of the step counter counted the skipped attempt
+                    with self.model["gnn"].forced_off_h2():
+                        out = self.train_step(feed_dict)
             else:
                 # a statistic of the batch is a statistic of the GLOBAL batch in a data-parallel session (collective:
                 # every rank fetches it, as run_batch does); predictions / last_states alone stay rank-local
-                out = self.forward(feed_dict, global_stats=any(n in STAT_FETCHES for n in names))
+                gs = any(n in STAT_FETCHES for n in names)
+                out = self.forward(feed_dict, global_stats=gs)
+                if self.range_exceeded():   # an activation left the fp16 range: this batch again on bf16x3 (fp32's range)
+                    with self.model["gnn"].forced_off_h2():
+                        out = self.forward(feed_dict, global_stats=gs)
         results = []
         stats = None
         for f in flist:
@@ -436,7 +466,7 @@ class Session(object):
 
     # The data-parallel step.  The loss is a mean over the GLOBAL batch (model.py:157), so rank r's
     # gradient of its local mean counts with weight B_r / B.  Everything that must cross ranks rides in ONE bucket:
-    #   bucket = [ B_r * grad_r | B_r, B_r*loss_r, B_r*acc_r, TP_r, FP_r, TN_r, FN_r, 0 ]     (VariableStore.bucket)
+    #   bucket = [ B_r * grad_r | B_r, B_r*loss_r, B_r*acc_r, TP_r, FP_r, TN_r, FN_r, range flag_r ]     (VariableStore.bucket)
     # one all-reduce(sum) of it (RCCL over xGMI with the 'nccl' backend; 462 KB at d=64), then every rank divides by the
     # reduced B on the device: no host round trip, so the two HIP graphs of capture_train_step run back to back around
     # the collective.  The L2 term, the clip by the GLOBAL norm and Adam follow on the reduced gradient, identically
@@ -455,6 +485,7 @@ class Session(object):
             tail[1:3].copy_(stats[0:2])
             tail[1:3].mul_(nb)
             tail[3:7].copy_(stats[2:6])
+        tail[7:8].copy_(store.h2_guard()[0:1])   # f16x2 range flag: every rank must skip / repeat the step together
         return tail
 
     def _unpack_bucket(self, stats, with_grad):
@@ -466,6 +497,7 @@ class Session(object):
         if stats is not None:
             stats[0:2].copy_(tail[1:3] * inv)
             stats[2:6].copy_(tail[3:7])
+        store.h2_guard()[0:1].copy_(tail[7:8] != 0)
 
     def allreduce_grads(self, local_batch, stats=None):
         """One all-reduce of [gradient | batch size, statistics]; afterwards ``store.grad`` holds the gradient of
@@ -530,7 +562,8 @@ class Session(object):
         b1, b2, eps = 0.9, 0.999, 1e-8     # tf.train.AdamOptimizer defaults
         _lib.call("tspgnn_adam_clip_step_f32", _lib.ptr(store.theta), _lib.ptr(store.grad), _lib.ptr(a["m"]),
                   _lib.ptr(a["v"]), store.theta.numel(), L2NORM_SCALING, GLOBAL_NORM_CLIP, LEARNING_RATE, b1, b2, eps,
-                  _lib.ptr(a["gnorm"]), _lib.ptr(a["ws"]), _lib.ptr(a["t"]), _lib.current_stream())
+                  _lib.ptr(a["gnorm"]), _lib.ptr(a["ws"]), _lib.ptr(a["t"]),
+                  store.h2_flag_ptr() if self.device.type == "cuda" else None, _lib.current_stream())
         store.touch()
         return a["gnorm"]
 
@@ -578,10 +611,31 @@ class Session(object):
         self._adam["step"] -= 1               # capture does not execute: undo the host mirror's increment
         out["global_norm"] = gnorm
 
+        # f16x2 range guard under replay: the packings happen inside graph A, so the guard words are looked at one
+        # replay LATE, through a pinned copy and an event (no synchronisation).  That is safe: the weight word trips at
+        # half the fp16 range (Adam moves a weight by ~lr per step), and a step whose activations overflowed was
+        # skipped by the optimiser kernel on the device (skip_flag).  Either way f16x2 is switched off for these
+        # variables and the caller is asked to capture again (the new capture runs on bf16x3).
+        gnn, store = self.model["gnn"], self.store
+        guard_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        pending = []
+
         def replay():
+            if pending and pending[0].query():
+                pending.clear()
+                if (int(guard_host[0]) & 1) or int(guard_host[1]) >= store.H2_WEIGHT_LIMIT_BITS:
+                    gnn._h2_off_at = store.assignments
+                    store.h2_guard().zero_()
+                    raise RuntimeError("f16x2 range exceeded during replayed training steps (the affected steps were "
+                                       "not applied): capture_train_step() again -- it will run on bf16x3")
             ga.replay()
             self.allreduce_grads(b.B, out["stats"])   # device-side only: no host sync between the two graphs
             gb.replay()
+            if not pending and gnn.active_arith() == "h2":
+                guard_host.copy_(store.h2_guard(), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                pending.append(ev)
             self._adam["step"] += 1
             self.store.touch()
             return out

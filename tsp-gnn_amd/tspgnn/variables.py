@@ -50,6 +50,26 @@ class VariableStore(object):
                               # Session re-broadcasts from rank 0 before its next training step
         self._packed = {}
         self.grad = None      # flat gradient buffer, same layout as theta (allocated on first use)
+        self._h2_guard = None
+        self.h2_packs_pending = 0   # f16x2 weight packings enqueued since the guard's weight word was last read
+
+    # -- f16x2 range guard (include/tspgnn.h, tspgnn_pack_weights_h2) ------------------------------------
+    # int32[4] on the device: [0] bit 0 set by an f16x2 launch whose operand left the fp16 range (the tasks' range_flag,
+    # also Adam's skip_flag); [1] IEEE bits of max |2^s W| over every f16x2 weight packing since it was last zeroed.
+    H2_WEIGHT_LIMIT_BITS = 0x46ffe000   # 32752.0f: HALF of fp16's largest finite value -- margin for the steps a
+                                        # training run takes between two looks at the word (Adam moves a weight by ~lr)
+
+    def h2_guard(self):
+        if self._h2_guard is None:
+            self._h2_guard = torch.zeros(4, dtype=torch.int32, device=self.theta.device)
+        return self._h2_guard
+
+    def h2_flag_ptr(self):
+        return self.h2_guard().data_ptr()
+
+    def h2_absmax_ptr(self):
+        self.h2_packs_pending += 1
+        return self.h2_guard().data_ptr() + 4
 
     # -- declaration phase -------------------------------------------------------------
     def declare(self, name, shape, initializer):
