@@ -83,6 +83,17 @@ def main():
     import tspgnn
     from tspgnn import _lib
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become one.  One rank per GPU through torch.distributed.run on
+        # the loopback address (same command line the driver uses); the ranks' single JSON line is rank 0's.
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+                                  str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                  os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -168,10 +179,18 @@ def main():
         try:
             dt_train, tout = timed(make_train_fn(), 1, args.train_steps)
             train = {"ms_per_batch": round(1e3 * dt_train / args.train_steps, 3),
+                     "ms_per_step": round(1e3 * dt_train / args.train_steps, 3),
+                     "value": round(world * args.train_steps * T / dt_train, 2), "unit": "mp-steps/s",
                      "mp_steps_per_s": round(world * args.train_steps * T / dt_train, 2),
+                     "n_gpus": world, "scaling": "weak", "global_batch": len(sizes) * world,
+                     "collective": "one all-reduce (RCCL) of the %d-byte bucket [gradient | batch size, statistics, "
+                                   "range flag] per step" % (4 * (sess.store.theta.numel() + sess.store.BUCKET_TAIL))
+                                   if world > 1 else None,
                      "steps": args.train_steps, "loss": float(tout["stats"][0].item()),
                      "global_norm": float(tout["global_norm"].item()),
-                     "what": "forward + backward through T steps + gradient all-reduce (world %d) + L2/clip/Adam" % world}
+                     "what": "forward + backward through T steps + gradient all-reduce (world %d) + L2/clip/Adam: the step "
+                             "north_star scales over GPUs (whole-job mp-steps/s = n_gpus * steps * T / max-over-ranks time; "
+                             "the forward-only `value` has no collective)" % world}
         except Exception as exc:   # noqa: BLE001 -- reported, not swallowed
             train = {"error": "%s: %s" % (type(exc).__name__, exc)}
         sess.run(tspgnn.global_variables_initializer(seed=0))   # restore the benchmark weights
@@ -266,6 +285,43 @@ def main():
             _lib.call("tspgnn_spmm_pair_f32", _lib.ptr(adj.uv), _lib.ptr(X), _lib.ptr(Y), _lib.ptr(rowptr), _lib.ptr(eid),
                       _lib.ptr(Z), _lib.ptr(Vout), M, N, d, st)
 
+        # ---- the V<-E row-sum WHERE IT RUNS: the replayed forward with and without its row-sum launches (the skipped
+        # aggregates are whatever the buffers held: timing only), alternating, difference / T.  Includes the launch
+        # boundary the kernel adds to the pass -- what the pass actually pays for the aggregation.
+        rowsum_in_fwd_us = None
+        if use_graph and args.mode == "forward":
+            from tspgnn.graphnn import DeviceAdjacency
+            full = sess.capture_forward(dev_batch)
+            orig_matmul = DeviceAdjacency.matmul
+            skipped = [0]
+
+            def no_rowsum(self_, y, transpose=False, out=None):
+                if transpose and out is not None:
+                    skipped[0] += 1
+                    return out
+                return orig_matmul(self_, y, transpose=transpose, out=out)
+            DeviceAdjacency.matmul = no_rowsum
+            try:
+                without = sess.capture_forward(dev_batch)
+            finally:
+                DeviceAdjacency.matmul = orig_matmul
+            if skipped[0]:
+                def t_replays(fn, n=20):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t0) / n
+                for fn in (full, without):
+                    t_replays(fn, 5)
+                d_full, d_wo = [], []
+                for _ in range(5):
+                    d_full.append(t_replays(full))
+                    d_wo.append(t_replays(without))
+                rowsum_in_fwd_us = (float(np.median(d_full)) - float(np.median(d_wo))) * 1e6 / T
+            sess.forward_device(dev_batch)   # (leave valid aggregates / outputs behind)
+
         t_gather, t_rowsum, t_two = time_loop([gather]), time_loop([rowsum]), time_loop([gather, rowsum])
         t_pair = t_two if bf16 else time_loop([pair])   # (the bf16-storage kernels have no one-launch pair)
         pair_gbs = (gather_b + rowsum_b) / (t_pair * 1e-6) / 1e9
@@ -299,25 +355,46 @@ def main():
                             "frac": round(bytes_ / pus / 1e3 / HBM_PEAK_GBS, 4), "traffic_bytes": pf.get("traffic_bytes"),
                             "source": "profiles/r02_spmm_pmc_traffic.json in_forward (rocprofv3 --kernel-trace --pmc, "
                                       "tools/forward_only.py)"}
-        roofline = {
-            "kernel": ("tspgnn_gather2_sum_bf16 + tspgnn_csr_rowsum_bf16 (the two aggregation launches of one step)" if bf16
-                       else "tspgnn_spmm_pair_f32 (E<-V gather + V<-E CSR row-sum of one step in one launch)"),
-            "bound": "hbm", "achieved": round(pair_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(pair_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+        rk = "tspgnn_csr_rowsum_" + sfx
+        micro = {
+            "kernel": ("MICRO-LOOP, not the forward: tspgnn_gather2_sum_bf16 + tspgnn_csr_rowsum_bf16 back to back" if bf16
+                       else "MICRO-LOOP, not the forward: tspgnn_spmm_pair_f32 (E<-V gather + V<-E CSR row-sum of one step "
+                            "in one launch) back to back on a cache-resident operand"),
+            "achieved": round(pair_gbs, 1), "frac": round(pair_gbs / HBM_PEAK_GBS, 4), "unit": "GB/s", "traffic": traffic,
             "traffic_source": traffic_src,
-            "in_forward": in_forward,
-            "algorithmic_bytes_per_launch": {"gather2_sum": gather_b, "csr_rowsum": rowsum_b},
             "avg_us": {"gather2_sum": round(t_gather, 2), "csr_rowsum": round(t_rowsum, 2), "pair": round(t_pair, 2),
                        "two_launches": round(t_two, 2)},
             "per_kernel_GBs": {"gather2_sum": round(gather_b / t_gather / 1e3, 1),
                                "csr_rowsum": round(rowsum_b / t_rowsum / 1e3, 1)},
-            "spmm_steps_per_s": round(1e6 / t_pair, 1),
-            "incidences_per_s": round(4 * M * 1e6 / t_pair, 1),
-            "note": "north_star's target kernel, measured back to back on the benchmark batch (HIP events on the launch "
-                    "stream, 300 launches).  In the timed forward the V<-E direction is the row-sum kernel -- `in_forward` "
-                    "gives its duration and roofline fraction THERE, reading messages the cell launch has just "
-                    "written -- and the E<-V gather is folded into the edge cell's operand load (Zx[u] + Zx[v] inside "
-                    "the fused cell launch, whose figures are in roofline_dense).",
+            "spmm_steps_per_s": round(1e6 / t_pair, 1), "incidences_per_s": round(4 * M * 1e6 / t_pair, 1),
+            "how": "HIP events on the launch stream, 300 launches of the same operands",
+        }
+        if rowsum_in_fwd_us and rowsum_in_fwd_us > 0:
+            where_us, where_how = rowsum_in_fwd_us, ("replayed HIP graph of the timed forward with and without its %d row-sum "
+                                                     "launches, medians of 5 x 20 alternating replays, difference / T "
+                                                     "(includes the launch boundary the kernel adds)" % T)
+        elif rk in kernels_us:
+            where_us, where_how = kernels_us[rk]["avg_us"], "HIP events around each launch in the eager forward"
+        else:
+            where_us, where_how = t_rowsum, "micro-loop (no row-sum launch in this forward)"
+        rs_traffic = None
+        for _gk, pf in sorted(prof_fwd.get("csr_rowsum", {}).items()):
+            rs_traffic = pf.get("traffic_bytes", rs_traffic)
+        roofline = {
+            "kernel": "%s IN THE TIMED FORWARD: the V<-E aggregation launch of a message-passing step, reading the messages "
+                      "the cell launch has just written (the E<-V direction has no launch of its own: Zx[u] + Zx[v] is the "
+                      "edge cell's operand gather inside the fused launch, see roofline_dense)" % rk,
+            "bound": "hbm", "achieved": round(rowsum_b / where_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(rowsum_b / where_us / 1e3 / HBM_PEAK_GBS, 4), "avg_us": round(where_us, 2), "how": where_how,
+            "traffic": rs_traffic,
+            "traffic_source": ("profiles/r02_spmm_pmc_traffic.json in_forward.csr_rowsum (rocprofv3 --kernel-trace --pmc "
+                               "FETCH_SIZE / WRITE_SIZE, separate passes, tools/forward_only.py)") if rs_traffic else None,
+            "algorithmic_bytes_per_launch": {"gather2_sum": gather_b, "csr_rowsum": rowsum_b},
+            "in_forward": in_forward,
+            "micro_loop": micro,
+            "note": "north_star's target kernel where the product executes it.  `micro_loop` is the same kernel family timed "
+                    "back to back on one operand (SURVEY 8d M1 i) and is labelled as such; `in_forward` holds the per-launch "
+                    "HIP-event and rocprofv3 views of the same launches.",
         }
         dense_names = ("tspgnn_mlp_fwd_f32", "tspgnn_mlp_fwd_multi_f32", "tspgnn_lnlstm_fwd_f32",
                        "tspgnn_lnlstm_fwd_multi_f32", "tspgnn_lnlstm_gather_fwd_f32", "tspgnn_linear_f32",

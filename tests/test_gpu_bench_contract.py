@@ -52,3 +52,18 @@ def test_bench_two_ranks_gloo_on_one_gpu(cuda_device):
     assert r["config"]["global_batch"] == 2 * r["config"]["per_gpu_batch"]
     assert abs(r["value"] - 2 * 32 * 1e3 / r["ms_per_step"]) / r["value"] < 1e-3      # whole-job aggregate
     assert "error" not in r["train"] and "world 2" in r["train"]["what"]
+
+
+def test_bench_spawns_its_own_ranks(cuda_device):
+    """`python bench.py --gpus 2` without a launcher (WORLD_SIZE unset) starts one rank per GPU itself -- the way the
+    driver calls `--gpus 1` -- and still prints exactly one JSON line; the training block carries the scaling fields."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TSPGNN_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--train-steps", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["train"]["n_gpus"] == 2 and r["train"]["scaling"] == "weak"
+    assert r["train"]["value"] > 0 and "all-reduce" in r["train"]["collective"]

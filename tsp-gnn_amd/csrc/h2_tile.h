@@ -48,7 +48,9 @@ __device__ __forceinline__ void split2w(const float (&x)[8], f16x8& hi, f16x8& l
         float r0, r1;
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x[i]));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x[i + 1]));
+#if !defined(H2_NO_WITNESS)   // (A/B builds only: the price of the guard)
         asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(wit) : "v"(r0), "v"(r1));
+#endif
         const f32x2 r = {r0, r1};
         const f16x2 l = __builtin_convertvector(r, f16x2);
         hi[i] = h[0];
