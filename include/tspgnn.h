@@ -359,9 +359,30 @@ typedef struct tspgnn_mlp_bwd_task {
     const int32_t* uv;                    /* optional, [rows,2]: gather-init mode -- dY is an [n_src,d] array and the chain
                                              starts from dY[uv[r][0]] + dY[uv[r][1]], i.e. the adjoint of the V<-E row-sum
                                              (EV x dY, graphnn.py:156-160 with adjoint_a) without materialising it */
+    int acts_bf16;                        /* != 0: acts (and Yout) are bf16 arrays -- the tape of the bf16-storage mode; they
+                                             only decide the relu masks.  The tasks of one launch share the flag */
 } tspgnn_mlp_bwd_task;    /* fields as the arguments of tspgnn_mlp_bwd_f32 (uv = NULL there) */
 
 int tspgnn_lnlstm_bwd_multi_f32(const tspgnn_lstm_bwd_task* tasks, int n_tasks, int d, void* stream);
+
+/*
+ * Training in the bf16-storage mode (model.py:160-167 with graphnn.py:18's float_dtype): backward kernels that read the
+ * bf16 TAPE the forward wrote -- no widened copies -- and multiply on the bf16 matrix cores.  Gradients are fp32.
+ *   tspgnn_lnlstm_bwd_multi_bf16: tspgnn_lstm_bwd_task with x, h (row-major) and Zx (projected-message format above) as
+ *     bf16 arrays and K = the bf16 packing of the kernel (piece 0 of tspgnn_pack_weights_x3; Kh in gather-init mode);
+ *     c, dh_out, dc_out, dz, dc_in, ln, ln_grad, workspace fp32 as in tspgnn_lnlstm_bwd_multi_f32.  z is recomputed with
+ *     one bf16 MFMA per product (both operands are bf16-exact: the forward's own z).  KT / dxh / zbias must be NULL.
+ *     d in {32, 64, 128}; at d = 128 Kh[128,512] is resident in LDS (128 KB).
+ *   tspgnn_linear_bf16w_f32: tspgnn_linear_f32 with Wp = the bf16 packing of a bf16-exact W[kin, n1+n2] (e.g. K^T for
+ *     [dx | dh] = dz K^T); X fp32, split into two bf16 pieces (16 significand bits), two MFMAs per product.
+ *   tspgnn_wgrad_bf16x_f32: tspgnn_wgrad_f32 with X a bf16 array (h, messages, hidden activations of the tape): three
+ *     bf16 MFMA terms per product (X exact, dY in three pieces); kin and nout multiples of 64 (else TSPGNN_EUNSUPPORTED).
+ */
+int tspgnn_lnlstm_bwd_multi_bf16(const tspgnn_lstm_bwd_task* tasks, int n_tasks, int d, void* stream);
+int tspgnn_linear_bf16w_f32(const float* X, int kin, const void* Wp, float* Y1, int n1, float* Y2, int n2,
+                            int accumulate_y2, int rows, void* stream);
+int tspgnn_wgrad_bf16x_f32(const void* X, const float* dY, long long rows, int kin, int nout, float* dW, float* db,
+                           float* workspace, void* stream);
 /*
  * tspgnn_lnlstm_bwd_multi_f32 with both GEMMs (the recomputation of z and dh = dz Kh^T) on the fp16 matrix cores
  * (f16x2, csrc/dense_bwd_h2.hip).  Same task structure; d in {32, 64}, dx a multiple of 32, K (and K^T) resident in LDS:

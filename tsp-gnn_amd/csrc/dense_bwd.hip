@@ -7,6 +7,7 @@
 //                   a deterministic two-stage reduction (per-chunk partials, then one pass over chunks)
 #include "common.h"
 #include "mfma_tile.h"
+#include "bf16_tile.h"
 #include "lstm_bwd_tile.h"
 
 namespace tspgnn {
@@ -357,7 +358,8 @@ struct MlpBwdTaskTable {
     int n;
 };
 
-template <int D, int MAXL>
+// ABF16: the saved activations (and Yout) are the bf16 arrays of a bf16-storage tape -- they only decide the relu masks.
+template <int D, int MAXL, bool ABF16>
 __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdTaskTable tt) {
     int k = 0;
     while (k + 1 < tt.n && (int)blockIdx.x >= tt.blk_end[k]) ++k;
@@ -407,12 +409,23 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(const MlpBwdTaskTable tt) 
         }
         for (int l = n_layers - 1; l >= 0; --l) {
             if ((relu_mask >> l) & 1u) {
-                const float* A = (l == n_layers - 1) ? Yout : acts + (size_t)l * acts_stride;
+                if constexpr (ABF16) {
+                    const __bf16* A = (l == n_layers - 1) ? reinterpret_cast<const __bf16*>(Yout)
+                                                          : reinterpret_cast<const __bf16*>(acts) + (size_t)l * acts_stride;
 #pragma unroll
-                for (int q = 0; q < NT; ++q) {
-                    const f32x4 av = ld4(A + rbase + q * 16);
+                    for (int q = 0; q < NT; ++q) {
+                        const f32x4 av = widen(ldw4(A + rbase + q * 16));
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a[q][r] = av[r] > 0.f ? a[q][r] : 0.f;
+                        for (int r = 0; r < 4; ++r) a[q][r] = av[r] > 0.f ? a[q][r] : 0.f;
+                    }
+                } else {
+                    const float* A = (l == n_layers - 1) ? Yout : acts + (size_t)l * acts_stride;
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        const f32x4 av = ld4(A + rbase + q * 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a[q][r] = av[r] > 0.f ? a[q][r] : 0.f;
+                    }
                 }
             }
             if (dpre != nullptr && valid) {
@@ -564,6 +577,9 @@ __device__ __forceinline__ void split3_w(const float (&x)[8], bf16x8_w& hi, bf16
     }
 }
 
+// XB: X is a bf16 array (a bf16-storage tape: h, messages, hidden activations) -- bf16-exact, so its split is the value
+// itself and a product needs three MFMA terms instead of six, and half the bytes of X are read.
+template <bool XB>
 __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                        long long rows, int kin, int nout, float* __restrict__ P,
                                                        float* __restrict__ Pb, int n_chunks, long long chunk_rows) {
@@ -574,6 +590,7 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
     const int c = (int)(w / nob), ob = (int)(w % nob), ib = ob / nbj, jb = ob % nbj;
     const long long r_beg = c * chunk_rows, r_end = min(rows, r_beg + chunk_rows);
     const float* xp = X + (size_t)ib * 64 + fl * 4;
+    const __bf16* xpb = reinterpret_cast<const __bf16*>(X) + (size_t)ib * 64 + fl * 4;
     const float* yp = dY + (size_t)jb * 64 + fl * 4;
     f32x4 acc[4][4];
 #pragma unroll
@@ -588,7 +605,8 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
             const long long r = r0 + 8 * g + j;
             const bool ok = r < r_end;
             const long long rr = ok ? r : r_beg;
-            a[j] = ld4(xp + rr * kin);
+            if constexpr (XB) a[j] = widen(ldw4(xpb + rr * kin));
+            else a[j] = ld4(xp + rr * kin);
             b[j] = ld4(yp + rr * nout);
             if (!ok) {
                 a[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -616,10 +634,12 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 f32x4 d = acc[m][n];
-                d = MFMA_BF16_W(al[m], bh, d);  // smallest terms first
-                d = MFMA_BF16_W(am[m], bm, d);
+                if constexpr (!XB) {
+                    d = MFMA_BF16_W(al[m], bh, d);  // smallest terms first
+                    d = MFMA_BF16_W(am[m], bm, d);
+                }
                 d = MFMA_BF16_W(ah[m], bl, d);
-                d = MFMA_BF16_W(am[m], bh, d);
+                if constexpr (!XB) d = MFMA_BF16_W(am[m], bh, d);
                 d = MFMA_BF16_W(ah[m], bm, d);
                 d = MFMA_BF16_W(ah[m], bh, d);
                 acc[m][n] = d;
@@ -790,7 +810,9 @@ static int launch_mlp_bwd(const tspgnn_mlp_bwd_task* tasks, int n, hipStream_t s
     const long long max_grid = (tiles_all + nw - 1) / nw;
     if (grid > max_grid) grid = (int)max_grid;
     grid = split_blocks_bwd(cost, n, grid, tt.blk_end);
-    mlp_bwd_kernel<D, MAXL><<<grid, nw * 64, 0, st>>>(tt);
+    // (one flag per launch: the tasks of a launch come from one tape)
+    if (tasks[0].acts_bf16) mlp_bwd_kernel<D, MAXL, true><<<grid, nw * 64, 0, st>>>(tt);
+    else mlp_bwd_kernel<D, MAXL, false><<<grid, nw * 64, 0, st>>>(tt);
     return launched("tspgnn_mlp_bwd_f32");
 }
 
@@ -893,6 +915,7 @@ extern "C" int tspgnn_mlp_bwd_multi_f32(const tspgnn_mlp_bwd_task* tasks, int n_
         const unsigned inner = t.relu_mask & ((1u << (t.n_layers - 1)) - 1u);
         TSPGNN_REQUIRE(!inner || t.acts, "mlp_bwd: relu layers need the saved activations");
         TSPGNN_REQUIRE(!((t.relu_mask >> (t.n_layers - 1)) & 1u) || t.Yout, "mlp_bwd: relu on the last layer needs Yout");
+        TSPGNN_REQUIRE(n == 0 || (t.acts_bf16 != 0) == (live[0].acts_bf16 != 0), "mlp_bwd: the tasks of a launch share acts_bf16");
         live[n++] = t;
     }
     if (n == 0) return TSPGNN_OK;
@@ -908,7 +931,7 @@ extern "C" int tspgnn_mlp_bwd_f32(const float* dY, const float* wt, const float*
                                   const float* Yout, float* dpre, long long dpre_stride, float* dX, int accumulate_dx,
                                   int rows, int d, int n_layers, unsigned relu_mask, void* stream) {
     const tspgnn_mlp_bwd_task t = {dY, wt, acts, acts_stride, Yout, dpre, dpre_stride, dX, accumulate_dx, rows, n_layers,
-                                   relu_mask, nullptr};
+                                   relu_mask, nullptr, 0};
     return tspgnn_mlp_bwd_multi_f32(&t, 1, d, stream);
 }
 
@@ -918,6 +941,29 @@ extern "C" long long tspgnn_wgrad_workspace_floats(long long rows, int kin, int 
     long long cr;
     wgrad_plan(rows, kin, nout, &nc, &cr);
     return (long long)nc * ((long long)kin * nout + nout);
+}
+
+extern "C" int tspgnn_wgrad_bf16x_f32(const void* X, const float* dY, long long rows, int kin, int nout, float* dW,
+                                      float* db, float* workspace, void* stream) {
+    TSPGNN_REQUIRE(rows >= 0, "wgrad_bf16x: rows=%lld", rows);
+    if (kin <= 0 || nout <= 0 || kin % 64 || nout % 64)
+        return fail(TSPGNN_EUNSUPPORTED, "wgrad_bf16x: kin=%d and nout=%d must be positive multiples of 64", kin, nout);
+    if (rows == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(X && dY && dW && workspace, "wgrad_bf16x: null pointer");
+    int nc;
+    long long cr;
+    wgrad_plan(rows, kin, nout, &nc, &cr);
+    float* P = workspace;
+    float* Pb = db ? workspace + (size_t)nc * kin * nout : nullptr;
+    hipStream_t st = as_stream(stream);
+    const int nob = (kin / 64) * (nout / 64);
+    const unsigned grid = (unsigned)(((long long)nc * nob + 3) / 4);
+    wgrad_x3_kernel<true><<<grid, 256, 0, st>>>(reinterpret_cast<const float*>(X), dY, rows, kin, nout, P, Pb, nc, cr);
+    int rc = launched("tspgnn_wgrad_bf16x_f32");
+    if (rc) return rc;
+    const int n = kin * nout;
+    reduce_partials2(P, nc, n, dW, n, Pb, nout, db, db ? nout : 0, 1.0f, 1, st);
+    return launched("tspgnn_wgrad_bf16x_f32(reduce)");
 }
 
 extern "C" int tspgnn_wgrad_f32(const float* X, const float* dY, long long rows, int kin, int nout, float* dW,
@@ -939,7 +985,7 @@ extern "C" int tspgnn_wgrad_f32(const float* X, const float* dY, long long rows,
     if (av == 4 && bv == 4 && rows >= 4096) {   // the big reductions over T*rows: bf16 matrix cores, fp32-class accuracy
         const int nob = (kin / 64) * (nout / 64);
         const unsigned grid = (unsigned)(((long long)nc * nob + 3) / 4);
-        wgrad_x3_kernel<<<grid, 256, 0, st>>>(X, dY, rows, kin, nout, P, Pb, nc, cr);
+        wgrad_x3_kernel<false><<<grid, 256, 0, st>>>(X, dY, rows, kin, nout, P, Pb, nc, cr);
         rc = launched("tspgnn_wgrad_f32");
     } else if (av == 4 && bv == 4) TSPGNN_WG(4, 4);
     else if (av == 4 && bv == 2) TSPGNN_WG(4, 2);

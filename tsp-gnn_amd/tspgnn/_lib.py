@@ -43,6 +43,9 @@ SIGNATURES = {
     "tspgnn_lnlstm_mlp_fwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_bwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_lnlstm_bwd_multi_bf16": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_linear_bf16w_f32": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tspgnn_wgrad_bf16x_f32": [c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "tspgnn_lnlstm_bwd_finish_f32": [c_void_p, c_void_p, c_int, c_void_p],
     "tspgnn_mlp_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_gather_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -133,7 +136,7 @@ class MlpBwdTask(ctypes.Structure):
     """tspgnn_mlp_bwd_task (include/tspgnn.h)."""
     _fields_ = [("dY", c_void_p), ("wt", c_void_p), ("acts", c_void_p), ("acts_stride", c_longlong), ("Yout", c_void_p),
                 ("dpre", c_void_p), ("dpre_stride", c_longlong), ("dX", c_void_p), ("accumulate_dx", c_int),
-                ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint), ("uv", c_void_p)]
+                ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint), ("uv", c_void_p), ("acts_bf16", c_int)]
 
 
 class TspgnnError(RuntimeError):

@@ -20,7 +20,7 @@ import torch
 from . import _lib
 from . import variables as V
 from .instance_loader import SparseEV
-from .mlp import Mlp
+from .mlp import Mlp, wgrad
 
 # Field order of tf.contrib.rnn.LSTMStateTuple is (c, h); the reference constructs it by keyword
 # (graphnn.py:138).
@@ -71,9 +71,10 @@ class Tape(object):
     the forward stored (C stays fp32) and the accessors below widen a step -- or a range of steps for the weight
     gradients -- to the fp32 operands the backward kernels take."""
 
-    @staticmethod
-    def _f32(x):
-        return x if x.dtype == torch.float32 else x.to(torch.float32)
+    native = False   # bf16 tape consumed as it is by the bf16-reading backward kernels (no widened copies)
+
+    def _f32(self, x):
+        return x if (x.dtype == torch.float32 or self.native) else x.to(torch.float32)
 
     def h(self, v, t):
         return self._f32(self.H[v][t])
@@ -83,7 +84,7 @@ class Tape(object):
 
     def zx(self, v, t):
         z = self.ZX[v][t]
-        if z.dtype == torch.float32:
+        if z.dtype == torch.float32 or self.native:
             return z
         pad, w = z.shape     # bf16 projected messages, blocked by 16 rows (include/tspgnn.h) -> fp32 row-major
         return z.view(pad // 16, w // 16, 4, 16, 4).permute(0, 3, 1, 2, 4).reshape(pad, w).to(torch.float32)
@@ -91,7 +92,7 @@ class Tape(object):
     def acts_at(self, key, t):
         """(hidden activations of step t [layers-1, rows, d], element stride between layers)."""
         a = self.acts[key]
-        if a.dtype == torch.float32:
+        if a.dtype == torch.float32 or self.native:
             return a[:, t], a.stride(0)
         w = a[:, t].to(torch.float32)
         return w, w.stride(0)
@@ -508,6 +509,46 @@ class LayerNormBasicLSTMCell(object):
                                 _lib.ptr(self.ln_grad()), _lib.ptr(ws), h.shape[0], _lib.ptr(adj.uv), _lib.ptr(zx),
                                 _lib.ptr(KT), _lib.ptr(dh_in) if fuse else None, 1 if defer else 0)
 
+    # ---- bf16-storage tape (tspgnn_lnlstm_bwd_multi_bf16 and friends, include/tspgnn.h)
+    def _packed_bf16_t(self, key, rows_lo, rows_hi):
+        """bf16 packing of the TRANSPOSE of kernel rows [rows_lo, rows_hi) ([4d, rows]): W of tspgnn_linear_bf16w_f32 for
+        the data gradient dz K^T."""
+        def build(out):
+            KT = self.kernel()[rows_lo:rows_hi].t().contiguous()
+            if out is None:
+                out = torch.empty(SPLIT_BYTES["x3"] * KT.numel(), dtype=torch.uint8, device=KT.device)
+            _pack_split(self.store, "x3", KT, out, 4 * self.d, rows_hi - rows_lo)
+            return out
+        return self.store.packed((key + ".x3", self.base), build)[:2 * 4 * self.d * (rows_hi - rows_lo)]
+
+    def backward_task_bf16(self, x, h, c, dh_out, dc_out, dz, dc_in, ws, adj=None, zx=None):
+        """tspgnn_lnlstm_bwd_multi_bf16 task: x / h (and zx: the blocked projected messages, gather-init mode with adj)
+        are the tape's bf16 arrays."""
+        if adj is not None:
+            K = self._packed_bf16("lstm.kh.x3", self.dx, self.dx + self.d)
+            return _lib.LstmBwdTask(None, 0, _lib.ptr(h), _lib.ptr(c), _lib.ptr(K), _lib.ptr(self.ln()), _lib.ptr(dh_out),
+                                    _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in), _lib.ptr(self.ln_grad()), _lib.ptr(ws),
+                                    h.shape[0], _lib.ptr(adj.uv), _lib.ptr(zx), None, None, 1)
+        K = self._packed_bf16("lstm.x3", 0, self.dx + self.d)
+        return _lib.LstmBwdTask(_lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(K), _lib.ptr(self.ln()),
+                                _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in), _lib.ptr(self.ln_grad()),
+                                _lib.ptr(ws), h.shape[0], None, None, None, None, 1)
+
+    def backward_data_bf16(self, dz, dx_out, dh_in):
+        """[dx | dh] = dz K^T on the bf16 matrix cores (the weights are bf16-exact in this mode)."""
+        W = self._packed_bf16_t("lstm.T", 0, self.dx + self.d)
+        _lib.call("tspgnn_linear_bf16w_f32", _lib.ptr(dz), 4 * self.d, _lib.ptr(W), _lib.ptr(dx_out), self.dx,
+                  _lib.ptr(dh_in), self.d, 0, dz.shape[0], _lib.current_stream())
+
+    def gather_backward_data_bf16(self, adj, dz, dh_in, dzx, dy):
+        """dh = dz Kh^T, dZx = EV^T dz, dy = dZx Kx^T (gather_backward_data with bf16-exact weights)."""
+        st = _lib.current_stream()
+        _lib.call("tspgnn_linear_bf16w_f32", _lib.ptr(dz), 4 * self.d, _lib.ptr(self._packed_bf16_t("lstm.khT", self.dx,
+                  self.dx + self.d)), None, 0, _lib.ptr(dh_in), self.d, 0, dz.shape[0], st)
+        adj.matmul(dz, transpose=True, out=dzx)
+        _lib.call("tspgnn_linear_bf16w_f32", _lib.ptr(dzx), 4 * self.d, _lib.ptr(self._packed_bf16_t("lstm.kxT", 0, self.dx)),
+                  None, 0, _lib.ptr(dy), self.dx, 0, dzx.shape[0], st)
+
     def backward_finish(self, ws):
         """Fold the LayerNorm-gradient partials that the deferred backward launches of all time steps left in ws."""
         _lib.call("tspgnn_lnlstm_bwd_finish_f32", _lib.ptr(ws), _lib.ptr(self.ln_grad()), self.d, _lib.current_stream())
@@ -542,13 +583,10 @@ class LayerNormBasicLSTMCell(object):
     def backward_weights_folded(self, y_all, dzx_all, rows_src, h_all, dz_all, rows):
         """dKx += y^T dZx over T*n_src rows (instead of T*M), dKh += h^T dz over T*M rows."""
         gK = self.store.grad_view(self.base + "/kernel")
-        st = _lib.current_stream()
         ws = _lib.workspace("tspgnn_wgrad_workspace_floats", rows_src, self.dx, 4 * self.d, device=dz_all.device)
-        _lib.call("tspgnn_wgrad_f32", _lib.ptr(y_all), _lib.ptr(dzx_all), rows_src, self.dx, 4 * self.d,
-                  _lib.ptr(gK[:self.dx]), None, _lib.ptr(ws), st)
+        wgrad(y_all, dzx_all, rows_src, self.dx, 4 * self.d, gK[:self.dx], None, ws)
         ws = _lib.workspace("tspgnn_wgrad_workspace_floats", rows, self.d, 4 * self.d, device=dz_all.device)
-        _lib.call("tspgnn_wgrad_f32", _lib.ptr(h_all), _lib.ptr(dz_all), rows, self.d, 4 * self.d,
-                  _lib.ptr(gK[self.dx:]), None, _lib.ptr(ws), st)
+        wgrad(h_all, dz_all, rows, self.d, 4 * self.d, gK[self.dx:], None, ws)
 
     def backward(self, x, h, c, dh_out, dc_out, dz, dc_in, dx_out, dh_in, ws):
         """One step: (dh_out, dc_out) -> dz (kept for the weight gradient), dc_in, dx_out, dh_in; the
@@ -563,14 +601,11 @@ class LayerNormBasicLSTMCell(object):
     def backward_weights(self, x_all, h_all, dz_all, rows):
         """dK += [x|h]^T dz over all time steps at once (rows = T * rows_per_step)."""
         gK = self.store.grad_view(self.base + "/kernel")
-        st = _lib.current_stream()
         if self.dx:
             ws = _lib.workspace("tspgnn_wgrad_workspace_floats", rows, self.dx, 4 * self.d, device=dz_all.device)
-            _lib.call("tspgnn_wgrad_f32", _lib.ptr(x_all), _lib.ptr(dz_all), rows, self.dx, 4 * self.d,
-                      _lib.ptr(gK[:self.dx]), None, _lib.ptr(ws), st)
+            wgrad(x_all, dz_all, rows, self.dx, 4 * self.d, gK[:self.dx], None, ws)
         ws = _lib.workspace("tspgnn_wgrad_workspace_floats", rows, self.d, 4 * self.d, device=dz_all.device)
-        _lib.call("tspgnn_wgrad_f32", _lib.ptr(h_all), _lib.ptr(dz_all), rows, self.d, 4 * self.d,
-                  _lib.ptr(gK[self.dx:]), None, _lib.ptr(ws), st)
+        wgrad(h_all, dz_all, rows, self.d, 4 * self.d, gK[self.dx:], None, ws)
 
 
 class GraphNN(object):
@@ -1579,6 +1614,12 @@ class GraphNN(object):
         n = {v: tape.H[v].shape[1] for v in self.var}
         folded = tape.folded
         bwd_arith = "h2" if getattr(tape, "arith", None) == "h2" else None   # the cells' backward follows the forward
+        # bf16-storage tape: the bf16-reading backward kernels take the tape's arrays as they are (widths 64 / 128; the
+        # narrow widths widen slices of the tape for the fp32 kernels instead)
+        native = getattr(tape, "arith", None) == "bf16" and all(d in (64, 128) for d in self.var.values()) \
+            and all(c.dx % 64 == 0 for c in self._RNN_cells.values()) \
+            and os.environ.get("TSPGNN_BF16_BACKWARD", "native") == "native"
+        tape.native = native
         # Weight gradients are one reduction per variable over a CHUNK of time steps: all T when the gradients w.r.t.
         # the pre-activations of the chunk (4d + the MLP layers' d floats per row and step) fit the budget -- the C2
         # case, ~6 GB -- else the largest chunk that does (a C5 shard: 84 GB for all 64 steps)
@@ -1643,7 +1684,13 @@ class GraphNN(object):
             for v, d in self.var.items():
                 cell = self._RNN_cells[v]
                 h_t, c_t = tape.h(v, t), tape.C[v][t]
-                if folded[v] is not None:
+                if native:
+                    if folded[v] is not None:
+                        task = cell.backward_task_bf16(None, h_t, c_t, dH[v], dC[v], DZ[v][k], ndC[v], ws[v],
+                                                       adj=mats[folded[v]["mat"]], zx=tape.zx(v, t))
+                    else:
+                        task = cell.backward_task_bf16(tape.x(v, t), h_t, c_t, dH[v], dC[v], DZ[v][k], ndC[v], ws[v])
+                elif folded[v] is not None:
                     zx_t = tape.zx(v, t)
                     keep += [h_t, zx_t]
                     task = cell.gather_backward_task(mats[folded[v]["mat"]], zx_t, h_t, c_t, dH[v], dC[v], DZ[v][k], ndC[v],
@@ -1660,11 +1707,15 @@ class GraphNN(object):
                 tasks.setdefault(d, []).append(task)
             for d, ts in tasks.items():
                 for j in range(0, len(ts), 4):
-                    _lib.call_multi("tspgnn_lnlstm_bwd_multi_" + (bwd_arith or "f32"), ts[j:j + 4], d)
+                    _lib.call_multi("tspgnn_lnlstm_bwd_multi_" + ("bf16" if native else (bwd_arith or "f32")), ts[j:j + 4], d)
             # ---- 2: data gradients of the cell GEMMs; these WRITE dh, the message paths below ACCUMULATE into it
             for v in self.var:
                 cell = self._RNN_cells[v]
-                if folded[v] is not None:   # dX[v] becomes the gradient w.r.t. the message y (source rows)
+                if native and folded[v] is not None:
+                    cell.gather_backward_data_bf16(mats[folded[v]["mat"]], DZ[v][k], ndH[v], DZX[v][k], dX[v])
+                elif native:
+                    cell.backward_data_bf16(DZ[v][k], dX[v], ndH[v])
+                elif folded[v] is not None:   # dX[v] becomes the gradient w.r.t. the message y (source rows)
                     cell.gather_backward_data(mats[folded[v]["mat"]], DZ[v][k], None if cell.d == 64 else ndH[v],
                                               DZX[v][k], dX[v])   # (d == 64: dh was formed by the cell launch)
                 elif pushed[v]:             # dX[v] becomes the gradient w.r.t. the aggregated last hidden activation

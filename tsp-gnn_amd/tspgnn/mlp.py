@@ -27,6 +27,24 @@ def _is_relu(act):
     raise NotImplementedError("Mlp activation %r: only relu and None have HIP kernels" % (act,))
 
 
+def _bf16_flag(acts):
+    """tspgnn_mlp_bwd_task.acts_bf16: the saved activations are the bf16 arrays of a bf16-storage tape."""
+    return 1 if (acts is not None and acts.dtype == torch.bfloat16) else 0
+
+
+def wgrad(X, dY, rows, kin, nout, gW, gb, ws):
+    """gW[kin, nout] += X^T dY, gb += colsum(dY) (gb None: skip) over ``rows`` rows; X fp32, or a bf16 tape array read
+    as it is (tspgnn_wgrad_bf16x_f32: widths in multiples of 64)."""
+    if X.dtype == torch.bfloat16:
+        if kin % 64 == 0 and nout % 64 == 0:
+            _lib.call("tspgnn_wgrad_bf16x_f32", _lib.ptr(X), _lib.ptr(dY), rows, kin, nout, _lib.ptr(gW), _lib.ptr(gb),
+                      _lib.ptr(ws), _lib.current_stream())
+            return
+        X = X.to(torch.float32)    # (narrow widths have no bf16-reading reduction: widened once)
+    _lib.call("tspgnn_wgrad_f32", _lib.ptr(X), _lib.ptr(dY), rows, kin, nout, _lib.ptr(gW), _lib.ptr(gb), _lib.ptr(ws),
+              _lib.current_stream())
+
+
 class Mlp(object):
     def __init__(self, layer_sizes, output_size=None, activations=None, output_activation=None, use_bias=True,
                  kernel_initializer=None, bias_initializer=V.zeros_init, kernel_regularizer=None,
@@ -227,9 +245,11 @@ class Mlp(object):
             first = l0 == 0
             yo = y_out if last else acts[l0 + n - 1]
             dst = dX if first else torch.empty_like(dY)
-            _lib.call("tspgnn_mlp_bwd_f32", _lib.ptr(g), _lib.ptr(self.wt_packed(l0, l0 + n - 1, d)),
-                      _lib.ptr(acts[l0]) if n > 1 else None, acts_stride, _lib.ptr(yo), _lib.ptr(dpre[l0]), dpre_stride,
-                      _lib.ptr(dst), 1 if (accumulate and first) else 0, rows, d, n, self.relu_mask(l0, n), st)
+            task = _lib.MlpBwdTask(_lib.ptr(g), _lib.ptr(self.wt_packed(l0, l0 + n - 1, d)),
+                                   _lib.ptr(acts[l0]) if n > 1 else None, acts_stride, _lib.ptr(yo), _lib.ptr(dpre[l0]),
+                                   dpre_stride, _lib.ptr(dst), 1 if (accumulate and first) else 0, rows, n,
+                                   self.relu_mask(l0, n), None, _bf16_flag(acts))
+            _lib.call_multi("tspgnn_mlp_bwd_multi_f32", [task], d)
             g = dst
 
     def backward_task(self, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, gather_uv=None):
@@ -241,7 +261,7 @@ class Mlp(object):
         return _lib.MlpBwdTask(_lib.ptr(dY), _lib.ptr(self.wt_packed(0, n_sq - 1, d)), _lib.ptr(acts), acts_stride,
                                _lib.ptr(y_out), _lib.ptr(dpre), dpre_stride, _lib.ptr(dX), 1 if accumulate else 0,
                                dY.shape[0] if gather_uv is None else gather_uv.shape[0], n_sq, self.relu_mask(0, n_sq),
-                               _lib.ptr(gather_uv))
+                               _lib.ptr(gather_uv), _bf16_flag(acts))
 
     def backward_prefix_task(self, n_layers, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, gather_uv=None):
         """backward_task for the first ``n_layers`` square layers only (the rest was pushed elsewhere); ``y_out`` = the
@@ -252,7 +272,7 @@ class Mlp(object):
         return _lib.MlpBwdTask(_lib.ptr(dY), _lib.ptr(self.wt_packed(0, n_layers - 1, d)), _lib.ptr(acts), acts_stride,
                                _lib.ptr(y_out), _lib.ptr(dpre), dpre_stride, _lib.ptr(dX), 1 if accumulate else 0,
                                dY.shape[0] if gather_uv is None else gather_uv.shape[0], n_layers,
-                               self.relu_mask(0, n_layers), _lib.ptr(gather_uv))
+                               self.relu_mask(0, n_layers), _lib.ptr(gather_uv), _bf16_flag(acts))
 
     def backward_task_fuses_gather(self, dY):
         """backward_task(..., gather_uv=...) is available: one kernel covers the chain and dY is a plain fp32 array."""
@@ -266,9 +286,8 @@ class Mlp(object):
         st = _lib.current_stream()
         for l in range(n_sq if n_layers is None else n_layers):
             name = self.layer_names[l]
-            _lib.call("tspgnn_wgrad_f32", _lib.ptr(layer_inputs[l]), _lib.ptr(layer_dpre[l]), rows, d, d,
-                      _lib.ptr(self.store.grad_view(name + "/kernel")), _lib.ptr(self.store.grad_view(name + "/bias")),
-                      _lib.ptr(ws), st)
+            wgrad(layer_inputs[l], layer_dpre[l], rows, d, d, self.store.grad_view(name + "/kernel"),
+                  self.store.grad_view(name + "/bias"), ws)
 
     # ------------------------------------------------------------------ forward
     def forward_split(self, x, arith="h2"):
