@@ -658,7 +658,10 @@ def test_bf16_storage_training_gradients(cuda_device, name, d, T):
     print("\n[%s d=%d T=%d bf16 training] gradient vs teacher-forced oracle: L2 %.2e, worst per-variable %.2e; vs the oracle's "
           "own forward: L2 %.2e (its spread under a 1e-6 nudge: %.2e)" % (name, d, T, tight, worst, end_to_end, spread))
     assert abs(float(out["stats"][0].item()) - ref_out["loss"].item()) < 5e-4
-    assert tight < 5e-3 and worst < 2e-2
+    # (measured, native bf16-reading backward == widened-tape backward to the printed digits: L2 1.5e-5 .. 2.4e-3, worst
+    # variable 6e-5 .. 6.0e-3; what is left is the teacher forcing itself -- the oracle re-derives the step's bf16
+    # messages / aggregates from the forced states and may round one of them the other way than the device did)
+    assert tight < 3e-3 and worst < 8e-3
     assert end_to_end < 3 * max(spread, 1e-2)
 
 

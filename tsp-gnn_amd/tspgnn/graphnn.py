@@ -1627,7 +1627,19 @@ class GraphNN(object):
         per_step = sum(n[v] * 4 * d * 4 for v, d in self.var.items())
         per_step += sum(self._msg_MLPs[self.loop[v][i]["msg"]].n_square * n[self.loop[v][i]["var"]]
                         * self.var[self.loop[v][i]["var"]] * 4 for (v, i) in tape.acts)
-        CH = max(1, min(T, int(self.wgrad_chunk_bytes // max(per_step, 1)))) if T > 0 else 1
+        per_step += sum(tape.X[v].shape[1] * 4 * self.var[v] * 4 for v in self.var if folded[v] is not None)   # DZX
+        per_step += sum(n[v] * 4 for v in self.var if (getattr(tape, "pushed", None) or {}).get(v))          # degrees
+        if getattr(tape, "arith", None) == "bf16" and not native:
+            # widened fp32 copies of the chunk's tape slices (h, cell inputs, hidden activations) for the fp32 reductions
+            per_step += sum(n[v] * d * 4 + tape.X[v].shape[1] * tape.X[v].shape[2] * 4 for v, d in self.var.items())
+            per_step += sum(a.shape[0] * a.shape[2] * a.shape[3] * 4 for a in tape.acts.values())
+        budget = self.wgrad_chunk_bytes
+        if device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            # never more than half of what is free next to the tape (smaller devices, other HBM sizes); memory the caching
+            # allocator holds but has not handed out counts as free
+            avail = torch.cuda.mem_get_info(device)[0] + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+            budget = min(budget, avail // 2)
+        CH = max(1, min(T, int(budget // max(per_step, 1)))) if T > 0 else 1
         DZ = {v: torch.empty((CH, n[v], 4 * d), **f32) for v, d in self.var.items()}
         DPRE = {}
         for (v, i), acts in tape.acts.items():
