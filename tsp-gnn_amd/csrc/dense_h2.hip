@@ -40,12 +40,18 @@
 #ifndef H2_NT_MSG
 #define H2_NT_MSG 0     // A/B: non-temporal stores for the messages
 #endif
+#ifndef H2_PIPE_DEFER
+#define H2_PIPE_DEFER 0 // A/B (pipelined loop): a tile's message rows are stored at the top of the NEXT tile, so that no
+#endif                  // store is young when the wavefront next waits for loads (a wait behind stores drains them)
 #ifndef H2_PIPE_C
 #define H2_PIPE_C 0     // A/B (pipelined loop): the row of c prefetched with h behind the previous tile's MLP
 #endif
 #ifndef H2_NT_LOADS
 #define H2_NT_LOADS 0   // A/B: the streamed state rows (h, c: read once) loaded non-temporally, so that they do not displace
 #endif                  // the projected-message rows the gathers re-read from the CU's 32 KB L1
+#ifndef H2_ABL
+#define H2_ABL 0   // development builds, timing by removal in the tile-at-a-time edge loop: 1 no Zx gathers, 2 no state loads
+#endif             // (h, c), 4 no stores, 8 no lock-step (vertex) task
 #ifndef H2_TRACE
 #define H2_TRACE 0   // development builds: per-phase cycle sums of the edge task's tile loop (tools/h2_trace.py)
 #endif
@@ -396,7 +402,10 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     };
     // z starts at 2^s * (its non-GEMM part); Zx is stored scaled by its producer (the f16x2 projection)
     auto init_acc = [&](f32x4 (&acc)[NT4], unsigned rc) {
-        if (uv != nullptr) {
+        if ((H2_ABL & 1) && uv != nullptr) {
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.1f * t, 0.2f * rl, 0.3f * g, 0.4f};
+        } else if (uv != nullptr) {
             const int2 ends = uv[rc];
             const float* zu = Zx + h2_zx_row<D>((unsigned)ends.x, g);
             const float* zv = Zx + h2_zx_row<D>((unsigned)ends.y, g);
@@ -419,7 +428,14 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         const float* hrow = h + h2_state_row<D>(rc, g, in_blk);
         for (int kb = kb0; kb < kb1; ++kb) {
             const float* src = kb < KBX ? xrow + kb * 32 : hrow + (kb - KBX) * 2 * in_ts;
-            const f32x4 lo4 = ld4x<H2_NT_LOADS != 0>(src), hi4 = ld4x<H2_NT_LOADS != 0>(src + (kb < KBX ? 16 : in_ts));
+            f32x4 lo4, hi4;
+            if constexpr (H2_ABL & 2) {
+                lo4 = f32x4{0.01f * rl, 0.02f * g, 0.03f * kb, 0.5f};
+                hi4 = f32x4{0.5f, 0.04f * rl, 0.01f * g, 0.02f * kb};
+            } else {
+                lo4 = ld4x<H2_NT_LOADS != 0>(src);
+                hi4 = ld4x<H2_NT_LOADS != 0>(src + (kb < KBX ? 16 : in_ts));
+            }
             float xv[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
             f16x8 bh, bl;
             split2w(xv, bh, bl, wit);
@@ -430,7 +446,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     auto cell = [&](f32x4 (&acc)[NT4], f32x4 (&cf)[TPG], unsigned rc, bool valid, f32x4 (&hn)[TPG]) {
         f32x4 nc[TPG];
         lstm_gates<D, true, H2_LN_SWAP != 0>(acc, cf, lds_ln, g, hn, nc, kH2GateEps);
-        if (valid) {
+        if ((H2_ABL & 4) ? (valid && hn[0][0] == 12345.678f) : valid) {   // (ablation: the stores depend on the values, never run)
             float* hd = h_out + h2_state_row<D>(rc, g, out_blk);
             float* cd = c_out + h2_state_row<D>(rc, g, out_blk);
 #pragma unroll
@@ -495,6 +511,13 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                     cr[t] = c != nullptr ? ld4(c + h2_state_row<D>(rc0, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
             }
+#if H2_PIPE_DEFER
+            f32x4 msg_prev[TPG];
+            unsigned msg_row = 0;
+            bool msg_pending = false;
+#pragma unroll
+            for (int t = 0; t < TPG; ++t) msg_prev[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
             TR_DECL;
             while (tile < t_end) {
                 TR(0);
@@ -534,6 +557,13 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                         for (int kb = 0; kb < KBH; ++kb) asm volatile("" : "+v"(bh[kb]), "+v"(bl[kb])::"memory");
                         __builtin_amdgcn_sched_barrier(0);
                         TR(1);
+#if H2_PIPE_DEFER
+                        if (msg_pending) {   // the previous tile's messages (see H2_PIPE_DEFER)
+#pragma unroll
+                            for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (msg_row * D + g * 4 + t * 16), msg_prev[t]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
                         // second gate pair's gathers and the row of c: in flight behind the first GEMM half
                         const float* pu = Zx + h2_zx_row<D>((unsigned)ends.x, g) + HN * 256;
                         const float* pv = Zx + h2_zx_row<D>((unsigned)ends.y, g) + HN * 256;
@@ -631,10 +661,17 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                             for (int t = 0; t < TPG; ++t) st4(dst + t * 16, hn[t]);
                         }
                     }
+#if H2_PIPE_DEFER
+                    msg_pending = valid && mlp_out != nullptr;
+                    msg_row = rc;
+#pragma unroll
+                    for (int t = 0; t < TPG; ++t) msg_prev[t] = hn[t];
+#else
                     if (valid && mlp_out != nullptr) {
 #pragma unroll
                         for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                     }
+#endif
                 }
                 tile = tile_next;
                 ends = ends_next;
@@ -645,6 +682,12 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 tr_acc[7] += 1;
 #endif
             }
+#if H2_PIPE_DEFER
+            if (msg_pending) {
+#pragma unroll
+                for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (msg_row * D + g * 4 + t * 16), msg_prev[t]);
+            }
+#endif
             TR_FLUSH;
         } else
 #endif
@@ -676,7 +719,8 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
 #endif
 #pragma unroll
                 for (int t = 0; t < TPG; ++t)
-                    cf[t] = c != nullptr ? ld4x<H2_NT_LOADS != 0>(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    cf[t] = (c != nullptr && !(H2_ABL & 2)) ? ld4x<H2_NT_LOADS != 0>(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts)
+                                                                : f32x4{0.1f * t, 0.f, 0.2f * rl, 0.f};
                 kloop(acc, rc, 0, 0, KBT);
 #if H2_TRACE
 #pragma unroll
@@ -701,7 +745,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                         for (int t = 0; t < TPG; ++t) st4(dst + t * 16, hn[t]);
                     }
                 }
-                if (valid && mlp_out != nullptr) {
+                if (((H2_ABL & 4) ? hn[0][0] == 12345.678f : true) && valid && mlp_out != nullptr) {
 #pragma unroll
                     for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
@@ -722,7 +766,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         // (fewer working wavefronts per workgroup than it has -- lock_tiles -- spread the task over more CUs: its GEMMs
         // are bound by the matrix pipes of the few CUs it runs on)
         const int lw = tt.lock_tiles[k];
-        const int rounds = (tiles_total + lw - 1) / lw;
+        const int rounds = (H2_ABL & 8) ? 0 : (tiles_total + lw - 1) / lw;
         for (int r = my_blk; r < rounds; r += my_grid) {
             {
                 const int l = opaque_lane();
