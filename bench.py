@@ -328,12 +328,14 @@ def main():
         # HBM-side bytes per launch (pair) from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py):
         # profiles/r02_spmm_pmc_traffic.json, keyed by workload
         traffic, traffic_src, prof_fwd = None, None, {}
-        tpath = os.path.join(ROOT, "profiles", "r02_spmm_pmc_traffic.json")
+        tname = next((n for n in ("r03_spmm_pmc_traffic.json", "r02_spmm_pmc_traffic.json")
+                      if os.path.exists(os.path.join(ROOT, "profiles", n))), "r02_spmm_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             with open(tpath) as f:
                 ent = json.load(f).get(args.workload)
             if ent:
-                traffic, traffic_src = ent.get("pair_traffic_bytes"), "profiles/r02_spmm_pmc_traffic.json: " + ent.get("how", "")
+                traffic, traffic_src = ent.get("pair_traffic_bytes"), "profiles/%s: " % tname + ent.get("how", "")
                 prof_fwd = ent.get("in_forward", {})
         # the SAME kernels where they execute: inside the forward pass (the instrumented eager pass above -- HIP events on
         # the launch stream around every launch, operands produced by the preceding launch, not replayed from cache)
@@ -353,8 +355,7 @@ def main():
                         in_forward[kname]["rocprof"] = {
                             "avg_us": pus, "dispatches": pf.get("dispatches"), "GBs": round(bytes_ / pus / 1e3, 1),
                             "frac": round(bytes_ / pus / 1e3 / HBM_PEAK_GBS, 4), "traffic_bytes": pf.get("traffic_bytes"),
-                            "source": "profiles/r02_spmm_pmc_traffic.json in_forward (rocprofv3 --kernel-trace --pmc, "
-                                      "tools/forward_only.py)"}
+                            "source": "profiles/%s in_forward (rocprofv3 --kernel-trace --pmc, tools/forward_only.py)" % tname}
         rk = "tspgnn_csr_rowsum_" + sfx
         micro = {
             "kernel": ("MICRO-LOOP, not the forward: tspgnn_gather2_sum_bf16 + tspgnn_csr_rowsum_bf16 back to back" if bf16
@@ -387,8 +388,8 @@ def main():
             "bound": "hbm", "achieved": round(rowsum_b / where_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(rowsum_b / where_us / 1e3 / HBM_PEAK_GBS, 4), "avg_us": round(where_us, 2), "how": where_how,
             "traffic": rs_traffic,
-            "traffic_source": ("profiles/r02_spmm_pmc_traffic.json in_forward.csr_rowsum (rocprofv3 --kernel-trace --pmc "
-                               "FETCH_SIZE / WRITE_SIZE, separate passes, tools/forward_only.py)") if rs_traffic else None,
+            "traffic_source": ("profiles/%s in_forward.csr_rowsum (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, "
+                               "separate passes, tools/forward_only.py)" % tname) if rs_traffic else None,
             "algorithmic_bytes_per_launch": {"gather2_sum": gather_b, "csr_rowsum": rowsum_b},
             "in_forward": in_forward,
             "micro_loop": micro,

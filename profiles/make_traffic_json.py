@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Builds profiles/r02_spmm_pmc_traffic.json from the per-workload PMC summaries tools/profile_r02.sh leaves in
-gpurun_out/r02/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; summarize_pmc.py text).  FETCH_SIZE is doubled
+"""Builds profiles/<round>_spmm_pmc_traffic.json (round = name of the source directory) from the per-workload PMC summaries
+tools/profile_r02.sh / tools/profile_r03_all.sh leave in gpurun_out/<round>/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; summarize_pmc.py text).  FETCH_SIZE is doubled
 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md); the counters sit on the L2<->fabric side.
 Usage: python profiles/make_traffic_json.py [gpurun_out/r02]"""
 import json
@@ -65,4 +65,5 @@ for w in ("c2", "c4", "c5"):
     res[w] = ent
     print(w, "pair", ent["pair_traffic_bytes"], {t: {g: (x["traffic_bytes"], x["avg_us_under_profiler"]) for g, x in d.items()}
                                                   for t, d in ent["in_forward"].items()})
-json.dump(res, open(os.path.join(ROOT, "profiles", "r02_spmm_pmc_traffic.json"), "w"), indent=1)
+tag = os.path.basename(os.path.normpath(SRC))
+json.dump(res, open(os.path.join(ROOT, "profiles", "%s_spmm_pmc_traffic.json" % tag), "w"), indent=1)
