@@ -719,8 +719,9 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
 #endif
 #pragma unroll
                 for (int t = 0; t < TPG; ++t)
-                    cf[t] = (c != nullptr && !(H2_ABL & 2)) ? ld4x<H2_NT_LOADS != 0>(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts)
-                                                                : f32x4{0.1f * t, 0.f, 0.2f * rl, 0.f};
+                    cf[t] = (H2_ABL & 2) ? f32x4{0.1f * t, 0.f, 0.2f * rl, 0.f}
+                            : c != nullptr ? ld4x<H2_NT_LOADS != 0>(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts)
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
                 kloop(acc, rc, 0, 0, KBT);
 #if H2_TRACE
 #pragma unroll

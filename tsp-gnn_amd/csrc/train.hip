@@ -69,16 +69,23 @@ __global__ __launch_bounds__(256) void wcolsum_kernel(const float4* __restrict__
 }
 
 // ------------------------------------------------------------- E_init_MLP weight gradients
-// Workgroup = 64 edges.  Phase 1 (one thread per edge): recompute the forward chain, back-propagate
-// dE0 through it, park activations and d(pre-activations) in LDS.  Phase 2 (all 256 threads): every
-// thread owns a strided set of the 2824 (d=64) parameters and sums its outer-product entries over the
-// 64 edges.  Per-workgroup partials go to the workspace; reduce_scaled_kernel folds them.
+// Persistent workgroups over chunks of 64 edges; every thread owns a strided set of the NP parameters (2 824 at d=64,
+// 11 088 at d=128) and keeps their sums in registers across ALL of the workgroup's chunks -- one partial row per
+// workgroup (512 rows) instead of one per chunk (9 950 rows = 441 MB at the C5 shard's 636 800 edges).  Per chunk:
+//   1a (all 256 threads, four per edge): recompute the forward chain of the edge, then a quarter of
+//      d3 = relu'(a3) . (dE0 W4^T) -- the 64x128x64 product that dominated the one-thread-per-edge version -- with W4
+//      staged in LDS once per workgroup (the same element for every edge: broadcast reads);
+//   1b (one thread per edge): d2, d1 through the two small layers;
+//   2  (all threads): outer-product sums of the chunk into the thread's parameters.
+// Fixed chunk -> workgroup assignment and fixed summation order: deterministic.
 template <int D>
 __global__ __launch_bounds__(256) void einit_bwd_kernel(const float2* __restrict__ WC, const float* __restrict__ wb,
-                                                        const float* __restrict__ dE0, float* __restrict__ P, int M) {
+                                                        const float* __restrict__ dE0, float* __restrict__ P, int M,
+                                                        int n_chunks) {
     constexpr int H1 = D / 8, H2 = D / 4, H3 = D / 2;
     constexpr int NP = 2 * H1 + H1 + H1 * H2 + H2 + H2 * H3 + H3 + H3 * D + D;
-    constexpr int E = 64;
+    constexpr int NPT = (NP + 255) / 256;
+    constexpr int E = 64, KQ = H3 / 4;
     const float* W1 = wb;
     const float* b1 = W1 + 2 * H1;
     const float* W2 = b1 + H1;
@@ -89,92 +96,111 @@ __global__ __launch_bounds__(256) void einit_bwd_kernel(const float2* __restrict
     __shared__ float s_in[E][2 + 1];
     __shared__ float s_a1[E][H1 + 1], s_a2[E][H2 + 1], s_a3[E][H3 + 1];
     __shared__ float s_d1[E][H1 + 1], s_d2[E][H2 + 1], s_d3[E][H3 + 1], s_d4[E][D + 1];
-    const int e0 = blockIdx.x * E;
+    __shared__ __attribute__((aligned(16))) float s_w4[H3 * D];
     const int t = threadIdx.x;
-    // dE0 tile -> LDS (coalesced)
-    for (int i = t; i < E * D; i += blockDim.x) {
-        const int le = i / D, j = i % D;
-        s_d4[le][j] = (e0 + le < M) ? dE0[(size_t)(e0 + le) * D + j] : 0.f;
+    for (int i = t; i < H3 * D / 4; i += blockDim.x) reinterpret_cast<float4*>(s_w4)[i] = reinterpret_cast<const float4*>(W4)[i];
+    float acc[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) acc[i] = 0.f;
+    for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int e0 = chunk * E;
+        __syncthreads();   // (the previous chunk's phase 2 has read the tiles; first pass: s_w4 is complete)
+        for (int i = t; i < E * D; i += blockDim.x) {   // dE0 tile -> LDS (coalesced)
+            const int le = i / D, j = i % D;
+            s_d4[le][j] = (e0 + le < M) ? dE0[(size_t)(e0 + le) * D + j] : 0.f;
+        }
+        __syncthreads();
+        {   // 1a
+            const int le = t >> 2, q = t & 3;
+            const int e = e0 + le;
+            const bool ok = e < M;
+            const float2 wc = ok ? WC[e] : make_float2(0.f, 0.f);
+            float a1[H1], a2[H2];
+#pragma unroll
+            for (int j = 0; j < H1; ++j) a1[j] = fmaxf(fmaf(wc.y, W1[H1 + j], fmaf(wc.x, W1[j], 0.f)) + b1[j], 0.f);
+#pragma unroll
+            for (int j = 0; j < H2; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < H1; ++k) s = fmaf(a1[k], W2[k * H2 + j], s);
+                a2[j] = fmaxf(s + b2[j], 0.f);
+            }
+            // this thread's quarter of the third layer: a3[k] and d3[k] = relu'(a3[k]) * (W4[k,:] . dE0[e,:])
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int k = q * KQ + kk;
+                float a3k = b3[k];
+#pragma unroll
+                for (int j = 0; j < H2; ++j) a3k = fmaf(a2[j], W3[j * H3 + k], a3k);
+                a3k = fmaxf(a3k, 0.f);
+                float s = 0.f;
+                _Pragma("unroll 8") for (int j = 0; j < D; ++j) s = fmaf(s_w4[k * D + j], s_d4[le][j], s);
+                s_a3[le][k] = a3k;
+                s_d3[le][k] = (ok && a3k > 0.f) ? s : 0.f;
+            }
+            if (q == 0) {
+                s_in[le][0] = wc.x, s_in[le][1] = wc.y;
+#pragma unroll
+                for (int k = 0; k < H1; ++k) s_a1[le][k] = a1[k];
+#pragma unroll
+                for (int k = 0; k < H2; ++k) s_a2[le][k] = a2[k];
+            }
+        }
+        __syncthreads();
+        if (t < E) {   // 1b
+            const bool ok = e0 + t < M;
+            float d2[H2];
+#pragma unroll
+            for (int k = 0; k < H2; ++k) {
+                float s = 0.f;
+                _Pragma("unroll 8") for (int j = 0; j < H3; ++j) s = fmaf(W3[k * H3 + j], s_d3[t][j], s);
+                d2[k] = (ok && s_a2[t][k] > 0.f) ? s : 0.f;
+                s_d2[t][k] = d2[k];
+            }
+#pragma unroll
+            for (int k = 0; k < H1; ++k) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < H2; ++j) s = fmaf(W2[k * H2 + j], d2[j], s);
+                s_d1[t][k] = (ok && s_a1[t][k] > 0.f) ? s : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {   // 2
+            const int p = t + i * 256;
+            if (p >= NP) break;
+            int q = p;
+            float s = 0.f;
+            if (q < 2 * H1) {  // W1[k][j]
+                const int k = q / H1, j = q % H1;
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s = fmaf(s_in[e][k], s_d1[e][j], s);
+            } else if ((q -= 2 * H1) < H1) {
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s += s_d1[e][q];
+            } else if ((q -= H1) < H1 * H2) {
+                const int k = q / H2, j = q % H2;
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s = fmaf(s_a1[e][k], s_d2[e][j], s);
+            } else if ((q -= H1 * H2) < H2) {
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s += s_d2[e][q];
+            } else if ((q -= H2) < H2 * H3) {
+                const int k = q / H3, j = q % H3;
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s = fmaf(s_a2[e][k], s_d3[e][j], s);
+            } else if ((q -= H2 * H3) < H3) {
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s += s_d3[e][q];
+            } else if ((q -= H3) < H3 * D) {
+                const int k = q / D, j = q % D;
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s = fmaf(s_a3[e][k], s_d4[e][j], s);
+            } else {
+                q -= H3 * D;
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s += s_d4[e][q];
+            }
+            acc[i] += s;
+        }
     }
-    __syncthreads();
-    if (t < E) {
-        const int e = e0 + t;
-        const bool ok = e < M;
-        const float2 wc = ok ? WC[e] : make_float2(0.f, 0.f);
-        float a1[H1], a2[H2], a3[H3];
-#pragma unroll
-        for (int j = 0; j < H1; ++j) a1[j] = fmaxf(fmaf(wc.y, W1[H1 + j], fmaf(wc.x, W1[j], 0.f)) + b1[j], 0.f);
-#pragma unroll
-        for (int j = 0; j < H2; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < H1; ++k) s = fmaf(a1[k], W2[k * H2 + j], s);
-            a2[j] = fmaxf(s + b2[j], 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < H3; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < H2; ++k) s = fmaf(a2[k], W3[k * H3 + j], s);
-            a3[j] = fmaxf(s + b3[j], 0.f);
-        }
-        float d3[H3], d2[H2], d1[H1];
-#pragma unroll
-        for (int k = 0; k < H3; ++k) {
-            float s = 0.f;
-            for (int j = 0; j < D; ++j) s = fmaf(W4[k * D + j], s_d4[t][j], s);
-            d3[k] = a3[k] > 0.f ? s : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < H2; ++k) {
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < H3; ++j) s = fmaf(W3[k * H3 + j], d3[j], s);
-            d2[k] = a2[k] > 0.f ? s : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < H1; ++k) {
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < H2; ++j) s = fmaf(W2[k * H2 + j], d2[j], s);
-            d1[k] = a1[k] > 0.f ? s : 0.f;
-        }
-        s_in[t][0] = wc.x, s_in[t][1] = wc.y;
-#pragma unroll
-        for (int k = 0; k < H1; ++k) s_a1[t][k] = a1[k], s_d1[t][k] = ok ? d1[k] : 0.f;
-#pragma unroll
-        for (int k = 0; k < H2; ++k) s_a2[t][k] = a2[k], s_d2[t][k] = ok ? d2[k] : 0.f;
-#pragma unroll
-        for (int k = 0; k < H3; ++k) s_a3[t][k] = a3[k], s_d3[t][k] = ok ? d3[k] : 0.f;
-    }
-    __syncthreads();
     float* Pb = P + (size_t)blockIdx.x * NP;
-    for (int p = t; p < NP; p += blockDim.x) {
-        int q = p;
-        float s = 0.f;
-        if (q < 2 * H1) {  // W1[k][j]
-            const int k = q / H1, j = q % H1;
-            for (int e = 0; e < E; ++e) s = fmaf(s_in[e][k], s_d1[e][j], s);
-        } else if ((q -= 2 * H1) < H1) {
-            for (int e = 0; e < E; ++e) s += s_d1[e][q];
-        } else if ((q -= H1) < H1 * H2) {
-            const int k = q / H2, j = q % H2;
-            for (int e = 0; e < E; ++e) s = fmaf(s_a1[e][k], s_d2[e][j], s);
-        } else if ((q -= H1 * H2) < H2) {
-            for (int e = 0; e < E; ++e) s += s_d2[e][q];
-        } else if ((q -= H2) < H2 * H3) {
-            const int k = q / H3, j = q % H3;
-            for (int e = 0; e < E; ++e) s = fmaf(s_a2[e][k], s_d3[e][j], s);
-        } else if ((q -= H2 * H3) < H3) {
-            for (int e = 0; e < E; ++e) s += s_d3[e][q];
-        } else if ((q -= H3) < H3 * D) {
-            const int k = q / D, j = q % D;
-            for (int e = 0; e < E; ++e) s = fmaf(s_a3[e][k], s_d4[e][j], s);
-        } else {
-            q -= H3 * D;
-            for (int e = 0; e < E; ++e) s += s_d4[e][q];
-        }
-        Pb[p] = s;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int p = t + i * 256;
+        if (p < NP) Pb[p] = acc[i];
     }
 }
 
@@ -310,13 +336,15 @@ extern "C" int tspgnn_einit_bwd_f32(const float* WC, const float* wb, const floa
     TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "einit_bwd: d=%d must be 32, 64 or 128", d);
     if (M == 0) return TSPGNN_OK;
     TSPGNN_REQUIRE(WC && wb && dE0 && dwb && workspace, "einit_bwd: null pointer");
-    const unsigned grid = (unsigned)((M + 63) / 64);
+    const int n_chunks = (M + 63) / 64;
+    unsigned grid = (unsigned)n_cus() * (d >= 128 ? 1u : 2u);   // persistent workgroups (LDS: 1 / 2 per CU)
+    if (grid > (unsigned)n_chunks) grid = (unsigned)n_chunks;
     hipStream_t st = as_stream(stream);
     const float2* WC2 = reinterpret_cast<const float2*>(WC);
     switch (d) {
-        case 32: einit_bwd_kernel<32><<<grid, 256, 0, st>>>(WC2, wb, dE0, workspace, M); break;
-        case 64: einit_bwd_kernel<64><<<grid, 256, 0, st>>>(WC2, wb, dE0, workspace, M); break;
-        default: einit_bwd_kernel<128><<<grid, 256, 0, st>>>(WC2, wb, dE0, workspace, M); break;
+        case 32: einit_bwd_kernel<32><<<grid, 256, 0, st>>>(WC2, wb, dE0, workspace, M, n_chunks); break;
+        case 64: einit_bwd_kernel<64><<<grid, 256, 0, st>>>(WC2, wb, dE0, workspace, M, n_chunks); break;
+        default: einit_bwd_kernel<128><<<grid, 256, 0, st>>>(WC2, wb, dE0, workspace, M, n_chunks); break;
     }
     int rc = launched("tspgnn_einit_bwd_f32");
     if (rc) return rc;
