@@ -906,3 +906,31 @@ def test_training_step_survives_an_activation_overflow(cuda_device):
     for k in ends["bf16x3"]:
         assert np.all(np.isfinite(ends["f16x2"][k])), k
         assert np.array_equal(ends["f16x2"][k], ends["bf16x3"][k]), k
+
+
+def test_f16x2_falls_back_when_only_the_pushed_product_leaves_the_range(cuda_device):
+    """The pushed form multiplies with K' = [W Kx ; Kh]: W and Kx can each be inside the fp16 range while an entry of their
+    product is not (here 40 * 40 * 64 columns' worth).  The product's packing is vetted before the plan's first launch."""
+    d, T = 64, 3
+    t = pack_tuple("ragged_B6", 2)
+    params = P.init_params(d, seed=9, perturb=True)
+    wk = [k for k in params if k.endswith("E_msg_V_MLP_layer_4/kernel")][0]
+    kk = [k for k in params if k.endswith("V_cell/layer_norm_basic_lstm_cell/kernel")][0]
+    params[wk] = params[wk].copy(); params[kk] = params[kk].copy()
+    params[wk][3, :] = 40.0          # row 3 of W (in [64, 64]) ...
+    params[kk][:64, 17] = 40.0       # ... times column 17 of Kx: (W Kx)[3, 17] = 64 * 1600 = 102 400; 2^6 * that overflows
+    model = tspgnn.build_network(d)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    EV, W, C, route_exists, n_vertices, n_edges = t
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    pred, last = sess.run([model["predictions"], model["last_states"]], feed_dict=feed)
+    assert model["gnn"].active_arith() == "x3"
+    ref = TO.forward(TO.to_torch(params, torch.float64), _oracle_batch(t), T)
+    assert np.all(np.isfinite(pred)) and rel_err(pred, ref["predictions"].numpy()) < REL_TOL
+    assert rel_err(last["V"].c, ref["last_states"]["V"][1].numpy()) < REL_TOL
+    # and a training step with these variables runs on bf16x3 from its first launch
+    _, loss = sess.run([model["train_step"], model["loss"]], feed_dict=feed)
+    assert np.isfinite(loss) and all(np.all(np.isfinite(v)) for v in model.store.state_dict().values())

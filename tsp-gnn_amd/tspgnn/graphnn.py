@@ -1145,6 +1145,16 @@ class GraphNN(object):
         pre_calls = [(_lib.task_array(ts[k:k + 4]), d) for d, ts in pre.items() for k in range(0, len(ts), 4)]
         built = {}
         self._plan_keep = keep
+        # the cells' packings are made here, not at the first step: the caller vets their range (check_h2_weights) between
+        # the construction of the plan and its first launch
+        for v in self.var:
+            cell = self._RNN_cells[v]
+            if folded[v] is not None:
+                cell._packed_split(arith, "lstm.kh", cell.dx, cell.dx + cell.d)
+            elif pushed[v]:
+                cell.pushed_bias_pack(self._msg_MLPs[self.loop[v][0]["msg"]], arith=arith)
+            else:
+                cell._packed_split(arith, "lstm", 0, cell.dx + cell.d)
 
         def run(T):
             for arr, d in pre_calls:
@@ -1390,6 +1400,10 @@ class GraphNN(object):
             for mlp in self._msg_MLPs.values():
                 if len(mlp._chunks()) == 1:
                     mlp.wb_packed_split("h2", 0, mlp.n_square - 1, mlp.sizes[-1])
+            if self.push_training and not self.fuse_training_messages:
+                for v in self.var:   # a pushed cell multiplies with the PRODUCT W Kx, which can leave the range on its own
+                    if self._pushable(v, mats, tape.folded):
+                        self._RNN_cells[v].pushed_bias_pack(self._msg_MLPs[self.loop[v][0]["msg"]], arith="h2")
             if not self.check_h2_weights():
                 arith = self._split_arith({v: initial_embeddings[v].shape[0] for v in self.var})
         tape.arith = arith
