@@ -223,7 +223,38 @@ struct LstmTableB {
     int n;
 };
 
-template <int D, int NW>
+// Pieces of the staged gather-init tile (below): the raw projected-message rows of one gate range, the accumulator
+// start z = Zx[u] + Zx[v], and the h Kh product of that range with the weight fragments PF deep in flight ahead of the
+// MFMAs (an LDS read is ~100 cycles, an MFMA 16: read-then-multiply in program order leaves the matrix pipe idle).
+template <int T0, int TN>
+__device__ __forceinline__ void zx_load_part(bf16x4 (&ru)[TN], bf16x4 (&rv)[TN], const __bf16* zu, const __bf16* zv) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t) ru[t] = ldw4(zu + (T0 + t) * 256);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) rv[t] = ldw4(zv + (T0 + t) * 256);
+}
+template <int D, int T0, int TN, int PF>
+__device__ __forceinline__ void gather_gemm_part(f32x4 (&acc)[TN], const bf16x4 (&ru)[TN], const bf16x4 (&rv)[TN],
+                                                 const __bf16* lds_w, const bf16x8 (&bv)[D / 32], int g, int rl) {
+    constexpr int NT4 = D / 4, KB = D / 32, TOTAL = KB * TN;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[t] = widen(ru[t]) + widen(rv[t]);
+    const __bf16* base = lds_w + ((size_t)g * NT4 * 16 + rl) * 8 + T0 * 128;   // + kb * 4 * NT4 * 128 + t * 128
+    bf16x8 a[PF + 1];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) a[i] = ldw8(base + (i / TN) * (4 * NT4 * 128) + (i % TN) * 128);
+#pragma unroll
+    for (int i = 0; i < TOTAL; ++i) {
+        if (i + PF < TOTAL) a[(i + PF) % (PF + 1)] = ldw8(base + ((i + PF) / TN) * (4 * NT4 * 128) + ((i + PF) % TN) * 128);
+        acc[i % TN] = MFMA_BF16(a[i % (PF + 1)], bv[i / TN], acc[i % TN]);
+    }
+}
+
+// STAGED: a resident gather-init (edge) task forms z gate by gate -- f, then (i, j), then o (mfma_tile.h's three
+// stages, bit-identical to the one-stage cell) -- with at most 64 accumulator registers live, which leaves room for
+// what the all-gates form at d = 128 (254 registers) cannot afford: every global load of a stage issued a stage ahead,
+// the weight fragments prefetched, the next tile's endpoints fetched a tile ahead, and a third wavefront per SIMD.
+template <int D, int NW, bool STAGED>
 __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTableB tt) {
     constexpr int NT4 = D / 4, TPG = D / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -308,18 +339,75 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTabl
         const int t_end = (int)((long long)tiles_total * (pos + 1) / my_grid);
         if (tid == 0) *ticket = t_beg;
         __syncthreads();
-        for (;;) {
-            int tile = 0;
-            if (lane == 0) tile = atomicAdd(ticket, 1);
-            tile = __builtin_amdgcn_readfirstlane(tile);
-            if (tile >= t_end) break;
-            const int row = tile * 16 + rl;
-            const bool valid = row < rows;
-            const size_t rc = (size_t)(valid ? row : rows - 1);
-            f32x4 acc[NT4];
-            init_acc(acc, rc);
-            kloop(acc, rc, 0, 0, KBT);
-            cell(acc, rc, valid);
+        if (STAGED && uv != nullptr) {
+            auto next_ticket = [&]() {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(ticket, 1);
+                return __builtin_amdgcn_readfirstlane(t);
+            };
+            auto row_of = [&](int tile) { return (unsigned)min(tile * 16 + rl, rows - 1); };
+            int tile = next_ticket();
+            int2 ends = uv[row_of(tile < t_end ? tile : t_beg)];
+            while (tile < t_end) {
+                const int ntile = next_ticket();
+                const bool valid = tile * 16 + rl < rows;
+                const unsigned rc = row_of(tile);
+                const __bf16* zu = Zx + zx_blocked<D>((unsigned)ends.x, g);
+                const __bf16* zv = Zx + zx_blocked<D>((unsigned)ends.y, g);
+                bf16x4 fu[TPG], fv[TPG];
+                zx_load_part<2 * TPG, TPG>(fu, fv, zu, zv);
+                const __bf16* hrow = h + c_blocked<D>(rc, g, c_in_blk);
+                bf16x8 bv[D / 32];
+#pragma unroll
+                for (int kb = 0; kb < D / 32; ++kb) bv[kb] = row_operand(hrow, kb, c_in_blk);
+                f32x4 cs[TPG];
+#pragma unroll
+                for (int t = 0; t < TPG; ++t) cs[t] = ld4(c + c_blocked<D>(rc, g, c_in_blk) + t * (c_in_blk ? 256 : 16));
+                ends = uv[row_of(ntile < t_end ? ntile : tile)];   // the next tile's endpoints, a tile ahead
+                bf16x4 iu[2 * TPG], iv[2 * TPG];
+                zx_load_part<0, 2 * TPG>(iu, iv, zu, zv);           // stage (i, j)'s rows behind stage f's product
+                constexpr int PF = 4;                               // weight fragments in flight
+                bf16x4 ou[TPG], ov[TPG];
+                {
+                    f32x4 zf[TPG];
+                    gather_gemm_part<D, 2 * TPG, TPG, PF>(zf, fu, fv, lds_w, bv, g, rl);
+                    zx_load_part<3 * TPG, TPG>(ou, ov, zu, zv);     // stage o's rows behind stage (i, j)'s product
+                    lstm_stage_f<D, true>(zf, cs, lds_ln, g);
+                }
+                {
+                    f32x4 zij[2 * TPG];
+                    gather_gemm_part<D, 0, 2 * TPG, PF>(zij, iu, iv, lds_w, bv, g, rl);
+                    lstm_stage_ij<D, true>(zij, cs, lds_ln, g);
+                }
+                f32x4 hn[TPG];
+                {
+                    f32x4 zo[TPG];
+                    gather_gemm_part<D, 3 * TPG, TPG, PF>(zo, ou, ov, lds_w, bv, g, rl);
+                    lstm_stage_o<D, true>(zo, cs, lds_ln, g, hn);
+                }
+                if (valid) {   // (all stores after the tile's last load: a wait behind mixed loads and stores is vmcnt(0))
+#pragma unroll
+                    for (int t = 0; t < TPG; ++t) {
+                        st4(c_out + c_blocked<D>(rc, g, c_out_blk) + t * (c_out_blk ? 256 : 16), cs[t]);
+                        stw4(h_out + c_blocked<D>(rc, g, c_out_blk) + t * (c_out_blk ? 256 : 16), narrow(hn[t]));
+                    }
+                }
+                tile = ntile;
+            }
+        } else {
+            for (;;) {
+                int tile = 0;
+                if (lane == 0) tile = atomicAdd(ticket, 1);
+                tile = __builtin_amdgcn_readfirstlane(tile);
+                if (tile >= t_end) break;
+                const int row = tile * 16 + rl;
+                const bool valid = row < rows;
+                const size_t rc = (size_t)(valid ? row : rows - 1);
+                f32x4 acc[NT4];
+                init_acc(acc, rc);
+                kloop(acc, rc, 0, 0, KBT);
+                cell(acc, rc, valid);
+            }
         }
     } else {
         const int rounds = (tiles_total + NW - 1) / NW;
@@ -372,7 +460,7 @@ static int launch_mlp_b(const tspgnn_mlp_task_bf16* tasks, int n, hipStream_t st
     return launched("tspgnn_mlp_fwd_multi_bf16");
 }
 
-template <int D, int NW>
+template <int D, int NW, bool STAGED>
 static int launch_lstm_b(const tspgnn_lstm_task_bf16* tasks, int n, hipStream_t st) {
     const size_t head = (10 * D + 4) * sizeof(float);
     const size_t per_kb = (size_t)32 * 4 * D * 2;
@@ -399,10 +487,10 @@ static int launch_lstm_b(const tspgnn_lstm_task_bf16* tasks, int n, hipStream_t 
     const long long max_grid = (tiles_all + NW - 1) / NW;
     if (grid > max_grid) grid = (int)max_grid;
     grid = split_blocks_b(cost, n, grid, tt.blk_end);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlstm_fwd_bf16_kernel<D, NW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlstm_fwd_bf16_kernel<D, NW, STAGED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail((int)e, "lnlstm_fwd_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    lnlstm_fwd_bf16_kernel<D, NW><<<grid, NW * 64, lds_bytes, st>>>(tt);
+    lnlstm_fwd_bf16_kernel<D, NW, STAGED><<<grid, NW * 64, lds_bytes, st>>>(tt);
     return launched("tspgnn_lnlstm_fwd_multi_bf16");
 }
 
@@ -469,6 +557,16 @@ extern "C" int tspgnn_mlp_fwd_multi_bf16(const tspgnn_mlp_task_bf16* tasks, int 
     return proj ? launch_mlp_b<128, 8, true>(live, n, st) : launch_mlp_b<128, 16, false>(live, n, st);
 }
 
+// development switch TSPGNN_BF16_CELL: 0 = all gates at once; 8 = staged (default)
+static int bf16_cell_mode() {
+    static const int v = [] {
+        const char* e = getenv("TSPGNN_BF16_CELL");
+        const int m = e ? atoi(e) : 8;
+        return m == 0 ? 0 : 8;
+    }();
+    return v;
+}
+
 extern "C" int tspgnn_lnlstm_fwd_multi_bf16(const tspgnn_lstm_task_bf16* tasks, int n_tasks, int d, void* stream) {
     TSPGNN_REQUIRE(tasks && n_tasks >= 1 && n_tasks <= kMaxTasksB, "lnlstm_fwd_multi_bf16: 1..%d tasks", kMaxTasksB);
     TSPGNN_REQUIRE(d == 32 || d == 64 || d == 128, "lnlstm_fwd_bf16: d=%d must be 32, 64 or 128", d);
@@ -486,7 +584,9 @@ extern "C" int tspgnn_lnlstm_fwd_multi_bf16(const tspgnn_lstm_task_bf16* tasks, 
     }
     if (n == 0) return TSPGNN_OK;
     hipStream_t st = as_stream(stream);
-    if (d == 32) return launch_lstm_b<32, 8>(live, n, st);
-    if (d == 64) return launch_lstm_b<64, 8>(live, n, st);
-    return launch_lstm_b<128, 8>(live, n, st);
+    if (d == 32) return launch_lstm_b<32, 8, false>(live, n, st);
+    if (d == 64) return launch_lstm_b<64, 8, false>(live, n, st);
+    const int mode = bf16_cell_mode();
+    if (mode == 0) return launch_lstm_b<128, 8, false>(live, n, st);
+    return launch_lstm_b<128, 8, true>(live, n, st);
 }

@@ -202,6 +202,54 @@ __device__ __forceinline__ void lstm_gates(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 
     }
 }
 
+// lstm_gates<D, true, SWAP> in three stages -- f, then (i, j), then o -- for kernels that form z one gate (pair) at a
+// time to keep a quarter / half of the accumulator registers live: the same operations on the same values in the same
+// order per element, so the result is bit-identical to the one-stage form.
+//   stage f:      cs = c * sig(LN_f(z_f))                     (cs arrives holding the old c)
+//   stage (i, j): cs = LN_s(sig(LN_i(z_i)) * relu(LN_j(z_j)) + cs)   = the new (normalised) c
+//   stage o:      h' = relu(c') * sig(LN_o(z_o))
+template <int D, bool SWAP>
+__device__ __forceinline__ void lstm_stage_f(f32x4 (&zf)[D / 16], f32x4 (&cs)[D / 16], const float* lds_ln, int g,
+                                             float eps_z = 1e-12f) {
+    constexpr int TPG = D / 16;
+    ln_gate<TPG, SWAP>(zf, lds_ln + 4 * D, lds_ln + 5 * D, g, D, eps_z);
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        cs[t].lo = cs[t].lo * sigmoid2_pre(zf[t].lo);
+        cs[t].hi = cs[t].hi * sigmoid2_pre(zf[t].hi);
+    }
+}
+template <int D, bool SWAP>
+__device__ __forceinline__ void lstm_stage_ij(f32x4 (&zij)[D / 8], f32x4 (&cs)[D / 16], const float* lds_ln, int g,
+                                              float eps_z = 1e-12f) {
+    constexpr int TPG = D / 16;
+    f32x4 gi[TPG], gj[TPG];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        gi[t] = zij[t];
+        gj[t] = zij[TPG + t];
+    }
+    ln_gate<TPG, SWAP>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D, eps_z);
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        cs[t].lo = fma2(sigmoid2_pre(gi[t].lo), relu2(gj[t].lo), cs[t].lo);
+        cs[t].hi = fma2(sigmoid2_pre(gi[t].hi), relu2(gj[t].hi), cs[t].hi);
+    }
+    ln_gate<TPG, SWAP>(cs, lds_ln + 8 * D, lds_ln + 9 * D, g, D);
+}
+template <int D, bool SWAP>
+__device__ __forceinline__ void lstm_stage_o(f32x4 (&zo)[D / 16], const f32x4 (&nc)[D / 16], const float* lds_ln, int g,
+                                             f32x4 (&hn)[D / 16], float eps_z = 1e-12f) {
+    constexpr int TPG = D / 16;
+    ln_gate<TPG, SWAP>(zo, lds_ln + 6 * D, lds_ln + 7 * D, g, D, eps_z);
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        hn[t].lo = relu2(nc[t].lo) * sigmoid2_pre(zo[t].lo);
+        hn[t].hi = relu2(nc[t].hi) * sigmoid2_pre(zo[t].hi);
+    }
+}
+
 template <int D>
 __device__ __forceinline__ void lstm_epilogue(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 16], const float* lds_ln, int g,
                                               bool valid, float* hd, float* cd) {
