@@ -132,30 +132,35 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_bf16_kernel(const MlpTableB t
     const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
     if (tid == 0) *ticket = t_beg;
     __syncthreads();
-    for (;;) {
-        int tile = 0;
-        if (lane == 0) tile = atomicAdd(ticket, 1);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= t_end) break;
+    auto next_ticket = [&]() {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(ticket, 1);
+        return __builtin_amdgcn_readfirstlane(t);
+    };
+    auto load_row = [&](int tile, bf16x8 (&dst)[KB]) {   // (rows past the end: the last row, never stored)
+        const __bf16* xr = X + c_blocked<D>((unsigned)min(tile * 16 + rl, rows - 1), g, x_blk);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) dst[kb] = row_operand(xr, kb, x_blk);
+    };
+    int tile = next_ticket();
+    bf16x8 bn[KB];                                       // the input rows of the NEXT tile, loaded a tile ahead
+    load_row(tile < t_end ? tile : t_beg, bn);
+    while (tile < t_end) {
+        const int ntile = next_ticket();
         const int row = tile * 16 + rl;
         const bool valid = row < rows;
         const size_t rbase = (size_t)(valid ? row : rows - 1) * D + g * 4;
-        const __bf16* xr = X + c_blocked<D>((unsigned)(valid ? row : rows - 1), g, x_blk);
         bf16x8 b[KB];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) b[kb] = row_operand(xr, kb, x_blk);
+        for (int kb = 0; kb < KB; ++kb) b[kb] = bn[kb];
+        load_row(ntile < t_end ? ntile : tile, bn);
         f32x4 acc[NT];
         for (int l = 0; l < n_layers; ++l) {
             const __bf16* wl = reinterpret_cast<const __bf16*>(lds_w + (size_t)l * LAYER_BYTES);
             const float* bl = reinterpret_cast<const float*>(lds_w + (size_t)l * LAYER_BYTES + D * D * 2);
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = ld4(bl + t * 16 + g * 4);
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                const __bf16* base = wl + ((size_t)(kb * 4 + g) * NT * 16 + rl) * 8;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = MFMA_BF16(ldw8(base + t * 128), b[kb], acc[t]);
-            }
+            gemm_frags_pf<NT, 0, NT, KB, 4>(acc, wl + ((size_t)g * NT * 16 + rl) * 8, b);
             if ((relu_mask >> l) & 1u) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
@@ -180,6 +185,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_bf16_kernel(const MlpTableB t
                 stw4(Y + rbase + (2 * kb + 1) * 16, bf16x4{b[kb][4], b[kb][5], b[kb][6], b[kb][7]});
             }
         }
+        tile = ntile;
     }
     if (PROJ && proj_w != nullptr) {  // second phase: proj_out = Y P, P packed [D, 4D]
         __threadfence_block();
@@ -199,13 +205,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_bf16_kernel(const MlpTableB t
             f32x4 acc[NP];
 #pragma unroll
             for (int t = 0; t < NP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 bv[KB];
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                const bf16x8 bv = row_operand(Y + rc * D + g * 4, kb);
-                const __bf16* base = wp + ((size_t)(kb * 4 + g) * NP * 16 + rl) * 8;
-#pragma unroll
-                for (int t = 0; t < NP; ++t) acc[t] = MFMA_BF16(ldw8(base + t * 128), bv, acc[t]);
-            }
+            for (int kb = 0; kb < KB; ++kb) bv[kb] = row_operand(Y + rc * D + g * 4, kb);
+            gemm_frags_pf<NP, 0, NP, KB, 4>(acc, wp + ((size_t)g * NP * 16 + rl) * 8, bv);
             if (valid) {
 #pragma unroll
                 for (int t = 0; t < NP; ++t) stw4(proj_out + zx_blocked<D>((unsigned)rc, g) + t * 256, narrow(acc[t]));
@@ -236,18 +239,10 @@ __device__ __forceinline__ void zx_load_part(bf16x4 (&ru)[TN], bf16x4 (&rv)[TN],
 template <int D, int T0, int TN, int PF>
 __device__ __forceinline__ void gather_gemm_part(f32x4 (&acc)[TN], const bf16x4 (&ru)[TN], const bf16x4 (&rv)[TN],
                                                  const __bf16* lds_w, const bf16x8 (&bv)[D / 32], int g, int rl) {
-    constexpr int NT4 = D / 4, KB = D / 32, TOTAL = KB * TN;
+    constexpr int NT4 = D / 4, KB = D / 32;
 #pragma unroll
     for (int t = 0; t < TN; ++t) acc[t] = widen(ru[t]) + widen(rv[t]);
-    const __bf16* base = lds_w + ((size_t)g * NT4 * 16 + rl) * 8 + T0 * 128;   // + kb * 4 * NT4 * 128 + t * 128
-    bf16x8 a[PF + 1];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) a[i] = ldw8(base + (i / TN) * (4 * NT4 * 128) + (i % TN) * 128);
-#pragma unroll
-    for (int i = 0; i < TOTAL; ++i) {
-        if (i + PF < TOTAL) a[(i + PF) % (PF + 1)] = ldw8(base + ((i + PF) / TN) * (4 * NT4 * 128) + ((i + PF) % TN) * 128);
-        acc[i % TN] = MFMA_BF16(a[i % (PF + 1)], bv[i / TN], acc[i % TN]);
-    }
+    gemm_frags_pf<NT4, T0, TN, KB, PF>(acc, lds_w + ((size_t)g * NT4 * 16 + rl) * 8, bv);
 }
 
 // STAGED: a resident gather-init (edge) task forms z gate by gate -- f, then (i, j), then o (mfma_tile.h's three

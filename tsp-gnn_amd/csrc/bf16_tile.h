@@ -42,4 +42,21 @@ __device__ __forceinline__ bf16x8 row_operand(const __bf16* row_g, int kb, bool 
     return blocked ? join(ldw4(row_g + kb * 512), ldw4(row_g + kb * 512 + 256)) : row_operand(row_g, kb);
 }
 
+// acc[t] += sum_kb W(kb, T0 + t) x bv[kb] for the TN output tiles T0.. of a packed bf16 matrix with NTOT output tiles
+// (LDS; base = the lane's fragment of (kb = 0, tile 0): + kb * 4 * NTOT * 128 + t * 128 elements), the weight fragments
+// PF deep in flight ahead of the MFMAs: an LDS read takes ~100 cycles, an MFMA 16 -- read-then-multiply in program order
+// (what the compiler emits for the plain loop) leaves the matrix pipe waiting on every fragment.
+template <int NTOT, int T0, int TN, int KB, int PF>
+__device__ __forceinline__ void gemm_frags_pf(f32x4 (&acc)[TN], const __bf16* base, const bf16x8 (&bv)[KB]) {
+    constexpr int TOTAL = KB * TN;
+    bf16x8 a[PF + 1];
+#pragma unroll
+    for (int i = 0; i < PF && i < TOTAL; ++i) a[i] = ldw8(base + (i / TN) * (4 * NTOT * 128) + (T0 + i % TN) * 128);
+#pragma unroll
+    for (int i = 0; i < TOTAL; ++i) {
+        if (i + PF < TOTAL) a[(i + PF) % (PF + 1)] = ldw8(base + ((i + PF) / TN) * (4 * NTOT * 128) + (T0 + (i + PF) % TN) * 128);
+        acc[i % TN] = MFMA_BF16(a[i % (PF + 1)], bv[i / TN], acc[i % TN]);
+    }
+}
+
 }  // namespace tspgnn

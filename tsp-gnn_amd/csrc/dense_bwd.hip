@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63, fl = lane & 15, g = lane >> 4;
     const int nbi = kin / 64, nbj = nout / 64, nob = nbi * nbj;
     // the wavefronts of one chunk read the same rows (X nbj times, dY nbi times): past four of them (one workgroup) they
-    // are kept on ONE XCD, whose L2 then serves the repeats
+    // are kept on ONE XCD, whose L2 then serves the repeats (xcd_map; d = 128 cell, 128 x 512: 4.03 -> 3.79 ms per 5.1 M rows)
     const int blk = xcd_map ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const long long w = ((long long)blk * blockDim.x + threadIdx.x) >> 6;
     if (w >= (long long)n_chunks * nob) return;  // wave-uniform
@@ -675,26 +675,10 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
 static int pick_vec(int width) { return width % 64 == 0 ? 4 : (width % 32 == 0 ? 2 : 1); }
 
 // Split of the row range used by tspgnn_wgrad_f32 (and its workspace size).
-static int wgrad_waves_per_cu() {   // development switch
-    static const int v = [] {
-        const char* e = getenv("TSPGNN_WGRAD_WPC");
-        const int m = e ? atoi(e) : 0;
-        return m > 0 ? m : 8;
-    }();
-    return v;
-}
-static int wgrad_group() {          // development switch: 1 = the workgroups of a chunk on one XCD
-    static const int v = [] {
-        const char* e = getenv("TSPGNN_WGRAD_XCD");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
-}
-
 static void wgrad_plan(long long rows, int kin, int nout, int* n_chunks, long long* chunk_rows) {
     const int av = pick_vec(kin), bv = pick_vec(nout);
     const int nob = (kin / (16 * av)) * (nout / (16 * bv));
-    long long target = (long long)n_cus() * wgrad_waves_per_cu() / nob;  // ~8 wavefronts per CU in total (HBM-bound: loads in flight)
+    long long target = (long long)n_cus() * 8 / nob;  // ~8 wavefronts per CU in total (HBM-bound: loads in flight)
     if (target < 1) target = 1;
     long long by_rows = (rows + 255) / 256;             // at least 256 rows per chunk
     long long nc = target < by_rows ? target : by_rows;
@@ -979,7 +963,7 @@ extern "C" int tspgnn_wgrad_bf16x_f32(const void* X, const float* dY, long long 
     const int nob = (kin / 64) * (nout / 64);
     const unsigned grid = (unsigned)(((long long)nc * nob + 3) / 4);
     wgrad_x3_kernel<true><<<grid, 256, 0, st>>>(reinterpret_cast<const float*>(X), dY, rows, kin, nout, P, Pb, nc, cr,
-                                               wgrad_group());
+                                               nob > 4);
     int rc = launched("tspgnn_wgrad_bf16x_f32");
     if (rc) return rc;
     const int n = kin * nout;
@@ -1006,7 +990,7 @@ extern "C" int tspgnn_wgrad_f32(const float* X, const float* dY, long long rows,
     if (av == 4 && bv == 4 && rows >= 4096) {   // the big reductions over T*rows: bf16 matrix cores, fp32-class accuracy
         const int nob = (kin / 64) * (nout / 64);
         const unsigned grid = (unsigned)(((long long)nc * nob + 3) / 4);
-        wgrad_x3_kernel<false><<<grid, 256, 0, st>>>(X, dY, rows, kin, nout, P, Pb, nc, cr, wgrad_group());
+        wgrad_x3_kernel<false><<<grid, 256, 0, st>>>(X, dY, rows, kin, nout, P, Pb, nc, cr, nob > 4);
         rc = launched("tspgnn_wgrad_f32");
     } else if (av == 4 && bv == 4) TSPGNN_WG(4, 4);
     else if (av == 4 && bv == 2) TSPGNN_WG(4, 2);
