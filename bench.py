@@ -41,6 +41,8 @@ WORKLOADS = {
     # BASELINE.json configs[4], ONE GPU's shard of it: n=200, 32 of the 256 graphs, embed=128, T=64, bf16 embeddings
     # with fp32 accumulation (M=636 800 edges; 340 MB of SpMM operands per step).  Not the metric's configuration.
     "c5": ([200] * 32, 128, 64, "bf16"),
+    # development: C2's batch in the bf16-storage mode (what that mode costs / saves at d = 64)
+    "c2b": ([40] * 128, 64, 32, "bf16"),
 }
 
 

@@ -552,12 +552,11 @@ extern "C" int tspgnn_mlp_fwd_multi_bf16(const tspgnn_mlp_task_bf16* tasks, int 
     return proj ? launch_mlp_b<128, 8, true>(live, n, st) : launch_mlp_b<128, 16, false>(live, n, st);
 }
 
-// development switch TSPGNN_BF16_CELL: 0 = all gates at once; 8 = staged (default)
-static int bf16_cell_mode() {
-    static const int v = [] {
+// development switch TSPGNN_BF16_CELL=0: the all-gates kernel (8 wavefronts) instead of the staged one
+static bool bf16_cell_staged() {
+    static const bool v = [] {
         const char* e = getenv("TSPGNN_BF16_CELL");
-        const int m = e ? atoi(e) : 8;
-        return m == 0 ? 0 : 8;
+        return !(e && atoi(e) == 0);
     }();
     return v;
 }
@@ -579,9 +578,10 @@ extern "C" int tspgnn_lnlstm_fwd_multi_bf16(const tspgnn_lstm_task_bf16* tasks, 
     }
     if (n == 0) return TSPGNN_OK;
     hipStream_t st = as_stream(stream);
+    // staged edge task (see lnlstm_fwd_bf16_kernel): d = 128 at two wavefronts per SIMD (256 registers: 289 -> 248 us per
+    // C5-shard launch), d = 64 at three (144 registers: 25.9 -> 22.5 us per C2-sized launch)
+    const bool staged = bf16_cell_staged();
     if (d == 32) return launch_lstm_b<32, 8, false>(live, n, st);
-    if (d == 64) return launch_lstm_b<64, 8, false>(live, n, st);
-    const int mode = bf16_cell_mode();
-    if (mode == 0) return launch_lstm_b<128, 8, false>(live, n, st);
-    return launch_lstm_b<128, 8, true>(live, n, st);
+    if (d == 64) return staged ? launch_lstm_b<64, 12, true>(live, n, st) : launch_lstm_b<64, 8, false>(live, n, st);
+    return staged ? launch_lstm_b<128, 8, true>(live, n, st) : launch_lstm_b<128, 8, false>(live, n, st);
 }
