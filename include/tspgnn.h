@@ -143,6 +143,12 @@ typedef struct tspgnn_lstm_task {
     const float* zbias; const float* zscale; /* optional: z starts at zscale[row] * zbias[4d] (a bias folded
                                                 through a row-sum aggregation: degree * (b Kx)) */
     unsigned* range_flag;                    /* as tspgnn_mlp_task.range_flag */
+    int z_centered;                          /* a promise, not a request: every row of z = [x|h] K (+ Zx[u] + Zx[v], + zscale
+                                                * zbias) has zero mean over each gate's d columns, because the caller centred
+                                                the columns of K (and of the Kx behind Zx, and zbias) per gate -- LayerNorm
+                                                subtracts that mean anyway, and the subtraction commutes with the product.
+                                                The f16x2 cell kernels then skip the mean pass of the four gate LayerNorms;
+                                                every other entry point ignores the field. */
 } tspgnn_lstm_task;  /* fields as the arguments of tspgnn_lnlstm_fwd_f32 / tspgnn_lnlstm_gather_fwd_f32 */
 
 int tspgnn_mlp_fwd_multi_f32(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream);

@@ -62,6 +62,39 @@ def test_forward_parity_with_oracle(cuda_device, name, d, T, gemm):
         assert float(hip[k]) == float(ref[k]), k
 
 
+def test_centered_gate_kernels_change_nothing_but_rounding(cuda_device):
+    """The f16x2 forward multiplies with cell kernels whose columns are centred per gate (and skips the mean pass of the
+    gate LayerNorms: tspgnn_lstm_task.z_centered) -- LayerNorm subtracts that mean anyway.  Against the same forward on
+    the plain kernels: equal to rounding, two orders below the 1e-5 parity budget; and against the float64 oracle the
+    budget holds with weights that have large per-gate column means (a bias-like offset on every kernel row)."""
+    t = pack_tuple("n20_B32")
+    d, T = 64, 8
+    params = P.init_params(d, seed=4, perturb=True)
+    for name in list(params):
+        if name.endswith("lstm_cell/kernel"):
+            params[name] = (params[name] + 0.05).astype(params[name].dtype)   # an offset on every column: the mean LayerNorm removes
+    outs = {}
+    for centered in (True, False):
+        model = tspgnn.build_network(d)
+        model["gnn"].center_gates = centered
+        sess = tspgnn.Session(model)
+        sess.run(tspgnn.global_variables_initializer())
+        model.store.load(params)
+        EV, W, C, route_exists, n_vertices, n_edges = t
+        feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+                model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+        outs[centered] = sess.run([model["predictions"], model["last_states"]], feed_dict=feed)
+    assert rel_err(outs[True][0], outs[False][0]) < 2e-6
+    for var in ("E", "V"):
+        assert rel_err(outs[True][1][var].h, outs[False][1][var].h) < 2e-6
+        assert rel_err(outs[True][1][var].c, outs[False][1][var].c) < 2e-6
+    batch = {"ev_uv": t[0].uv, "W": t[1], "C": t[2], "route_exists": t[3], "n_vertices": t[4], "n_edges": t[5]}
+    ref = TO.forward(TO.to_torch(params, torch.float64), batch, T)
+    assert rel_err(outs[True][0], ref["predictions"].numpy()) < REL_TOL
+    assert rel_err(outs[True][1]["E"].h, ref["last_states"]["E"][0].numpy()) < REL_TOL
+    assert rel_err(outs[True][1]["V"].c, ref["last_states"]["V"][1].numpy()) < REL_TOL
+
+
 def test_reference_hyperparameters_c1(cuda_device):
     """BASELINE configs[0]: n=20, B=32, d=64, T=8 with the reference's initialisers."""
     t = pack_tuple("n20_B32", 2)

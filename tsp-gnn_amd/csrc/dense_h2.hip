@@ -334,7 +334,9 @@ struct CellTaskTableH2 {
     int n;
 };
 
-template <int D, int MAXT>
+// CENTERED: every task of the launch promises z_centered (include/tspgnn.h) -- the gate LayerNorms run without their
+// mean pass (a compile-time variant: the same choice as a branch inside the tile loop cost 47 spilled registers).
+template <int D, int MAXT, bool CENTERED>
 __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTableH2 tt) {
     constexpr int NT4 = D / 4, TPG = D / 16, KBH = D / 32;
     constexpr int LAYER_BYTES = 2 * D * D * 2 + D * 4;  // { hi, lo, bias } of one MLP layer
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     // gates + state stores; returns h' in registers (the D layout is the next GEMM's B operand)
     auto cell = [&](f32x4 (&acc)[NT4], f32x4 (&cf)[TPG], unsigned rc, bool valid, f32x4 (&hn)[TPG]) {
         f32x4 nc[TPG];
-        lstm_gates<D, true, H2_LN_SWAP != 0>(acc, cf, lds_ln, g, hn, nc, kH2GateEps);
+        lstm_gates<D, true, H2_LN_SWAP != 0, CENTERED>(acc, cf, lds_ln, g, hn, nc, kH2GateEps);
         if ((H2_ABL & 4) ? (valid && hn[0][0] == 12345.678f) : valid) {   // (ablation: the stores depend on the values, never run)
             float* hd = h_out + h2_state_row<D>(rc, g, out_blk);
             float* cd = c_out + h2_state_row<D>(rc, g, out_blk);
@@ -1038,14 +1040,21 @@ static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
             grid = used;
         }
     }
-    const void* fn = nw_max == 16 ? reinterpret_cast<const void*>(&lnlstm_mlp_fwd_h2_kernel<D, 1024>)
-                                  : reinterpret_cast<const void*>(&lnlstm_mlp_fwd_h2_kernel<D, 768>);
+    bool centered = true;
+    for (int k = 0; k < n; ++k) centered = centered && tasks[k].cell.z_centered != 0;
+    const void* fn = nw_max == 16 ? (centered ? reinterpret_cast<const void*>(&lnlstm_mlp_fwd_h2_kernel<D, 1024, true>)
+                                              : reinterpret_cast<const void*>(&lnlstm_mlp_fwd_h2_kernel<D, 1024, false>))
+                                  : (centered ? reinterpret_cast<const void*>(&lnlstm_mlp_fwd_h2_kernel<D, 768, true>)
+                                              : reinterpret_cast<const void*>(&lnlstm_mlp_fwd_h2_kernel<D, 768, false>));
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute(%d B): %s", what, (int)lds_bytes, hipGetErrorString(e));
-    if (nw_max == 16)
-        lnlstm_mlp_fwd_h2_kernel<D, 1024><<<grid, nw * 64, lds_bytes, st>>>(tt);
-    else
-        lnlstm_mlp_fwd_h2_kernel<D, 768><<<grid, nw * 64, lds_bytes, st>>>(tt);
+    if (nw_max == 16) {
+        if (centered) lnlstm_mlp_fwd_h2_kernel<D, 1024, true><<<grid, nw * 64, lds_bytes, st>>>(tt);
+        else lnlstm_mlp_fwd_h2_kernel<D, 1024, false><<<grid, nw * 64, lds_bytes, st>>>(tt);
+    } else {
+        if (centered) lnlstm_mlp_fwd_h2_kernel<D, 768, true><<<grid, nw * 64, lds_bytes, st>>>(tt);
+        else lnlstm_mlp_fwd_h2_kernel<D, 768, false><<<grid, nw * 64, lds_bytes, st>>>(tt);
+    }
     return launched(what);
 }
 

@@ -109,23 +109,34 @@ __device__ __forceinline__ float sum_over_lane_groups16_swap(float v) {
     return s + t;
 }
 
-template <int TPG, bool SWAP = false>
+// CENTERED: the rows of v have zero mean already -- the caller's GEMM used operands whose columns were centred per gate
+// (LayerNorm's mean subtraction is the linear map I - 11^T/D on a gate's columns and commutes with the product; see
+// tspgnn_lstm_task.z_centered) -- so the mean pass (sum, lane reduction, subtraction: 23 of ~60 instructions) is skipped.
+template <int TPG, bool SWAP = false, bool CENTERED = false>
 __device__ __forceinline__ void ln_gate(f32x4 (&v)[TPG], const float* gamma, const float* beta, int g, int D,
                                         float eps = 1e-12f) {
     auto lane_sum = [](float x) { return SWAP ? sum_over_lane_groups16_swap(x) : sum_over_lane_groups16(x); };
-    f32x2 s2 = v[0].lo + v[0].hi;
-#pragma unroll
-    for (int t = 1; t < TPG; ++t) s2 += v[t].lo + v[t].hi;
-    const float mean = lane_sum(s2[0] + s2[1]) * (1.0f / (float)D);
-    const f32x2 m2 = {mean, mean};
     f32x2 q2 = {0.f, 0.f};
+    if constexpr (CENTERED) {
 #pragma unroll
-    for (int t = 0; t < TPG; ++t) {  // centred values replace v: y = (x - mean) * (rstd * gamma) + beta
-        const f32x2 a = v[t].lo - m2, b = v[t].hi - m2;
-        q2 = fma2(a, a, q2);
-        q2 = fma2(b, b, q2);
-        v[t].lo = a;
-        v[t].hi = b;
+        for (int t = 0; t < TPG; ++t) {
+            q2 = fma2(v[t].lo, v[t].lo, q2);
+            q2 = fma2(v[t].hi, v[t].hi, q2);
+        }
+    } else {
+        f32x2 s2 = v[0].lo + v[0].hi;
+#pragma unroll
+        for (int t = 1; t < TPG; ++t) s2 += v[t].lo + v[t].hi;
+        const float mean = lane_sum(s2[0] + s2[1]) * (1.0f / (float)D);
+        const f32x2 m2 = {mean, mean};
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) {  // centred values replace v: y = (x - mean) * (rstd * gamma) + beta
+            const f32x2 a = v[t].lo - m2, b = v[t].hi - m2;
+            q2 = fma2(a, a, q2);
+            q2 = fma2(b, b, q2);
+            v[t].lo = a;
+            v[t].hi = b;
+        }
     }
     const float var = lane_sum(q2[0] + q2[1]) * (1.0f / (float)D);
     const float rstd = __builtin_amdgcn_rsqf(var + eps);  // v_rsq_f32, ~1 ulp
@@ -163,7 +174,7 @@ __device__ __forceinline__ f32x2 sigmoid2_pre(f32x2 t) {
 // beta_f), so their LayerNorm output is the exponent of the sigmoid directly -- one packed multiply-add per pair less;
 // eps_z: the epsilon of the four gate LayerNorms (a caller whose z is scaled by 2^s passes 2^2s * 1e-12, which makes
 // the normalised gates those of the unscaled z exactly -- a power-of-two scale commutes with every rounding).
-template <int D, bool PRE = false, bool SWAP = false>
+template <int D, bool PRE = false, bool SWAP = false, bool CENTERED = false>
 __device__ __forceinline__ void lstm_gates(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 16], const float* lds_ln, int g,
                                            f32x4 (&hn)[D / 16], f32x4 (&nc)[D / 16], float eps_z = 1e-12f) {
     constexpr int TPG = D / 16;
@@ -175,10 +186,10 @@ __device__ __forceinline__ void lstm_gates(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 
         gf[t] = acc[2 * TPG + t];
         go[t] = acc[3 * TPG + t];
     }
-    ln_gate<TPG, SWAP>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D, eps_z);
-    ln_gate<TPG, SWAP>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D, eps_z);
-    ln_gate<TPG, SWAP>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D, eps_z);
-    ln_gate<TPG, SWAP>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP, CENTERED>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP, CENTERED>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP, CENTERED>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP, CENTERED>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D, eps_z);
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
         if constexpr (PRE) {

@@ -99,7 +99,7 @@ class LstmTask(ctypes.Structure):
     """tspgnn_lstm_task (include/tspgnn.h)."""
     _fields_ = [("x", c_void_p), ("dx", c_int), ("h", c_void_p), ("c", c_void_p), ("K", c_void_p), ("ln", c_void_p),
                 ("h_out", c_void_p), ("c_out", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p),
-                ("zbias", c_void_p), ("zscale", c_void_p), ("range_flag", c_void_p)]
+                ("zbias", c_void_p), ("zscale", c_void_p), ("range_flag", c_void_p), ("z_centered", c_int)]
 
 
 class CellMlpTask(ctypes.Structure):

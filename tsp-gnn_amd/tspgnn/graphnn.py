@@ -49,6 +49,13 @@ def _pack_split(store, arith, W, out, krows, ncols):
         _lib.call("tspgnn_pack_weights_" + arith, _lib.ptr(W), _lib.ptr(out), krows, ncols, _lib.current_stream())
 
 
+def _center_gates(K, d):
+    """K [rows, 4d] with the mean over each gate's d columns subtracted per row (float64 arithmetic): LayerNorm's mean
+    subtraction moved from every z row of every step into the weights (tspgnn_lstm_task.z_centered)."""
+    k64 = K.to(torch.float64).reshape(K.shape[0], 4, d)
+    return (k64 - k64.mean(dim=2, keepdim=True)).reshape(K.shape[0], 4 * d).to(torch.float32).contiguous()
+
+
 def _dev_i32(a, device):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
 
@@ -289,16 +296,19 @@ class LayerNormBasicLSTMCell(object):
             return out
         return self.store.packed((key, self.base), build)
 
-    def _packed_split(self, arith, key, rows_lo, rows_hi):
+    def _packed_split(self, arith, key, rows_lo, rows_hi, centered=False):
         """Split-operand packing of kernel rows [rows_lo, rows_hi) as a byte tensor: ``arith`` = "x3" (three bf16
-        pieces, tspgnn_pack_weights_x3) or "h2" (two fp16 pieces of 2^s K, tspgnn_pack_weights_h2)."""
+        pieces, tspgnn_pack_weights_x3) or "h2" (two fp16 pieces of 2^s K, tspgnn_pack_weights_h2).  ``centered``: of
+        the kernel with each gate's columns centred (_center_gates) -- a packing of its own."""
         def build(out):
             K = self.kernel()[rows_lo:rows_hi]
+            if centered:
+                K = _center_gates(K, self.d)
             if out is None:
                 out = torch.empty(SPLIT_BYTES[arith] * K.numel(), dtype=torch.uint8, device=K.device)
             _pack_split(self.store, arith, K, out, rows_hi - rows_lo, 4 * self.d)
             return out
-        return self.store.packed((key + "." + arith, self.base), build)
+        return self.store.packed((key + "." + arith + (".c" if centered else ""), self.base), build)
 
     def _packed_x3(self, key, rows_lo, rows_hi):
         return self._packed_split("x3", key, rows_lo, rows_hi)
@@ -337,17 +347,19 @@ class LayerNormBasicLSTMCell(object):
     def kh_t_packed(self):
         return self._packed_slice("lstm.khT", self.dx, self.dx + self.d, True)
 
-    def task(self, x, state, out, arith=None):
-        K = self._packed_split(arith, "lstm", 0, self.dx + self.d) if arith else self.kernel_packed()
+    def task(self, x, state, out, arith=None, centered=False):
+        K = self._packed_split(arith, "lstm", 0, self.dx + self.d, centered) if arith else self.kernel_packed()
         return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(K),
                              _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None,
-                             None, None, self._flag(arith))
+                             None, None, self._flag(arith), int(centered))
 
-    def gather_task(self, adj, zx, state, out, arith=None):
-        K = self._packed_split(arith, "lstm.kh", self.dx, self.dx + self.d) if arith else self.kh_packed()
+    def gather_task(self, adj, zx, state, out, arith=None, centered=False):
+        """``centered``: Kh AND the Kx behind zx were centred per gate (the caller projects with
+        _packed_split(..., "lstm.kx", ..., centered=True))."""
+        K = self._packed_split(arith, "lstm.kh", self.dx, self.dx + self.d, centered) if arith else self.kh_packed()
         return _lib.LstmTask(None, 0, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(K),
                              _lib.ptr(self.ln()), _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0],
-                             _lib.ptr(adj.uv), _lib.ptr(zx), None, None, self._flag(arith))
+                             _lib.ptr(adj.uv), _lib.ptr(zx), None, None, self._flag(arith), int(centered))
 
     def _flag(self, arith):
         """The range_flag of an f16x2 task (include/tspgnn.h): the store's guard word."""
@@ -377,7 +389,7 @@ class LayerNormBasicLSTMCell(object):
             return (kfull, zb, kt)
         return self.store.packed(("lstm.pushed.kernel", self.base, last), build)
 
-    def pushed_bias_pack(self, mlp, arith=None):
+    def pushed_bias_pack(self, mlp, arith=None, centered=False):
         """For a cell whose input is a row-sum aggregation of ``mlp``'s output: (pack(K'), b Kx) of pushed_kernel in the
         packing of ``arith``.  The cell then takes the row-sum of the LAST HIDDEN activation as its input and starts z
         at degree * (b Kx).  One Dense(d) layer less on every edge row per step."""
@@ -386,6 +398,8 @@ class LayerNormBasicLSTMCell(object):
 
         def build(out):
             kfull, zb, _ = self.pushed_kernel(mlp)
+            if centered:   # (K' and b Kx centred per gate: tspgnn_lstm_task.z_centered)
+                kfull = _center_gates(kfull, d)
             if out is None:
                 out = torch.empty(SPLIT_BYTES[arith] * (dx + d) * 4 * d, dtype=torch.uint8, device=kfull.device) if arith \
                     else torch.empty((dx + d, 4 * d), dtype=torch.float32, device=kfull.device)
@@ -395,7 +409,13 @@ class LayerNormBasicLSTMCell(object):
             else:
                 _lib.call("tspgnn_pack_weights_f32", _lib.ptr(kfull), _lib.ptr(out), dx + d, 4 * d, 0, st)
             return out
-        return self.store.packed(("lstm.pushed." + (arith or "f32"), self.base, last), build), self.pushed_kernel(mlp)[1]
+        packed = self.store.packed(("lstm.pushed." + (arith or "f32") + (".c" if centered else ""), self.base, last), build)
+        if not centered:
+            return packed, self.pushed_kernel(mlp)[1]
+        zb_c = self.store.packed(("lstm.pushed.zb.c", self.base, last),
+                                 lambda out: _center_gates(self.pushed_kernel(mlp)[1], d) if out is None
+                                 else out.copy_(_center_gates(self.pushed_kernel(mlp)[1], d)))
+        return packed, zb_c
 
     def pushed_backward_task(self, x, h, c, dh_out, dc_out, dz, dc_in, ws, kp, zb, deg, defer=False):
         """Backward task (tspgnn_lnlstm_bwd_multi_h2) of pushed_task: K = pushed_bias_pack's f16x2 K', z restarts at
@@ -445,11 +465,11 @@ class LayerNormBasicLSTMCell(object):
         dkx.addcmul_(b.view(-1, 1), g_zb.view(1, -1))
         self.store.grad_view(self.base + "/kernel")[:dx].add_(dkx)
 
-    def pushed_task(self, x, state, out, kp, zb, deg, arith=None):
+    def pushed_task(self, x, state, out, kp, zb, deg, arith=None, centered=False):
         """Cell task whose kernel operand is pushed_bias_pack's K' (either packing) and z starts at deg * zb."""
         return _lib.LstmTask(_lib.ptr(x), self.dx, _lib.ptr(state.h), _lib.ptr(state.c), _lib.ptr(kp), _lib.ptr(self.ln()),
                              _lib.ptr(out[0]), _lib.ptr(out[1]), state.h.shape[0], None, None, _lib.ptr(zb), _lib.ptr(deg),
-                             self._flag(arith))
+                             self._flag(arith), int(centered))
 
     def premultiply(self, y, out=None, scale=None):
         """Zx = y Kx  ([n_src, 4d]); ``scale``: times 2^s for an f16x2 cell, whose z carries that factor."""
@@ -632,6 +652,8 @@ class GraphNN(object):
         self.float_dtype = float_dtype
         self.store = store if store is not None else V.get_default_store()
         self.fold_adjacency = True   # (EV y) Kx = EV (y Kx) fast path; False = op-for-op reference order
+        # f16x2 fused forward: LayerNorm's mean subtraction folded into the cell kernels (TSPGNN_CENTER_GATES=0: A/B)
+        self.center_gates = os.environ.get("TSPGNN_CENTER_GATES", "1") != "0"
         # training (f16x2): a message MLP's last linear layer pushed through the row-sum into the receiving cell, as in the
         # inference plan (one Dense layer less per edge row in the forward, the backward and the weight gradients)
         self.push_training = os.environ.get("TSPGNN_PUSH_TRAINING", "1") != "0"
@@ -1041,6 +1063,9 @@ class GraphNN(object):
         # takes h' from registers -- so the loop's ping-pong buffers are loaded and stored 1 KiB contiguous per
         # instruction; the first step reads the caller's row-major states, the last one writes row-major again.
         blocked = {v: arith == "h2" and folded[v] is not None for v in self.var}
+        # f16x2: the cells' kernels (and with Kx the projected messages, and a pushed bias) are centred per gate, so that
+        # the four gate LayerNorms of every row and step skip their mean pass (tspgnn_lstm_task.z_centered)
+        cen = arith == "h2" and self.center_gates
         rows_of = {v: st.h.shape[0] for v, st in states.items()}
 
         def state_buffers():
@@ -1077,7 +1102,7 @@ class GraphNN(object):
             pw = po = None
             if folded[v] is not None:
                 cv = self._RNN_cells[v]
-                pw, po = cv._packed_split(arith, "lstm.kx", 0, cv.dx), zxs[p][v]
+                pw, po = cv._packed_split(arith, "lstm.kx", 0, cv.dx, cen), zxs[p][v]
             out = mo[p].get((v, i))
             return (mlp.wb_packed_split(arith, 0, n - 1, d), n, mlp.relu_mask(0, n), out, pw, po)
 
@@ -1092,7 +1117,7 @@ class GraphNN(object):
                 st = first_state[v] if first else LSTMStateTuple(c=src[v].c[:n_v], h=src[v].h[:n_v])
                 out = (dst[v].h, dst[v].c)
                 if folded[v] is not None:
-                    t = cell.gather_task(mats[folded[v]["mat"]], zxs[p][v], st, out, arith=arith)
+                    t = cell.gather_task(mats[folded[v]["mat"]], zxs[p][v], st, out, arith=arith, centered=cen)
                 else:
                     inputs = []
                     for i, u in enumerate(self.loop[v]):
@@ -1113,11 +1138,11 @@ class GraphNN(object):
                     keep.append(x)
                     if pushed[v]:
                         u0 = self.loop[v][0]
-                        kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], arith=arith)
+                        kp, zb = cell.pushed_bias_pack(self._msg_MLPs[u0["msg"]], arith=arith, centered=cen)
                         deg = mats[u0["mat"]].row_degrees(bool(u0.get("transpose?", False)))
-                        t = cell.pushed_task(x, st, out, kp, zb, deg, arith=arith)
+                        t = cell.pushed_task(x, st, out, kp, zb, deg, arith=arith, centered=cen)
                     else:
-                        t = cell.task(x, st, out, arith=arith)
+                        t = cell.task(x, st, out, arith=arith, centered=cen)
                 s_in = 1 if blocked[v] and not first else 0
                 s_out = 1 if blocked[v] and with_messages else 0
                 if with_messages:   # the message MLP that reads this variable's new h in the next step
@@ -1150,11 +1175,11 @@ class GraphNN(object):
         for v in self.var:
             cell = self._RNN_cells[v]
             if folded[v] is not None:
-                cell._packed_split(arith, "lstm.kh", cell.dx, cell.dx + cell.d)
+                cell._packed_split(arith, "lstm.kh", cell.dx, cell.dx + cell.d, cen)
             elif pushed[v]:
-                cell.pushed_bias_pack(self._msg_MLPs[self.loop[v][0]["msg"]], arith=arith)
+                cell.pushed_bias_pack(self._msg_MLPs[self.loop[v][0]["msg"]], arith=arith, centered=cen)
             else:
-                cell._packed_split(arith, "lstm", 0, cell.dx + cell.d)
+                cell._packed_split(arith, "lstm", 0, cell.dx + cell.d, cen)
 
         def run(T):
             for arr, d in pre_calls:
