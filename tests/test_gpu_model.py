@@ -95,6 +95,31 @@ def test_centered_gate_kernels_change_nothing_but_rounding(cuda_device):
     assert rel_err(outs[True][1]["V"].c, ref["last_states"]["V"][1].numpy()) < REL_TOL
 
 
+@pytest.mark.parametrize("name,d,fold", [("ragged_B6", 64, False), ("sparse_B4", 64, True), ("n5_B2", 32, True)])
+def test_centered_gate_kernels_in_every_plan_shape(cuda_device, name, d, fold):
+    """The centred packings cover every way the fused f16x2 plan feeds a cell -- gather-init (Kh + the Kx behind Zx), the
+    pushed last layer ([W Kx ; Kh] and b Kx), and with fold_adjacency off the plain [Kx ; Kh] kernel: parity with the
+    float64 oracle on ragged / sparse / tiny batches."""
+    t = pack_tuple(name)
+    T = 4
+    params = P.init_params(d, seed=8, perturb=True)
+    model = tspgnn.build_network(d)
+    model["gnn"].fold_adjacency = fold
+    assert model["gnn"].center_gates
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    EV, W, C, route_exists, n_vertices, n_edges = t
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    pred, last = sess.run([model["predictions"], model["last_states"]], feed_dict=feed)
+    batch = {"ev_uv": t[0].uv, "W": t[1], "C": t[2], "route_exists": t[3], "n_vertices": t[4], "n_edges": t[5]}
+    ref = TO.forward(TO.to_torch(params, torch.float64), batch, T)
+    assert rel_err(pred, ref["predictions"].numpy()) < REL_TOL
+    assert rel_err(last["E"].h, ref["last_states"]["E"][0].numpy()) < REL_TOL
+    assert rel_err(last["V"].h, ref["last_states"]["V"][0].numpy()) < REL_TOL
+
+
 def test_reference_hyperparameters_c1(cuda_device):
     """BASELINE configs[0]: n=20, B=32, d=64, T=8 with the reference's initialisers."""
     t = pack_tuple("n20_B32", 2)
