@@ -770,6 +770,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         // are bound by the matrix pipes of the few CUs it runs on)
         const int lw = tt.lock_tiles[k];
         const int rounds = (H2_ABL & 8) ? 0 : (tiles_total + lw - 1) / lw;
+        TR_DECL;
         for (int r = my_blk; r < rounds; r += my_grid) {
             {
                 const int l = opaque_lane();
@@ -802,12 +803,14 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                         }
                     }
                 }
+                TR(0);
                 for (int kb0 = 0; kb0 < KBT; kb0 += kbc) {
                     const int kb1 = min(KBT, kb0 + kbc);
                     __syncthreads();
                     stage(kb0, kb1);
                     h2_stage_wait();
                     __syncthreads();
+                    TR(1);
                     if (live && pre) {
 #pragma unroll
                         for (int kb = 0; kb < KBP; ++kb) {
@@ -823,6 +826,11 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                         kloop(acc, rc, kb0, kb0, kb1);
                     }
                 }
+#if H2_TRACE
+#pragma unroll
+                for (int t = 0; t < NT4; ++t) asm volatile("" : "+v"(acc[t]));
+#endif
+                TR(2);
                 if (n_layers > 0) {  // every wavefront is done with K: the next residency loads behind the gates
                     __syncthreads();
                     h2_copy_to_lds(lds_wb, mlp_wb, n_layers * LAYER_BYTES, tid, blockDim.x);
@@ -834,10 +842,16 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 for (int t = 0; t < TPG; ++t)
                     cf[t] = c != nullptr ? ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
                 cell(acc, cf, rc, valid, hn);
+#if H2_TRACE
+#pragma unroll
+                for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(hn[t]));
+#endif
+                TR(3);
             }
             if (n_layers > 0) {
                 h2_stage_wait();
                 __syncthreads();
+                TR(4);
                 for (int l = 0; l < n_layers; ++l) {
                     const _Float16* wh = reinterpret_cast<const _Float16*>(lds_wb + (size_t)l * LAYER_BYTES);
                     const float* bias = reinterpret_cast<const float*>(lds_wb + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
@@ -852,6 +866,11 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
 #pragma unroll
                     for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
+#if H2_TRACE
+#pragma unroll
+                for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(hn[t]));
+#endif
+                TR(5);
                 if (proj_w != nullptr) {  // proj_out = 2^s mlp(h') P, P packed [D, 4D]
                     if (!together) {
                         __syncthreads();
@@ -878,7 +897,13 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                     }
                 }
             }
+#if H2_TRACE
+            __builtin_amdgcn_s_waitcnt(0);
+            TR(6);
+            tr_acc[7] += 1;
+#endif
         }
+        TR_FLUSH;
     }
     h2_range_report(tk.range_flag, wit);
 }
