@@ -254,6 +254,12 @@ typedef struct tspgnn_mlp_task_bf16 {
     void* acts; long long acts_stride;   /* optional (training): the stored (bf16) hidden activations, layer l of row r
                                             at acts[l*acts_stride + r*d] (elements); stride 0 = rows*d */
     int x_blocked;                       /* X is a loop state h stored blocked by 16 rows (see the lstm task) */
+    int y_interleaved;                   /* the LAST layer's packed weights and bias have their output columns permuted --
+                                            packed column 16t + 4g + j (t < d/16, g, j < 4) holds true column
+                                            32(t/2) + 8g + 4(t%2) + j -- so that a lane's eight results of a tile pair are
+                                            eight CONSECUTIVE columns of Y: one 16-byte store, 64-byte runs per row and
+                                            instruction, instead of two 8-byte stores in 32-byte runs.  Y itself is the
+                                            ordinary row-major [rows, d].  Not with a projection or saved activations. */
 } tspgnn_mlp_task_bf16;
 typedef struct tspgnn_lstm_task_bf16 {
     const void* x; int dx; const void* h; const float* c; const void* K; const float* ln;

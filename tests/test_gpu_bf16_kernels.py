@@ -126,6 +126,33 @@ def test_mlp_bf16_two_tasks_with_projection(cuda_device, d, rows):
     assert rel_err(h2_zx_unpack(f64(Zb), rows_b, 1.0), f64(Yb) @ rb(P)) < 2.0 ** -7       # projection of the kernel's own (stored) Y: one rounding
 
 
+@pytest.mark.parametrize("d", [32, 64, 128])
+@pytest.mark.parametrize("rows", [1, 333, 5003])
+def test_mlp_bf16_interleaved_last_layer_stores_the_same_rows(cuda_device, d, rows):
+    """tspgnn_mlp_task_bf16.y_interleaved: the last layer packed with its output columns permuted (packed column
+    16t+4g+j = true column 32(t/2)+8g+4(t%2)+j) and Y written in 16-byte pieces -- the same row-major Y, bit for bit."""
+    rng = np.random.RandomState(3 * d + rows)
+    X = rng.randn(rows, d)
+    layers = [((rng.randn(d, d) / np.sqrt(d)).astype(np.float32), (0.1 * rng.randn(d)).astype(np.float32)) for _ in range(3)]
+    c = np.arange(d)
+    t, g, r = c // 16, (c % 16) // 4, c % 4
+    perm = 32 * (t // 2) + 8 * g + 4 * (t % 2) + r
+    inter = layers[:-1] + [(np.ascontiguousarray(layers[-1][0][:, perm]), np.ascontiguousarray(layers[-1][1][perm]))]
+    outs = []
+    for lay, flag in ((layers, 0), (inter, 1)):
+        Y = torch.zeros((rows, d), dtype=torch.bfloat16, device=cuda_device)
+        task = _lib.MlpTaskB(_lib.ptr(dev_bf16(X, cuda_device)), _lib.ptr(mlp_blocks_bf16(lay, cuda_device)), _lib.ptr(Y), rows, 3,
+                             0b011, None, None, None, 0, 0, flag)
+        _lib.call_multi("tspgnn_mlp_fwd_multi_bf16", [task], d)
+        torch.cuda.synchronize()
+        outs.append(f64(Y))
+    assert np.array_equal(outs[0], outs[1])
+    x = rb(X)
+    for (W, b), relu in zip(layers, [True, True, False]):
+        x = rb(NO.dense(x, rb(W), b.astype(np.float64), relu))
+    assert rel_err(outs[1], x) < BF16_TOL
+
+
 def ln_params(rng, d):
     ln = np.stack([np.stack([1 + 0.2 * rng.randn(d), 0.2 * rng.randn(d)]) for _ in range(5)]).astype(np.float32)
     names = ("input", "transform", "forget", "output", "state")

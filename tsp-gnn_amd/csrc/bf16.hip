@@ -119,7 +119,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_bf16_kernel(const MlpTableB t
     const unsigned relu_mask = tt.task[k].relu_mask;
     const __bf16* __restrict__ proj_w = reinterpret_cast<const __bf16*>(tt.task[k].proj_w);
     __bf16* __restrict__ proj_out = reinterpret_cast<__bf16*>(tt.task[k].proj_out);
-    const bool x_blk = tt.task[k].x_blocked != 0;
+    const bool x_blk = tt.task[k].x_blocked != 0, y_inter = tt.task[k].y_interleaved != 0;
     __bf16* __restrict__ acts = reinterpret_cast<__bf16*>(tt.task[k].acts);   // training: the stored hidden activations
     const long long acts_stride = tt.task[k].acts_stride;
     const int tiles_total = (rows + 15) / 16;
@@ -178,7 +178,11 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_bf16_kernel(const MlpTableB t
                 }
             }
         }
-        if (valid) {
+        if (valid && y_inter) {   // (last layer packed with interleaved columns: the lane's 8 values are 8 consecutive columns)
+            __bf16* dst = Y + (size_t)row * D + g * 8;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) *reinterpret_cast<bf16x8*>(dst + kb * 32) = b[kb];
+        } else if (valid) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 stw4(Y + rbase + (2 * kb) * 16, bf16x4{b[kb][0], b[kb][1], b[kb][2], b[kb][3]});
@@ -539,6 +543,7 @@ extern "C" int tspgnn_mlp_fwd_multi_bf16(const tspgnn_mlp_task_bf16* tasks, int 
         TSPGNN_REQUIRE(t.X && t.wb && t.Y, "mlp_fwd_bf16: null pointer");
         TSPGNN_REQUIRE(!t.proj_w || t.proj_out, "mlp_fwd_bf16: projection needs proj_out");
         TSPGNN_REQUIRE(t.acts_stride >= 0, "mlp_fwd_bf16: acts_stride=%lld", t.acts_stride);
+        TSPGNN_REQUIRE(!t.y_interleaved || (!t.proj_w && !t.acts), "mlp_fwd_bf16: y_interleaved excludes a projection and saved activations");
         live[n] = t;
         if (live[n].acts && live[n].acts_stride == 0) live[n].acts_stride = (long long)t.rows * d;
         ++n;

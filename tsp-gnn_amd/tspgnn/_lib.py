@@ -114,7 +114,7 @@ class MlpTaskB(ctypes.Structure):
     """tspgnn_mlp_task_bf16 (include/tspgnn.h)."""
     _fields_ = [("X", c_void_p), ("wb", c_void_p), ("Y", c_void_p), ("rows", c_int), ("n_layers", c_int),
                 ("relu_mask", c_uint), ("proj_w", c_void_p), ("proj_out", c_void_p),
-                ("acts", c_void_p), ("acts_stride", ctypes.c_longlong), ("x_blocked", c_int)]
+                ("acts", c_void_p), ("acts_stride", ctypes.c_longlong), ("x_blocked", c_int), ("y_interleaved", c_int)]
 
 
 class LstmTaskB(ctypes.Structure):

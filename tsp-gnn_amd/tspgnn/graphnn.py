@@ -909,9 +909,12 @@ class GraphNN(object):
                             zxs[v] = torch.empty((_pad16(rows), 4 * self.var[v]), **bf)
                             pw, po = cv._packed_bf16("lstm.kx", 0, cv.dx), zxs[v]
                         n = mlp.n_square
+                        # a plain message (no projection rides behind it): the last layer's columns interleaved in the
+                        # packing, 16-byte stores of Y (tspgnn_mlp_task_bf16.y_interleaved)
+                        il = pw is None and d % 32 == 0 and os.environ.get("TSPGNN_BF16_INTERLEAVE", "1") != "0"
                         mlp_tasks.setdefault(d, []).append(_lib.MlpTaskB(
-                            _lib.ptr(y), _lib.ptr(mlp.wb_packed_bf16(0, n - 1, d)), _lib.ptr(out), rows, n,
-                            mlp.relu_mask(0, n), _lib.ptr(pw), _lib.ptr(po), None, 0, int(blk_in[src])))
+                            _lib.ptr(y), _lib.ptr(mlp.wb_packed_bf16(0, n - 1, d, interleave_last=il)), _lib.ptr(out), rows, n,
+                            mlp.relu_mask(0, n), _lib.ptr(pw), _lib.ptr(po), None, 0, int(blk_in[src]), int(il)))
                         y = out
                     msg_out[(v, i)] = y
             for v, d in self.var.items():

@@ -151,9 +151,11 @@ class Mlp(object):
     def wb_packed_x3(self, first, last, d):
         return self.wb_packed_split("x3", first, last, d)
 
-    def wb_packed_bf16(self, first, last, d):
+    def wb_packed_bf16(self, first, last, d, interleave_last=False):
         """Byte tensor of {bf16 pack(W) [d*d*2 B] (weights rounded to bf16, fragment order), b [d*4 B]} per square
-        layer first..last for the bf16-storage kernels, cached until the variables change."""
+        layer first..last for the bf16-storage kernels, cached until the variables change.  ``interleave_last``: the
+        last layer's output columns permuted for tspgnn_mlp_task_bf16.y_interleaved (packed column 16t+4g+j holds true
+        column 32(t/2)+8g+4(t%2)+j)."""
         def build(out):
             src = self.wb_packed_x3(first, last, d)
             per3, per = 6 * d * d + 4 * d, 2 * d * d + 4 * d
@@ -162,8 +164,19 @@ class Mlp(object):
             for j in range(last - first + 1):
                 out[j * per:j * per + 2 * d * d].copy_(src[j * per3:j * per3 + 2 * d * d])            # piece 0
                 out[j * per + 2 * d * d:(j + 1) * per].copy_(src[j * per3 + 6 * d * d:(j + 1) * per3])  # bias
+            if interleave_last:
+                j = last - first
+                c = torch.arange(d, device=src.device)
+                t, g, r = c // 16, (c % 16) // 4, c % 4
+                perm = 32 * (t // 2) + 8 * g + 4 * (t % 2) + r
+                wb = self.wb(last, last)
+                W = wb[:d * d].view(d, d)[:, perm].contiguous()
+                tmp = torch.empty(6 * d * d, dtype=torch.uint8, device=src.device)
+                _lib.call("tspgnn_pack_weights_x3", _lib.ptr(W), _lib.ptr(tmp), d, d, _lib.current_stream())
+                out[j * per:j * per + 2 * d * d].copy_(tmp[:2 * d * d])
+                out[j * per + 2 * d * d:(j + 1) * per].copy_(wb[d * d:d * d + d][perm].contiguous().view(torch.uint8))
             return out
-        return self.store.packed(("mlp.bf16", self.name, first, last), build)
+        return self.store.packed(("mlp.bf16" + (".il" if interleave_last else ""), self.name, first, last), build)
 
     def wt_packed(self, first, last, d):
         """pack(W_l^T) for square layers first..last back to back (data-gradient kernels)."""
