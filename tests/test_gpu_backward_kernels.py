@@ -304,6 +304,30 @@ def test_wgrad_accumulates_and_large_rows(cuda_device):
     assert rel_err(dW.cpu().numpy(), ref) < TOL
 
 
+@pytest.mark.parametrize("bf16_x", [False, True])
+def test_wgrad_wide_outputs_span_several_workgroups(cuda_device, bf16_x):
+    """kin x nout = 128 x 512 (the d = 128 cell): sixteen 64 x 64 output blocks per row chunk, i.e. four workgroups per
+    chunk, which the kernel keeps on one XCD (blockIdx remapped) -- every block of every chunk must still be formed
+    exactly once; with the bias row, fp32 and bf16 X (tspgnn_wgrad_f32 / tspgnn_wgrad_bf16x_f32)."""
+    rng = np.random.RandomState(11)
+    rows, kin, nout = 70001, 128, 512
+    X = rng.randn(rows, kin).astype(np.float32)
+    dY = rng.randn(rows, nout).astype(np.float32)
+    if bf16_x:
+        xt = dev(X, cuda_device).to(torch.bfloat16)
+        X = xt.to(torch.float32).cpu().numpy()
+    else:
+        xt = dev(X, cuda_device)
+    dW = empty((kin, nout), cuda_device, 0.0)
+    db = empty((nout,), cuda_device, 0.0)
+    w = ws("tspgnn_wgrad_workspace_floats", rows, kin, nout, device=cuda_device)
+    _lib.call("tspgnn_wgrad_bf16x_f32" if bf16_x else "tspgnn_wgrad_f32", _lib.ptr(xt), _lib.ptr(dev(dY, cuda_device)), rows, kin,
+              nout, _lib.ptr(dW), _lib.ptr(db), _lib.ptr(w), None)
+    torch.cuda.synchronize()
+    assert rel_err(dW.cpu().numpy(), X.astype(np.float64).T @ dY.astype(np.float64)) < TOL
+    assert rel_err(db.cpu().numpy(), dY.astype(np.float64).sum(0)) < TOL
+
+
 def test_vote_head_backward_pieces(cuda_device):
     rng = np.random.RandomState(9)
     n_edges = np.array([3, 780, 21, 190]); B = len(n_edges)
