@@ -64,6 +64,55 @@ def dense_flops_per_step(N, M, d, folded=True):
     return mlp + M * 2 * d * 4 * d + N * 2 * 2 * d * 4 * d + N * 2 * d * 4 * d
 
 
+PROFILE_ROUNDS = ("r04", "r03")   # newest first: the rocprofv3 summaries bench.py quotes (profiles/<round>_<workload>_...)
+
+
+def profile_kernel_stats(workload):
+    """-> (relative path, {kernel name: (calls, avg_us)}) from the newest committed rocprofv3 --kernel-trace --stats
+    summary of THIS workload's replayed forward (profiles/rNN_<workload>_forward_kernel_stats.txt, written by
+    profiles/summarize_rocpd.py from `rocprofv3 --kernel-trace --stats -- python tools/forward_graph.py <workload> 20`).
+    rocprofv3 cannot run inside bench.py; the file travels with the repo, so every figure quoted from it can be
+    recomputed from that one named file."""
+    for rnd in PROFILE_ROUNDS:
+        rel = "profiles/%s_%s_forward_kernel_stats.txt" % (rnd, workload)
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        out = {}
+        with open(path) as f:
+            for line in f:
+                if line.startswith("#") or line.startswith("kernel "):
+                    continue
+                parts = line.rstrip().rsplit(None, 9)   # name | grid wg lds vgpr calls avg min max pct
+                if len(parts) != 10:
+                    continue
+                name, calls, avg = parts[0].strip(), int(parts[5]), float(parts[6])
+                if name not in out or calls > out[name][0]:
+                    out[name] = (calls, avg)
+        return rel, out
+    return None, {}
+
+
+def profile_lookup(stats, *needles):
+    """The entry with the most calls whose kernel name contains every needle."""
+    best = None
+    for name, (calls, avg) in stats.items():
+        if all(n in name for n in needles) and (best is None or calls > best[1]):
+            best = (name, calls, avg)
+    return best
+
+
+def cell_launch_bytes(N, M, d, eb=4):
+    """Compulsory bytes of ONE cell + message launch of the fused forward: the edge task reads h, c and writes
+    h', c' and the next step's messages ([M, d] each), gathers the projected messages Zx[N, 4d] and the endpoints; the
+    vertex task reads the aggregate x, h, c, writes h', c' ([N, d] each) and the next Zx.  Weights (112 + 258 KB per
+    workgroup, L2 hits) are not counted."""
+    edge = 5 * M * d * eb + N * 4 * d * 4 + 2 * M * 4
+    vertex = 5 * N * d * eb + N * 4 * d * 4
+    return {"edge_states_and_messages": 5 * M * d * eb, "Zx_read": N * 4 * d * 4, "endpoints": 2 * M * 4,
+            "vertex_side": vertex, "total": edge + vertex}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +126,10 @@ def main():
                                                                "under 'train' when --mode forward")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
                                                             "the captured HIP graph of the forward pass")
+    ap.add_argument("--serve-batches", type=int, default=24,
+                    help="fresh-batch ('serve') leg: this many batches of NEW instances go host instances -> native packer "
+                         "-> BatchPrefetcher (worker thread, side-stream upload) -> DeviceBatch.copy_from -> replayed graph; "
+                         "0 skips it.  Reported under 'serve', never in 'value'.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (bounded sample)")
     args = ap.parse_args()
@@ -174,6 +227,55 @@ def main():
     loss = float(out["stats"][0].item())
     if not np.isfinite(loss):
         raise SystemExit("non-finite loss in the timed region")
+    # ---- the fresh-batch path (">= 6x at 8 GPUs hinges on the host packer and launch overhead"): every
+    # batch is NEW host instances -> tspgnn_host_pack_batch (native) -> upload on a side stream behind the previous
+    # batch -> copied into the buffers of the captured graph -> replay.  Every rank packs its own shard concurrently, so at
+    # N > 1 this is where host contention between the ranks' packers would show; the resident-batch `value` cannot see it.
+    serve = None
+    if args.mode == "forward" and use_graph and args.serve_batches > 0:
+        try:
+            rng = np.random.RandomState(99 + rank)
+            uniq = sorted(set(int(n) for n in sizes))
+            pool = {n: [tspgnn.random_instance(n, rng) for _ in range(min(len(sizes), 64) if len(uniq) > 1 else 3 * len(sizes))]
+                    for n in uniq}
+
+            def fresh_batches(nb):
+                for i in range(nb):
+                    inst = [pool[int(n)][(i * 37 + j) % len(pool[int(n)])] for j, n in enumerate(sizes)]
+                    yield tspgnn.InstanceLoader.create_batch(inst, dev=0.02)
+
+            t_p0 = time.perf_counter()
+            for _ in fresh_batches(4):
+                pass
+            pack_ms = 1e3 * (time.perf_counter() - t_p0) / 4
+            for bb in tspgnn.BatchPrefetcher(sess, fresh_batches(3), T):      # warm-up: allocator, worker thread
+                dev_batch.copy_from(bb)
+                replay()
+            barrier()
+            t_s0 = time.perf_counter()
+            keep = []
+            for bb in tspgnn.BatchPrefetcher(sess, fresh_batches(args.serve_batches), T):
+                dev_batch.copy_from(bb)
+                keep.append(replay()["predictions"].clone())
+            barrier()
+            dt_serve = time.perf_counter() - t_s0
+            if world > 1:
+                tmax = torch.tensor([dt_serve, pack_ms], dtype=torch.float64, device=device)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt_serve, pack_ms = float(tmax[0].item()), float(tmax[1].item())
+            serve = {"what": "fresh instances every batch: host instances -> native packer (worker thread) -> side-stream "
+                             "upload -> DeviceBatch.copy_from -> replayed forward graph; one packer + prefetcher per rank; "
+                             "max over ranks", "batches": args.serve_batches,
+                     "ms_per_batch": round(1e3 * dt_serve / args.serve_batches, 4),
+                     "value": round(world * args.serve_batches * T / dt_serve, 2), "unit": "mp-steps/s",
+                     "host_pack_ms_per_batch_one_thread": round(pack_ms, 3), "n_gpus": world,
+                     "finite": bool(all(torch.isfinite(k).all().item() for k in keep))}
+            dev_batch.copy_from(sess.prepare(feed))   # the benchmark batch back in the graph's buffers
+            replay()
+            torch.cuda.synchronize()
+        except Exception as exc:   # noqa: BLE001 -- reported, not swallowed
+            serve = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     train = None
     if args.mode == "forward" and args.train_steps > 0:
         # the training step (backward + RCCL all-reduce of the 462 KB gradient bucket + fused optimiser), reported
@@ -330,15 +432,17 @@ def main():
         # HBM-side bytes per launch (pair) from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py):
         # profiles/r02_spmm_pmc_traffic.json, keyed by workload
         traffic, traffic_src, prof_fwd = None, None, {}
-        tname = next((n for n in ("r03_spmm_pmc_traffic.json", "r02_spmm_pmc_traffic.json")
-                      if os.path.exists(os.path.join(ROOT, "profiles", n))), "r02_spmm_pmc_traffic.json")
-        tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                ent = json.load(f).get(args.workload)
-            if ent:
-                traffic, traffic_src = ent.get("pair_traffic_bytes"), "profiles/%s: " % tname + ent.get("how", "")
-                prof_fwd = ent.get("in_forward", {})
+        tname = None
+        for rnd in PROFILE_ROUNDS + ("r02",):     # newest round that measured THIS workload
+            cand = "%s_spmm_pmc_traffic.json" % rnd
+            if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+                with open(os.path.join(ROOT, "profiles", cand)) as f:
+                    ent = json.load(f).get(args.workload)
+                if ent:
+                    tname = cand
+                    traffic, traffic_src = ent.get("pair_traffic_bytes"), "profiles/%s: " % tname + ent.get("how", "")
+                    prof_fwd = ent.get("in_forward", {})
+                    break
         # the SAME kernels where they execute: inside the forward pass (the instrumented eager pass above -- HIP events on
         # the launch stream around every launch, operands produced by the preceding launch, not replayed from cache)
         in_forward = {}
@@ -372,33 +476,82 @@ def main():
             "spmm_steps_per_s": round(1e6 / t_pair, 1), "incidences_per_s": round(4 * M * 1e6 / t_pair, 1),
             "how": "HIP events on the launch stream, 300 launches of the same operands",
         }
-        if rowsum_in_fwd_us and rowsum_in_fwd_us > 0:
-            where_us, where_how = rowsum_in_fwd_us, ("replayed HIP graph of the timed forward with and without its %d row-sum "
-                                                     "launches, medians of 5 x 20 alternating replays, difference / T "
-                                                     "(includes the launch boundary the kernel adds)" % T)
-        elif rk in kernels_us:
-            where_us, where_how = kernels_us[rk]["avg_us"], "HIP events around each launch in the eager forward"
+        # ---- the headline roofline: the V<-E row-sum launch's OWN duration where the product runs it.
+        #   avg_us / frac: the kernel's average duration in the replayed forward as rocprofv3's kernel trace recorded it
+        #     (begin -> end of the dispatch), read from the committed summary of THIS workload -- recomputable from that one
+        #     named file: frac = algorithmic bytes / avg_us / 8 TB/s;
+        #   live_events_us: HIP events on the launch stream around each launch of the (eager) forward, measured now on this
+        #     box -- includes ~2 us of launch gap on a ~7 us kernel, so it reads higher than the kernel's own duration;
+        #   marginal_cost_us: (replayed forward - replayed forward without its row-sum launches) / T -- what the pass PAYS
+        #     for the aggregation (a difference of two replays, NOT a kernel time: the launch that follows starts cold).
+        prof_path, prof_stats = profile_kernel_stats(args.workload)
+        rs_prof = profile_lookup(prof_stats, "csr_rowsum_bf16" if bf16 else "csr_rowsum_kernel")
+        live_us = kernels_us[rk]["avg_us"] if rk in kernels_us else None
+        if rs_prof:
+            where_us = rs_prof[2]
+            where_how = ("rocprofv3 --kernel-trace --stats of the replayed forward (tools/forward_graph.py %s 20): average "
+                         "duration of %d dispatches of `%s`" % (args.workload, rs_prof[1], rs_prof[0]))
+            where_src = prof_path
+        elif live_us is not None:
+            where_us, where_how, where_src = live_us, "HIP events around each launch in the eager forward (no committed " \
+                "rocprofv3 summary for this workload)", "live"
         else:
-            where_us, where_how = t_rowsum, "micro-loop (no row-sum launch in this forward)"
+            where_us, where_how, where_src = t_rowsum, "micro-loop (no row-sum launch in this forward)", "live"
         rs_traffic = None
         for _gk, pf in sorted(prof_fwd.get("csr_rowsum", {}).items()):
             rs_traffic = pf.get("traffic_bytes", rs_traffic)
         roofline = {
             "kernel": "%s IN THE TIMED FORWARD: the V<-E aggregation launch of a message-passing step, reading the messages "
                       "the cell launch has just written (the E<-V direction has no launch of its own: Zx[u] + Zx[v] is the "
-                      "edge cell's operand gather inside the fused launch, see roofline_dense)" % rk,
+                      "edge cell's operand gather inside the fused launch, see roofline_cell)" % rk,
             "bound": "hbm", "achieved": round(rowsum_b / where_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(rowsum_b / where_us / 1e3 / HBM_PEAK_GBS, 4), "avg_us": round(where_us, 2), "how": where_how,
+            "source": where_src,
+            "live_events_us": round(live_us, 2) if live_us is not None else None,
+            "live_events_frac": round(rowsum_b / live_us / 1e3 / HBM_PEAK_GBS, 4) if live_us else None,
+            "marginal_cost_us": round(rowsum_in_fwd_us, 2) if rowsum_in_fwd_us and rowsum_in_fwd_us > 0 else None,
+            "marginal_cost_how": "replayed HIP graph of the timed forward with and without its %d row-sum launches, medians of "
+                                 "5 x 20 alternating replays, difference / T; a marginal cost of the pass, not a kernel "
+                                 "duration" % T,
             "traffic": rs_traffic,
+            "traffic_over_algorithmic": round(rs_traffic / rowsum_b, 3) if rs_traffic else None,
             "traffic_source": ("profiles/%s in_forward.csr_rowsum (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, "
-                               "separate passes, tools/forward_only.py)" % tname) if rs_traffic else None,
+                               "separate passes, tools/forward_only.py; FETCH_SIZE doubled per the gfx950 correction)" % tname)
+                              if rs_traffic else None,
             "algorithmic_bytes_per_launch": {"gather2_sum": gather_b, "csr_rowsum": rowsum_b},
             "in_forward": in_forward,
             "micro_loop": micro,
             "note": "north_star's target kernel where the product executes it.  `micro_loop` is the same kernel family timed "
-                    "back to back on one operand (SURVEY 8d M1 i) and is labelled as such; `in_forward` holds the per-launch "
-                    "HIP-event and rocprofv3 views of the same launches.",
+                    "back to back on one operand (SURVEY 8d M1 i) and is labelled as such.",
         }
+        # ---- the launch that decides the headline: cell + next step's messages (79 % of the pass).  HBM view: compulsory
+        # bytes over the launch's own duration (same committed rocprofv3 file), PMC bytes next to it.
+        roofline_cell = None
+        cell_prof = profile_lookup(prof_stats, "lnlstm_mlp_fwd_h2_kernel") if not bf16 else \
+            profile_lookup(prof_stats, "lnlstm_fwd_bf16_kernel")
+        if cell_prof:
+            cb = cell_launch_bytes(N, M, d, eb=2 if bf16 else 4)
+            if bf16:   # bf16 storage: h and messages bf16, c fp32; the message MLP is a launch of its own
+                cb = {"edge_states": M * d * (2 + 4 + 2 + 4), "Zx_read": N * 4 * d * 2, "endpoints": 2 * M * 4,
+                      "vertex_side": N * d * (2 + 2 + 4 + 2 + 4)}
+                cb["total"] = sum(cb.values())
+            cell_traffic = None
+            for key in ("cell_launch", "cell_launch_bf16"):
+                for _gk, pf in sorted(prof_fwd.get(key, {}).items()):
+                    cell_traffic = pf.get("traffic_bytes", cell_traffic)
+            cname = "tspgnn_lnlstm_mlp_fwd_multi_h2" if not bf16 else "tspgnn_lnlstm_fwd_multi_bf16"
+            roofline_cell = {
+                "kernel": cell_prof[0], "bound": "hbm first, then VALU + MFMA issue (DESIGN 4)",
+                "compulsory_bytes_per_launch": cb, "avg_us": cell_prof[2], "dispatches": cell_prof[1],
+                "achieved": round(cb["total"] / cell_prof[2] / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(cb["total"] / cell_prof[2] / 1e3 / HBM_PEAK_GBS, 4),
+                "traffic": cell_traffic,
+                "traffic_over_compulsory": round(cell_traffic / cb["total"], 3) if cell_traffic else None,
+                "source": prof_path, "traffic_source": ("profiles/%s in_forward" % tname) if cell_traffic else None,
+                "live_events_us": round(kernels_us[cname]["avg_us"], 2) if cname in kernels_us else None,
+                "share_of_forward": round(cell_prof[1] * cell_prof[2] /
+                                          max(1e-9, sum(c * a for c, a in prof_stats.values())), 4),
+            }
         dense_names = ("tspgnn_mlp_fwd_f32", "tspgnn_mlp_fwd_multi_f32", "tspgnn_lnlstm_fwd_f32",
                        "tspgnn_lnlstm_fwd_multi_f32", "tspgnn_lnlstm_gather_fwd_f32", "tspgnn_linear_f32",
                        "tspgnn_mlp_fwd_multi_x3", "tspgnn_lnlstm_fwd_multi_x3", "tspgnn_lnlstm_mlp_fwd_multi_x3",
@@ -450,11 +603,13 @@ def main():
             "edges_per_s": round(mp_steps_per_s * M, 1),
             "incidences_per_s": round(mp_steps_per_s * 4 * M, 1),
             "roofline": roofline,
+            "roofline_cell": roofline_cell,
             "roofline_dense": roofline_dense,
             "cpu_baseline": cpu_baseline,
             "gemm": gemm,
             "mode": args.mode, "hip_graph": bool(use_graph),
             "train": train,
+            "serve": serve,
             "kernels_us": {k: {"n": v["n"], "avg_us": round(v["avg_us"], 2)} for k, v in kernels_us.items()},
             "host_pack_s": round(t_pack, 4),
             "loss": loss,

@@ -133,7 +133,8 @@ typedef struct tspgnn_mlp_task {
     int rows; int n_layers; unsigned relu_mask;
     const float* proj_w; float* proj_out;  /* optional: proj_out[rows,4d] = Y * P, proj_w = pack_weights(P[d,4d]) */
     unsigned* range_flag;  /* _h2 entry points only (optional, others ignore it): device word, |= 1 when an activation
-                              left the fp16 range of the f16x2 split (see tspgnn_pack_weights_h2) */
+                              left the fp16 range of the f16x2 split at the top, |= 2 (cell entry points) when a gate row's
+                              spread fell below the split's absolute error at the bottom (see tspgnn_pack_weights_h2) */
 } tspgnn_mlp_task;   /* fields as the arguments of tspgnn_mlp_fwd_f32 */
 
 typedef struct tspgnn_lstm_task {
@@ -207,6 +208,11 @@ int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_task
  *     have fp32's range.  Activations: an operand row of a GEMM (h, a message MLP's hidden activation, an aggregate)
  *     with an entry >= 65504 in magnitude overflows the same way; the kernels detect it where they split the operand
  *     and set bit 0 of the task's range_flag (then the launch's outputs are not to be used: re-run on _x3 / _f32);
+ *     the LOW end: the lo piece of an operand below 2^-3 is an fp16 subnormal, so the split of a small value carries an
+ *     ABSOLUTE error up to 2^-25 where fp32 carries a relative one -- immaterial next to a z of ordinary size, but
+ *     LayerNorm divides by the row's spread.  The cell kernels therefore keep the smallest positive variance they
+ *     normalise a gate row by and set bit 1 of range_flag when it is below (2^-5)^2 in units of the unscaled z (a row
+ *     of exactly zero variance -- exact operands -- does not count): same consequence as bit 0;
  *   mlp task:  wb = n_layers blocks of { packed[2*d*d] fp16, 2^s * bias[d] float }; Y comes back unscaled;
  *              proj_out = the PROJECTED-MESSAGE FORMAT of this family: 2^s * (Y P), blocked by 16 source rows -- the
  *              float4 (columns 16t + 4g .. 4g+3) of row v at float offset (((v/16) * d/4 + t) * 4 + g) * 64 + (v%16) * 4;

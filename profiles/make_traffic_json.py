@@ -65,5 +65,7 @@ for w in ("c2", "c4", "c5"):
     res[w] = ent
     print(w, "pair", ent["pair_traffic_bytes"], {t: {g: (x["traffic_bytes"], x["avg_us_under_profiler"]) for g, x in d.items()}
                                                   for t, d in ent["in_forward"].items()})
-tag = os.path.basename(os.path.normpath(SRC))
+tag = os.path.basename(os.path.normpath(os.path.abspath(SRC)))
+if not re.fullmatch(r"r\d\d\w*", tag):   # (round 3 ran with SRC='.' and committed profiles/._spmm_pmc_traffic.json)
+    raise SystemExit("make_traffic_json: source directory %r must be named after its round (r04, r04b, ...)" % SRC)
 json.dump(res, open(os.path.join(ROOT, "profiles", "%s_spmm_pmc_traffic.json" % tag), "w"), indent=1)

@@ -992,3 +992,121 @@ def test_f16x2_falls_back_when_only_the_pushed_product_leaves_the_range(cuda_dev
     # and a training step with these variables runs on bf16x3 from its first launch
     _, loss = sess.run([model["train_step"], model["loss"]], feed_dict=feed)
     assert np.isfinite(loss) and all(np.all(np.isfinite(v)) for v in model.store.state_dict().values())
+
+
+# ---------------------------------------------------------------- the LOW end of f16x2's range
+def _low_end_params(case, d, seed):
+    """Well-conditioned in the reference's fp32 (graphnn.py:18), small for an fp16 piece:
+    a: the E->V message MLP's last layer scaled by 1e-4;  b: both cells' state/gamma = 1e-3 (all of h tiny);
+    c: V_init = 0 and the E_init weights x 1e-3;  d: b AND every message-MLP bias zero AND every state/beta zero -- then
+    every term of a cell's z is tiny and only LayerNorm's rescaling brings the gates back to O(1)."""
+    p = {k: v.copy() for k, v in P.init_params(d, seed=seed, perturb=True).items()}
+    if case == "a":
+        for k in p:
+            if "E_msg_V_MLP_layer_4/" in k:
+                p[k] *= 1e-4
+    if case in ("b", "d"):
+        for k in p:
+            if k.endswith("state/gamma"):
+                p[k] = np.full_like(p[k], 1e-3) * np.sign(p[k] + 1e-30)
+    if case == "c":
+        p["V_init"] = np.zeros_like(p["V_init"])
+        for k in p:
+            if k.startswith("E_init_MLP") and k.endswith("kernel"):
+                p[k] *= 1e-3
+    if case == "d":
+        for k in p:
+            if ("_msg_" in k and k.endswith("bias")) or k.endswith("state/beta"):
+                p[k] = np.zeros_like(p[k])
+    return p
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+@pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "f32"])
+def test_small_activations_keep_the_1e5_budget(cuda_device, case, gemm):
+    """Inputs the reference's fp32 handles at 1e-7 whose activations sit where an fp16 piece is subnormal: every
+    arithmetic stays within 1e-5 of the float64 oracle -- f16x2 either by itself or because the kernels' variance floor
+    (range_flag bit 1) sent the batch to bf16x3."""
+    d, T = 64, 6
+    t = pack_tuple("ragged_B6", 1)
+    params = _low_end_params(case, d, 31)
+    model = tspgnn.build_network(d)
+    model["gnn"].gemm = gemm
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    EV, W, C, route_exists, n_vertices, n_edges = t
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    pred, last, loss = sess.run([model["predictions"], model["last_states"], model["loss"]], feed_dict=feed)
+    ref = TO.forward(TO.to_torch(params, torch.float64), _oracle_batch(t), T)
+    errs = {"pred": rel_err(pred, ref["predictions"].numpy()),
+            "E.h": rel_err(last["E"].h, ref["last_states"]["E"][0].numpy()),
+            "E.c": rel_err(last["E"].c, ref["last_states"]["E"][1].numpy()),
+            "V.h": rel_err(last["V"].h, ref["last_states"]["V"][0].numpy()),
+            "V.c": rel_err(last["V"].c, ref["last_states"]["V"][1].numpy())}
+    print("\n[low end %s %s] %s  guard bits %d  max|E.h| %.2e" % (
+        case, gemm, "  ".join("%s %.2e" % kv for kv in errs.items()), sess.last_range_bits,
+        float(np.abs(ref["last_states"]["E"][0].numpy()).max())))
+    assert all(e < REL_TOL for e in errs.values()), errs
+    assert abs(float(loss) - ref["loss"].item()) < REL_TOL
+    if gemm != "f16x2":
+        assert sess.last_range_bits == 0
+
+
+def test_variance_floor_routes_a_tiny_z_to_bf16x3(cuda_device):
+    """Case d (every term of z tiny): the unguarded f16x2 forward raises bit 1 of the range flag -- and only bit 1 --;
+    run() answers with bf16x3, a training step on the batch ends where a bf16x3-only session ends, and a batch of
+    ordinary size on the same session is not flagged."""
+    d, T = 64, 6
+    t = pack_tuple("ragged_B6", 1)
+    params = _low_end_params("d", d, 31)
+    ends = {}
+    for gemm in ("f16x2", "bf16x3"):
+        model = tspgnn.build_network(d)
+        model["gnn"].gemm = gemm
+        sess = tspgnn.Session(model)
+        sess.run(tspgnn.global_variables_initializer())
+        model.store.load(params)
+        EV, W, C, route_exists, n_vertices, n_edges = t
+        feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+                model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+        if gemm == "f16x2":
+            out = sess.forward_device(sess.prepare(feed))
+            raw = out["last_states"]["E"].h.cpu().numpy().copy()
+            assert int(sess.store.h2_guard()[0].item()) == 2
+            assert sess.range_exceeded() and sess.last_range_bits == 2
+            ref = TO.forward(TO.to_torch(params, torch.float64), _oracle_batch(t), T)
+            print("\n[variance floor] unguarded f16x2 E.h error %.2e (bar %.0e)"
+                  % (rel_err(raw, ref["last_states"]["E"][0].numpy()), REL_TOL))
+        _, loss = sess.run([model["train_step"], model["loss"]], feed_dict=feed)
+        assert np.isfinite(loss)
+        assert int(sess._adam["t"].item()) == 1 and sess._adam["step"] == 1
+        ends[gemm] = model.store.state_dict()
+        if gemm == "f16x2":
+            model.store.load(P.init_params(d, seed=31, perturb=True))
+            sess.last_range_bits = 0
+            sess.run(model["predictions"], feed_dict=feed)
+            assert sess.last_range_bits == 0 and model["gnn"].active_arith() == "h2"
+    for k in ends["bf16x3"]:
+        assert np.array_equal(ends["f16x2"][k], ends["bf16x3"][k]), k
+
+
+def test_train_step_clears_a_stale_range_flag(cuda_device):
+    """A flag left up by an unchecked forward() must not make the optimiser kernel skip a direct train_step() -- and
+    every one after it: train_step clears the word before the pass it judges."""
+    d, T = 64, 2
+    t = tspgnn.synthetic_batch([12, 12], seed=8)
+    model = tspgnn.build_network(d)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    EV, W, C, route_exists, n_vertices, n_edges = t
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    before = model.store.theta.clone()
+    sess.store.h2_guard()[0:1].fill_(1)            # what an overflowing, unchecked forward() leaves behind
+    for k in range(3):
+        sess.train_step(sess.prepare(feed))
+        assert int(sess._adam["t"].item()) == k + 1 and sess._adam["step"] == k + 1
+    assert not torch.equal(before, model.store.theta)
+    assert model["gnn"].active_arith() == "h2"

@@ -30,43 +30,19 @@
 #include "h2_tile.h"
 #include "mfma_tile.h"
 
-#ifndef H2_PIPE
-#define H2_PIPE 0   // 1: the edge task software-pipelined across tiles (measured slower; kept for A/B builds)
-#endif
-
-#ifndef H2_NT_STATE
-#define H2_NT_STATE 0   // A/B: non-temporal stores for the states h', c' of the edge task
-#endif
-#ifndef H2_NT_MSG
-#define H2_NT_MSG 0     // A/B: non-temporal stores for the messages
-#endif
-#ifndef H2_PIPE_DEFER
-#define H2_PIPE_DEFER 0 // A/B (pipelined loop): a tile's message rows are stored at the top of the NEXT tile, so that no
-#endif                  // store is young when the wavefront next waits for loads (a wait behind stores drains them)
-#ifndef H2_PIPE_C
-#define H2_PIPE_C 0     // A/B (pipelined loop): the row of c prefetched with h behind the previous tile's MLP
-#endif
-#ifndef H2_NT_LOADS
-#define H2_NT_LOADS 0   // A/B: the streamed state rows (h, c: read once) loaded non-temporally, so that they do not displace
-#endif                  // the projected-message rows the gathers re-read from the CU's 32 KB L1
-#ifndef H2_ABL
-#define H2_ABL 0   // development builds, timing by removal in the tile-at-a-time edge loop: 1 no Zx gathers, 2 no state loads
-#endif             // (h, c), 4 no stores, 8 no lock-step (vertex) task
 #ifndef H2_TRACE
 #define H2_TRACE 0   // development builds: per-phase cycle sums of the edge task's tile loop (tools/h2_trace.py)
 #endif
 
 namespace tspgnn {
 
-template <bool NT>
-__device__ __forceinline__ f32x4 ld4x(const float* p) {
-    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-    else return ld4(p);
-}
-template <bool NT>
-__device__ __forceinline__ void st4x(float* p, f32x4 v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
-    else st4(p, v);
+// The edge task's output rows (h', c', the next step's messages).  st4o() is the one place their store flavour is chosen.
+__device__ __forceinline__ void st4o(float* p, f32x4 v) {
+#if defined(H2_WT)   // (round-4 A/B, see DESIGN 7: write-through `sc0 sc1` stores leave no dirty lines for the kernel boundary)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#else
+    st4(p, v);
+#endif
 }
 
 #if H2_TRACE
@@ -264,55 +240,6 @@ __global__ __launch_bounds__(1024) void mlp_fwd_h2_kernel(const MlpTaskTableH2 t
     h2_range_report(tt.task[k].range_flag, wit);
 }
 
-// The cell arithmetic of mfma_tile.h's lstm_gates<D, true, SWAP> in two stages, one per gate pair, so that a tile's z
-// can be formed -- and normalised -- as (i, j) first and (f, o) second with half the accumulator registers live at a
-// time.  Same operations on the same values in the same order per element: bit-identical to the one-stage form.
-template <int D>
-__device__ __forceinline__ void lstm_gates_ij(f32x4 (&acc)[D / 8], const float* lds_ln, int g, f32x4 (&si)[D / 16],
-                                              f32x4 (&rj)[D / 16], float eps_z) {
-    constexpr int TPG = D / 16;
-    f32x4 gi[TPG], gj[TPG];
-#pragma unroll
-    for (int t = 0; t < TPG; ++t) {
-        gi[t] = acc[t];
-        gj[t] = acc[TPG + t];
-    }
-    ln_gate<TPG, H2_LN_SWAP != 0>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D, eps_z);
-    ln_gate<TPG, H2_LN_SWAP != 0>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D, eps_z);
-#pragma unroll
-    for (int t = 0; t < TPG; ++t) {
-        si[t].lo = sigmoid2_pre(gi[t].lo);
-        si[t].hi = sigmoid2_pre(gi[t].hi);
-        rj[t].lo = relu2(gj[t].lo);
-        rj[t].hi = relu2(gj[t].hi);
-    }
-}
-template <int D>
-__device__ __forceinline__ void lstm_gates_fo(f32x4 (&acc)[D / 8], f32x4 (&cf)[D / 16], const f32x4 (&si)[D / 16],
-                                              const f32x4 (&rj)[D / 16], const float* lds_ln, int g, f32x4 (&hn)[D / 16],
-                                              f32x4 (&nc)[D / 16], float eps_z) {
-    constexpr int TPG = D / 16;
-    f32x4 gf[TPG], go[TPG];
-#pragma unroll
-    for (int t = 0; t < TPG; ++t) {
-        gf[t] = acc[t];
-        go[t] = acc[TPG + t];
-    }
-    ln_gate<TPG, H2_LN_SWAP != 0>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D, eps_z);
-    ln_gate<TPG, H2_LN_SWAP != 0>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D, eps_z);
-#pragma unroll
-    for (int t = 0; t < TPG; ++t) {
-        nc[t].lo = fma2(si[t].lo, rj[t].lo, cf[t].lo * sigmoid2_pre(gf[t].lo));
-        nc[t].hi = fma2(si[t].hi, rj[t].hi, cf[t].hi * sigmoid2_pre(gf[t].hi));
-    }
-    ln_gate<TPG, H2_LN_SWAP != 0>(nc, lds_ln + 8 * D, lds_ln + 9 * D, g, D);
-#pragma unroll
-    for (int t = 0; t < TPG; ++t) {
-        hn[t].lo = relu2(nc[t].lo) * sigmoid2_pre(go[t].lo);
-        hn[t].hi = relu2(nc[t].hi) * sigmoid2_pre(go[t].hi);
-    }
-}
-
 // ---------------------------------------------------------------------------------- LN-LSTM (+ MLP) (f16x2)
 // z = 2^s ([x|h] K (+ gather-init / bias-init)), five LayerNorms and the gate arithmetic of dense.hip's cell --
 // optionally followed, on the same 16 rows while h' is still in registers, by the message MLP that consumes h' in the
@@ -385,6 +312,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int rl = lane & 15, g = lane >> 4;   // (re-derived per tile inside the loops: see opaque_lane)
     float wit = 0.f;                     // fp16-overflow witness of this wavefront's operand splits (h2_tile.h)
+    unsigned vmin = 0xffffffffu;         // smallest positive gate variance normalised by (low end of the range, h2_tile.h)
     // LayerNorm parameters, rows [g_i, b_i, g_j, b_j, g_f, b_f, g_o, b_o, g_s, b_s]: the gates i, f, o feed sigmoids
     // only, so their gamma / beta are stored times -log2(e) with the forget bias folded into b_f (lstm_gates<D, true>)
     for (int i = tid; i < 10 * D; i += blockDim.x) {
@@ -403,11 +331,8 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                            blockDim.x);
     };
     // z starts at 2^s * (its non-GEMM part); Zx is stored scaled by its producer (the f16x2 projection)
-    auto init_acc = [&](f32x4 (&acc)[NT4], unsigned rc) {
-        if ((H2_ABL & 1) && uv != nullptr) {
-#pragma unroll
-            for (int t = 0; t < NT4; ++t) acc[t] = f32x4{0.1f * t, 0.2f * rl, 0.3f * g, 0.4f};
-        } else if (uv != nullptr) {
+    auto init_acc = [&](f32x4 (&acc)[NT4], unsigned rc, bool live) {
+        if (uv != nullptr) {
             const int2 ends = uv[rc];
             const float* zu = Zx + h2_zx_row<D>((unsigned)ends.x, g);
             const float* zv = Zx + h2_zx_row<D>((unsigned)ends.y, g);
@@ -416,7 +341,9 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] += ld4(zv + t * 256);
         } else if (zbias != nullptr) {
-            const float sc = zscale[rc] * kH2Scale;
+            // (an idle wavefront of a lock-step round keeps z == 0: a variance of exactly 0 is not a row of the batch
+            // for the range guard, see ln_gate<..., TRACK>)
+            const float sc = live ? zscale[rc] * kH2Scale : 0.f;
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] = ld4(zbias + t * 16 + g * 4) * sc;
         } else {
@@ -430,14 +357,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         const float* hrow = h + h2_state_row<D>(rc, g, in_blk);
         for (int kb = kb0; kb < kb1; ++kb) {
             const float* src = kb < KBX ? xrow + kb * 32 : hrow + (kb - KBX) * 2 * in_ts;
-            f32x4 lo4, hi4;
-            if constexpr (H2_ABL & 2) {
-                lo4 = f32x4{0.01f * rl, 0.02f * g, 0.03f * kb, 0.5f};
-                hi4 = f32x4{0.5f, 0.04f * rl, 0.01f * g, 0.02f * kb};
-            } else {
-                lo4 = ld4x<H2_NT_LOADS != 0>(src);
-                hi4 = ld4x<H2_NT_LOADS != 0>(src + (kb < KBX ? 16 : in_ts));
-            }
+            const f32x4 lo4 = ld4(src), hi4 = ld4(src + (kb < KBX ? 16 : in_ts));
             float xv[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
             f16x8 bh, bl;
             split2w(xv, bh, bl, wit);
@@ -447,14 +367,14 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
     // gates + state stores; returns h' in registers (the D layout is the next GEMM's B operand)
     auto cell = [&](f32x4 (&acc)[NT4], f32x4 (&cf)[TPG], unsigned rc, bool valid, f32x4 (&hn)[TPG]) {
         f32x4 nc[TPG];
-        lstm_gates<D, true, H2_LN_SWAP != 0, CENTERED>(acc, cf, lds_ln, g, hn, nc, kH2GateEps);
-        if ((H2_ABL & 4) ? (valid && hn[0][0] == 12345.678f) : valid) {   // (ablation: the stores depend on the values, never run)
+        lstm_gates<D, true, H2_LN_SWAP != 0, CENTERED, true>(acc, cf, lds_ln, g, hn, nc, kH2GateEps, &vmin);
+        if (valid) {
             float* hd = h_out + h2_state_row<D>(rc, g, out_blk);
             float* cd = c_out + h2_state_row<D>(rc, g, out_blk);
 #pragma unroll
             for (int t = 0; t < TPG; ++t) {
-                st4x<H2_NT_STATE != 0>(hd + t * out_ts, hn[t]);
-                st4x<H2_NT_STATE != 0>(cd + t * out_ts, nc[t]);
+                st4o(hd + t * out_ts, hn[t]);
+                st4o(cd + t * out_ts, nc[t]);
             }
         }
     };
@@ -470,229 +390,6 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         if (tid == 0) *ticket = t_beg;
         h2_stage_wait();
         __syncthreads();
-#if H2_PIPE
-        if (uv != nullptr && dx == 0) {
-            // Gather-init (edge) tiles, software-pipelined ACROSS tiles.  A tile used to open with a chain of dependent
-            // round trips -- ticket -> endpoints -> projected-message gathers -> state rows -- during which the
-            // wavefront was parked (two fifths of all wave cycles, profiles/r03a_c2_forward_pmc_mfma_baseline.txt), and
-            // three wavefronts per SIMD do not cover it.  Here z is formed in gate pairs, (i, j) then (f, o): with half
-            // the accumulators live, the registers that fall free behind the gate arithmetic take the NEXT tile's loads
-            // -- its endpoints during the second GEMM half, its (i, j) gathers and h rows during the message MLP -- and
-            // the (f, o) gathers and the row of c of the current tile fly behind its first GEMM half.  A tile therefore
-            // starts with its operands in registers.  Arithmetic and summation order per element are unchanged.
-            constexpr int HN = NT4 / 2;
-            auto take = [&]() {
-                int t = 0;
-                if (lane == 0) t = atomicAdd(ticket, 1);
-                return __builtin_amdgcn_readfirstlane(t);
-            };
-            int tile = take();
-            f32x4 zu[HN], zv[HN], hr[TPG];
-#if H2_PIPE_C
-            f32x4 cr[TPG];
-#endif
-            int2 ends;
-            {
-                const int l = opaque_lane();
-                rl = l & 15;
-                g = l >> 4;
-                const unsigned rc0 = (unsigned)min(tile * 16 + rl, rows - 1);
-                ends = uv[rc0];
-                const float* pu = Zx + h2_zx_row<D>((unsigned)ends.x, g);
-                const float* pv = Zx + h2_zx_row<D>((unsigned)ends.y, g);
-                const float* ph = h + h2_state_row<D>(rc0, g, in_blk);
-#pragma unroll
-                for (int t = 0; t < HN; ++t) zu[t] = ld4(pu + t * 256);
-#pragma unroll
-                for (int t = 0; t < HN; ++t) zv[t] = ld4(pv + t * 256);
-#pragma unroll
-                for (int t = 0; t < TPG; ++t) hr[t] = ld4(ph + t * in_ts);
-#if H2_PIPE_C
-#pragma unroll
-                for (int t = 0; t < TPG; ++t)
-                    cr[t] = c != nullptr ? ld4(c + h2_state_row<D>(rc0, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
-            }
-#if H2_PIPE_DEFER
-            f32x4 msg_prev[TPG];
-            unsigned msg_row = 0;
-            bool msg_pending = false;
-#pragma unroll
-            for (int t = 0; t < TPG; ++t) msg_prev[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
-            TR_DECL;
-            while (tile < t_end) {
-                TR(0);
-                {
-                    const int l = opaque_lane();
-                    rl = l & 15;
-                    g = l >> 4;
-                }
-                const int row = tile * 16 + rl;
-                const bool valid = row < rows;
-                const unsigned rc = (unsigned)(valid ? row : rows - 1);
-                f32x4 hn[TPG];
-                int tile_next;
-                int2 ends_next;
-                unsigned rc_next;
-                const float *pu_n, *pv_n, *ph_n;
-                {
-                    f32x4 si[TPG], rj[TPG], cf[TPG];
-                    f16x8 bh[KBH], bl[KBH];
-                    {
-                        f32x4 acc[HN];
-#pragma unroll
-                        for (int t = 0; t < HN; ++t) acc[t] = zu[t] + zv[t];
-#pragma unroll
-                        for (int kb = 0; kb < KBH; ++kb) {
-                            float xv[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) xv[j] = hr[2 * kb + (j >> 2)][j & 3];
-                            split2w(xv, bh[kb], bl[kb], wit);
-                        }
-                        // (pinned: the sums and the split free the registers the loads below land in; an empty asm makes each
-                        // value opaque at this point, so neither the optimiser nor the scheduler can sink the arithmetic below
-                        // the loads or hoist the loads above it)
-#pragma unroll
-                        for (int t = 0; t < HN; ++t) asm volatile("" : "+v"(acc[t]));
-#pragma unroll
-                        for (int kb = 0; kb < KBH; ++kb) asm volatile("" : "+v"(bh[kb]), "+v"(bl[kb])::"memory");
-                        __builtin_amdgcn_sched_barrier(0);
-                        TR(1);
-#if H2_PIPE_DEFER
-                        if (msg_pending) {   // the previous tile's messages (see H2_PIPE_DEFER)
-#pragma unroll
-                            for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (msg_row * D + g * 4 + t * 16), msg_prev[t]);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#endif
-                        // second gate pair's gathers and the row of c: in flight behind the first GEMM half
-                        const float* pu = Zx + h2_zx_row<D>((unsigned)ends.x, g) + HN * 256;
-                        const float* pv = Zx + h2_zx_row<D>((unsigned)ends.y, g) + HN * 256;
-#pragma unroll
-                        for (int t = 0; t < HN; ++t) zu[t] = ld4(pu + t * 256);
-#pragma unroll
-                        for (int t = 0; t < HN; ++t) zv[t] = ld4(pv + t * 256);
-#if H2_PIPE_C
-#pragma unroll
-                        for (int t = 0; t < TPG; ++t) cf[t] = cr[t];
-#else
-                        if (c != nullptr) {
-                            const float* pc = c + h2_state_row<D>(rc, g, in_blk);
-#pragma unroll
-                            for (int t = 0; t < TPG; ++t) cf[t] = ld4(pc + t * in_ts);
-                        } else {
-#pragma unroll
-                            for (int t = 0; t < TPG; ++t) cf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        }
-#endif
-                        tile_next = take();
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int kb = 0; kb < KBH; ++kb)
-                            kblock_h2_part<NT4, 0, HN>(acc, lds_w, lds_w + chunk_total, kb, g, rl, bh[kb], bl[kb]);
-                        lstm_gates_ij<D>(acc, lds_ln, g, si, rj, kH2GateEps);
-                    }
-                    rc_next = (unsigned)min(tile_next * 16 + rl, rows - 1);   // (clamped: in bounds past the last tile too)
-                    ends_next = uv[rc_next];
-                    // (the sums below wait for the gathers: pinned behind the first pair's work -- instruction selection would
-                    // otherwise place them, and their wait, at the top of the first GEMM half)
-                    __builtin_amdgcn_sched_barrier(0);
-#if H2_TRACE
-#pragma unroll
-                    for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(si[t]), "+v"(rj[t]));
-                    TR(2);
-#endif
-#pragma unroll
-                    for (int t = 0; t < HN; ++t) asm volatile("" : "+v"(zu[t]), "+v"(zv[t]));
-                    TR(3);
-                    {
-                        f32x4 acc[HN], nc[TPG];
-#pragma unroll
-                        for (int t = 0; t < HN; ++t) acc[t] = zu[t] + zv[t];
-#pragma unroll
-                        for (int kb = 0; kb < KBH; ++kb)
-                            kblock_h2_part<NT4, HN, HN>(acc, lds_w, lds_w + chunk_total, kb, g, rl, bh[kb], bl[kb]);
-                        lstm_gates_fo<D>(acc, cf, si, rj, lds_ln, g, hn, nc, kH2GateEps);
-                        // (the next tile's addresses are formed BEFORE the stores: behind the conditional stores the wait for
-                        // the endpoints would be a wait for every outstanding store as well)
-                        pu_n = Zx + h2_zx_row<D>((unsigned)ends_next.x, g);
-                        pv_n = Zx + h2_zx_row<D>((unsigned)ends_next.y, g);
-                        ph_n = h + h2_state_row<D>(rc_next, g, in_blk);
-                        asm volatile("" : "+v"(pu_n), "+v"(pv_n), "+v"(ph_n));
-                        if (valid) {
-                            float* hd = h_out + h2_state_row<D>(rc, g, out_blk);
-                            float* cd = c_out + h2_state_row<D>(rc, g, out_blk);
-#pragma unroll
-                            for (int t = 0; t < TPG; ++t) {
-                                st4x<H2_NT_STATE != 0>(hd + t * out_ts, hn[t]);
-                                st4x<H2_NT_STATE != 0>(cd + t * out_ts, nc[t]);
-                            }
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#if H2_TRACE
-#pragma unroll
-                for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(hn[t]));
-                TR(4);
-#endif
-                {   // the next tile's first gate pair and h rows: in flight behind the message MLP
-#pragma unroll
-                    for (int t = 0; t < HN; ++t) zu[t] = ld4(pu_n + t * 256);
-#pragma unroll
-                    for (int t = 0; t < HN; ++t) zv[t] = ld4(pv_n + t * 256);
-#pragma unroll
-                    for (int t = 0; t < TPG; ++t) hr[t] = ld4(ph_n + t * in_ts);
-#if H2_PIPE_C
-                    if (c != nullptr) {
-                        const float* pc = c + h2_state_row<D>(rc_next, g, in_blk);
-#pragma unroll
-                        for (int t = 0; t < TPG; ++t) cr[t] = ld4(pc + t * in_ts);
-                    }
-#endif
-                }
-                if (n_layers > 0) {
-                    for (int l = 0; l < n_layers; ++l) {
-                        const _Float16* wh = reinterpret_cast<const _Float16*>(lds_mlp + (size_t)l * LAYER_BYTES);
-                        const float* bias = reinterpret_cast<const float*>(lds_mlp + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
-                        dense_layer_h2<D>(hn, wh, wh + D * D, bias, (relu_mask >> l) & 1u, g, rl, wit);
-                        if (mlp_acts != nullptr && l < n_layers - 1 && valid) {
-                            float* dst = mlp_acts + ((size_t)l * acts_stride + (size_t)rc * D + g * 4);
-#pragma unroll
-                            for (int t = 0; t < TPG; ++t) st4(dst + t * 16, hn[t]);
-                        }
-                    }
-#if H2_PIPE_DEFER
-                    msg_pending = valid && mlp_out != nullptr;
-                    msg_row = rc;
-#pragma unroll
-                    for (int t = 0; t < TPG; ++t) msg_prev[t] = hn[t];
-#else
-                    if (valid && mlp_out != nullptr) {
-#pragma unroll
-                        for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
-                    }
-#endif
-                }
-                tile = tile_next;
-                ends = ends_next;
-#if H2_TRACE
-#pragma unroll
-                for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(hn[t]));
-                TR(5);
-                tr_acc[7] += 1;
-#endif
-            }
-#if H2_PIPE_DEFER
-            if (msg_pending) {
-#pragma unroll
-                for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (msg_row * D + g * 4 + t * 16), msg_prev[t]);
-            }
-#endif
-            TR_FLUSH;
-        } else
-#endif
         {
         TR_DECL;
         for (;;) {
@@ -713,7 +410,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
             f32x4 hn[TPG];
             {
                 f32x4 acc[NT4], cf[TPG];
-                init_acc(acc, rc);
+                init_acc(acc, rc, true);
 #if H2_TRACE
 #pragma unroll
                 for (int t = 0; t < NT4; ++t) asm volatile("" : "+v"(acc[t]));
@@ -721,9 +418,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
 #endif
 #pragma unroll
                 for (int t = 0; t < TPG; ++t)
-                    cf[t] = (H2_ABL & 2) ? f32x4{0.1f * t, 0.f, 0.2f * rl, 0.f}
-                            : c != nullptr ? ld4x<H2_NT_LOADS != 0>(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts)
-                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+                    cf[t] = c != nullptr ? ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
                 kloop(acc, rc, 0, 0, KBT);
 #if H2_TRACE
 #pragma unroll
@@ -748,9 +443,9 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                         for (int t = 0; t < TPG; ++t) st4(dst + t * 16, hn[t]);
                     }
                 }
-                if (((H2_ABL & 4) ? hn[0][0] == 12345.678f : true) && valid && mlp_out != nullptr) {
+                if (valid && mlp_out != nullptr) {
 #pragma unroll
-                    for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                    for (int t = 0; t < TPG; ++t) st4o(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
             }
 #if H2_TRACE
@@ -769,7 +464,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         // (fewer working wavefronts per workgroup than it has -- lock_tiles -- spread the task over more CUs: its GEMMs
         // are bound by the matrix pipes of the few CUs it runs on)
         const int lw = tt.lock_tiles[k];
-        const int rounds = (H2_ABL & 8) ? 0 : (tiles_total + lw - 1) / lw;
+        const int rounds = (tiles_total + lw - 1) / lw;
         TR_DECL;
         for (int r = my_blk; r < rounds; r += my_grid) {
             {
@@ -785,7 +480,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
             f32x4 hn[TPG];
             {
                 f32x4 acc[NT4], cf[TPG];
-                init_acc(acc, rc);
+                init_acc(acc, rc, live);
                 // The [x | h] operand rows of up to four k-blocks are fetched before the K staging is waited for: every
                 // wavefront of the workgroup is in the same phase here, nobody hides a global round trip per k-block.
                 constexpr int KBP = 4;
@@ -864,7 +559,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 }
                 if (valid && mlp_out != nullptr) {
 #pragma unroll
-                    for (int t = 0; t < TPG; ++t) st4x<H2_NT_MSG != 0>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                    for (int t = 0; t < TPG; ++t) st4(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
 #if H2_TRACE
 #pragma unroll
@@ -905,7 +600,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
         }
         TR_FLUSH;
     }
-    h2_range_report(tk.range_flag, wit);
+    h2_range_report(tk.range_flag, wit, vmin);
 }
 
 static int split_blocks_h2(const long long* cost, int n, int grid, int* blk_end) {

@@ -16,6 +16,14 @@ constexpr float kH2Scale = (float)(1 << kH2ScaleLog2);
 constexpr float kH2InvScale = 1.0f / kH2Scale;
 constexpr float kH2GateEps = 1e-12f * kH2Scale * kH2Scale;  // LayerNorm epsilon of a z scaled by 2^s
 constexpr float kNegLog2e = -1.4426950408889634f;
+// The low end of the range.  The lo piece of an operand below 2^-3 is an fp16 subnormal: the split of such a value carries
+// an ABSOLUTE error up to 2^-25 where the reference's fp32 carries a relative one.  Through a GEMM with weights of
+// magnitude w that is ~2^-25 * 2^s * w * sqrt(K) in the scaled z (7e-7 for xavier weights at K = 64) -- nothing next to a
+// z of ordinary size, but LayerNorm divides by the row's spread: a gate row whose standard deviation is below 2^-5 (in
+// units of the unscaled z) would come out with a relative error above ~1e-6 per step.  The cell kernels keep the smallest
+// positive variance they normalise by (ln_gate<..., TRACK>) and raise bit 1 of the task's range_flag when it is below
+// this floor; the caller repeats the batch on bf16x3 (whose pieces keep fp32's exponent range), exactly as for bit 0.
+constexpr float kH2VarFloor = kH2Scale * kH2Scale / 1024.0f;   // (2^-5)^2 in units of the scaled z's variance
 
 // x = hi + lo to 2^-24 relative: two v_cvt_pk_f16_f32 and two v_fma_mix_f32 (x - float(hi), the fp16 operand widened
 // inside the instruction) per pair of values.
@@ -59,10 +67,12 @@ __device__ __forceinline__ void split2w(const float (&x)[8], f16x8& hi, f16x8& l
         lo[i + 1] = l[1];
     }
 }
-__device__ __forceinline__ void h2_range_report(unsigned* flag, float wit) {
-    if (flag != nullptr && __any(!(wit <= 3.0e38f))) {
-        if ((threadIdx.x & 63) == 0) atomicOr(flag, 1u);
-    }
+__device__ __forceinline__ void h2_range_report(unsigned* flag, float wit, unsigned vmin = 0xffffffffu) {
+    if (flag == nullptr) return;
+    unsigned bits = __any(!(wit <= 3.0e38f)) ? 1u : 0u;
+    // vmin = (smallest positive variance's bit pattern) - 1, see ln_gate<..., TRACK>
+    if (__any(vmin < __float_as_uint(kH2VarFloor) - 1u)) bits |= 2u;
+    if (bits != 0u && (threadIdx.x & 63) == 0) atomicOr(flag, bits);
 }
 
 // The projected messages Zx = 2^s (y Kx) between an f16x2 projection (producer, vertex rows) and an f16x2 cell in
@@ -125,34 +135,6 @@ __device__ __forceinline__ void kblock_h2(f32x4 (&acc)[NT], const _Float16* wh, 
         const f16x8 a_h = ah[t % (PF + 1)], a_l = al[t % (PF + 1)];
         f32x4 c = acc[t];
         c = MFMA_F16(a_l, bh, c);  // smallest terms first
-        c = MFMA_F16(a_h, bl, c);
-        c = MFMA_F16(a_h, bh, c);
-        acc[t] = c;
-    }
-}
-
-// The same for the TN output tiles T0 .. T0+TN-1 of a matrix with NTOT output tiles (a gate pair of the cell's z):
-// per accumulator the same MFMA sequence as kblock_h2<NTOT>, so a GEMM done in column halves is bit-identical.
-template <int NTOT, int T0, int TN>
-__device__ __forceinline__ void kblock_h2_part(f32x4 (&acc)[TN], const _Float16* wh, const _Float16* wl, int kb, int g, int jl,
-                                               const f16x8& bh, const f16x8& bl) {
-    const int off = ((kb * 4 + g) * NTOT * 16 + jl) * 8 + T0 * 128;
-    constexpr int PF = H2_PF < TN ? H2_PF : TN;
-    f16x8 ah[PF + 1], al[PF + 1];
-#pragma unroll
-    for (int p = 0; p < PF; ++p) {
-        ah[p] = ldw(wh + off + p * 128);
-        al[p] = ldw(wl + off + p * 128);
-    }
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        if (t + PF < TN) {
-            ah[(t + PF) % (PF + 1)] = ldw(wh + off + (t + PF) * 128);
-            al[(t + PF) % (PF + 1)] = ldw(wl + off + (t + PF) * 128);
-        }
-        const f16x8 a_h = ah[t % (PF + 1)], a_l = al[t % (PF + 1)];
-        f32x4 c = acc[t];
-        c = MFMA_F16(a_l, bh, c);
         c = MFMA_F16(a_h, bl, c);
         c = MFMA_F16(a_h, bh, c);
         acc[t] = c;

@@ -112,9 +112,13 @@ __device__ __forceinline__ float sum_over_lane_groups16_swap(float v) {
 // CENTERED: the rows of v have zero mean already -- the caller's GEMM used operands whose columns were centred per gate
 // (LayerNorm's mean subtraction is the linear map I - 11^T/D on a gate's columns and commutes with the product; see
 // tspgnn_lstm_task.z_centered) -- so the mean pass (sum, lane reduction, subtraction: 23 of ~60 instructions) is skipped.
-template <int TPG, bool SWAP = false, bool CENTERED = false>
+// TRACK: *vmin (unsigned, starts at 0xffffffff) keeps the smallest POSITIVE variance this lane has normalised by, as
+// (bit pattern - 1) -- positive floats order like their bit patterns, and a variance of exactly 0 (a constant row: exact
+// operands) wraps to the maximum and is ignored.  The f16x2 kernels turn it into bit 1 of the task's range_flag: a z whose
+// spread is below the absolute error of its operands' fp16 pieces (h2_tile.h, kH2VarFloor).
+template <int TPG, bool SWAP = false, bool CENTERED = false, bool TRACK = false>
 __device__ __forceinline__ void ln_gate(f32x4 (&v)[TPG], const float* gamma, const float* beta, int g, int D,
-                                        float eps = 1e-12f) {
+                                        float eps = 1e-12f, unsigned* vmin = nullptr) {
     auto lane_sum = [](float x) { return SWAP ? sum_over_lane_groups16_swap(x) : sum_over_lane_groups16(x); };
     f32x2 q2 = {0.f, 0.f};
     if constexpr (CENTERED) {
@@ -139,6 +143,10 @@ __device__ __forceinline__ void ln_gate(f32x4 (&v)[TPG], const float* gamma, con
         }
     }
     const float var = lane_sum(q2[0] + q2[1]) * (1.0f / (float)D);
+    if constexpr (TRACK) {
+        const unsigned vb = __float_as_uint(var) - 1u;
+        *vmin = vb < *vmin ? vb : *vmin;
+    }
     const float rstd = __builtin_amdgcn_rsqf(var + eps);  // v_rsq_f32, ~1 ulp
     const f32x2 r2 = {rstd, rstd};
 #pragma unroll
@@ -174,9 +182,10 @@ __device__ __forceinline__ f32x2 sigmoid2_pre(f32x2 t) {
 // beta_f), so their LayerNorm output is the exponent of the sigmoid directly -- one packed multiply-add per pair less;
 // eps_z: the epsilon of the four gate LayerNorms (a caller whose z is scaled by 2^s passes 2^2s * 1e-12, which makes
 // the normalised gates those of the unscaled z exactly -- a power-of-two scale commutes with every rounding).
-template <int D, bool PRE = false, bool SWAP = false, bool CENTERED = false>
+template <int D, bool PRE = false, bool SWAP = false, bool CENTERED = false, bool TRACK = false>
 __device__ __forceinline__ void lstm_gates(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 16], const float* lds_ln, int g,
-                                           f32x4 (&hn)[D / 16], f32x4 (&nc)[D / 16], float eps_z = 1e-12f) {
+                                           f32x4 (&hn)[D / 16], f32x4 (&nc)[D / 16], float eps_z = 1e-12f,
+                                           unsigned* vmin = nullptr) {
     constexpr int TPG = D / 16;
     f32x4 gi[TPG], gj[TPG], gf[TPG], go[TPG];
 #pragma unroll
@@ -186,10 +195,10 @@ __device__ __forceinline__ void lstm_gates(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 
         gf[t] = acc[2 * TPG + t];
         go[t] = acc[3 * TPG + t];
     }
-    ln_gate<TPG, SWAP, CENTERED>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D, eps_z);
-    ln_gate<TPG, SWAP, CENTERED>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D, eps_z);
-    ln_gate<TPG, SWAP, CENTERED>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D, eps_z);
-    ln_gate<TPG, SWAP, CENTERED>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP, CENTERED, TRACK>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D, eps_z, vmin);
+    ln_gate<TPG, SWAP, CENTERED, TRACK>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D, eps_z, vmin);
+    ln_gate<TPG, SWAP, CENTERED, TRACK>(gf, lds_ln + 4 * D, lds_ln + 5 * D, g, D, eps_z, vmin);
+    ln_gate<TPG, SWAP, CENTERED, TRACK>(go, lds_ln + 6 * D, lds_ln + 7 * D, g, D, eps_z, vmin);
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
         if constexpr (PRE) {

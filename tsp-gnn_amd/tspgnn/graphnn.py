@@ -1423,15 +1423,20 @@ class GraphNN(object):
         if arith == "h2":
             # the step's f16x2 packings up front (they are cached for the tasks below), so that the guard can veto them
             # before any kernel multiplies with them
-            for cell in self._RNN_cells.values():
-                cell._packed_split("h2", "lstm", 0, cell.dx + cell.d)
+            # (exactly the packings the tasks below take: a folded cell multiplies with Kh and projects with Kx, a pushed
+            # one with the PRODUCT [W Kx ; Kh] -- which can leave the range on its own --, the others with the whole kernel)
+            for v, cell in self._RNN_cells.items():
+                if tape.folded[v] is not None:
+                    cell._packed_split("h2", "lstm.kh", cell.dx, cell.dx + cell.d)
+                    if "msg" in tape.folded[v]:
+                        cell._packed_split("h2", "lstm.kx", 0, cell.dx)
+                elif self.push_training and not self.fuse_training_messages and self._pushable(v, mats, tape.folded):
+                    cell.pushed_bias_pack(self._msg_MLPs[self.loop[v][0]["msg"]], arith="h2")
+                else:
+                    cell._packed_split("h2", "lstm", 0, cell.dx + cell.d)
             for mlp in self._msg_MLPs.values():
                 if len(mlp._chunks()) == 1:
                     mlp.wb_packed_split("h2", 0, mlp.n_square - 1, mlp.sizes[-1])
-            if self.push_training and not self.fuse_training_messages:
-                for v in self.var:   # a pushed cell multiplies with the PRODUCT W Kx, which can leave the range on its own
-                    if self._pushable(v, mats, tape.folded):
-                        self._RNN_cells[v].pushed_bias_pack(self._msg_MLPs[self.loop[v][0]["msg"]], arith="h2")
             if not self.check_h2_weights():
                 arith = self._split_arith({v: initial_embeddings[v].shape[0] for v in self.var})
         tape.arith = arith

@@ -187,6 +187,7 @@ class Session(object):
         self.process_group = process_group
         self._replicas_synced = False
         self._synced_assignments = -1
+        self.last_range_bits = 0     # the f16x2 guard bits (1 overflow, 2 underflow) of the last flagged batch: diagnostics
 
     @property
     def world_size(self):
@@ -315,10 +316,12 @@ class Session(object):
         if self.device.type != "cuda":
             return False
         guard = self.store.h2_guard()
-        hit = bool(int(guard[0].item()) & 1)
-        if hit and clear:
-            guard[0:1].zero_()
-        return hit
+        bits = int(guard[0].item()) & 3     # bit 0: an operand beyond fp16's largest value; bit 1: a gate row whose spread
+        if bits:                            # is below the absolute error of its operands' fp16 pieces (h2_tile.h)
+            self.last_range_bits = bits
+            if clear:
+                guard[0:1].zero_()
+        return bool(bits)
 
     def capture_forward(self, batch):
         """Captures one forward pass over a resident batch into a HIP graph (hipStreamBeginCapture via
@@ -369,11 +372,7 @@ class Session(object):
             if missing:
                 raise ValueError("You must feed a value for placeholder(s) %s" % ", ".join(missing))
             if "train_step" in names:
-                out = self.train_step(feed_dict)
-                if self.range_exceeded():   # (Adam skipped the update on the device: the variables are untouched)
-                    self._adam["step"] -= 1     # the host mirror of the step counter counted the skipped attempt
-                    with self.model["gnn"].forced_off_h2():
-                        out = self.train_step(feed_dict)
+                out = self.train_step(feed_dict)   # (looks after the f16x2 range flag itself)
             else:
                 # a statistic of the batch is a statistic of the GLOBAL batch in a data-parallel session (collective:
                 # every rank fetches it, as run_batch does); predictions / last_states alone stay rank-local
@@ -550,7 +549,15 @@ class Session(object):
         (initialiser, load_weights / store.load) -- those happen on every rank or on rank 0 only, and either way the
         replicas must leave this call identical.  Collective when it fires: assignments must be made (or not made)
         at the same points of the program on every rank, like the training steps themselves."""
-        if not self._replicas_synced or self._synced_assignments != self.store.assignments:
+        need = not self._replicas_synced or self._synced_assignments != self.store.assignments
+        if self.world_size > 1:
+            # the decision is made TOGETHER (one 1-int all-reduce): a restore on rank 0 only bumps rank 0's counter alone,
+            # and a rank that broadcast while its peers went on to the gradient all-reduce would hang the job
+            import torch.distributed as dist
+            flag = torch.tensor([1 if need else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.process_group)
+            need = bool(int(flag.item()))
+        if need:
             self.broadcast_variables(0)
 
     def apply_gradients(self):
@@ -584,8 +591,26 @@ class Session(object):
         self._replicas_synced = False
 
     def train_step(self, feed):
-        """One ``sess.run(train_step)``: forward, backward, (all-reduce), L2 + clip + Adam."""
+        """One ``sess.run(train_step)``: forward, backward, (all-reduce), L2 + clip + Adam.
+
+        The f16x2 range flag is this call's business, whoever the caller is: it is cleared first (a flag left behind by an
+        earlier, unchecked forward() must not make the optimiser kernel skip this step -- and every later one), read
+        once after the optimiser launch (one blocking 4-byte read per eager step), and a flagged step -- which the
+        optimiser kernel skipped on the device -- is repeated on bf16x3 with the host mirror of the step counter put
+        back.  In a data-parallel session the flag every rank reads is the all-reduced one, so all ranks repeat
+        together."""
         self._sync_replicas_once()
+        guarded = self.device.type == "cuda"
+        if guarded:
+            self.store.h2_guard()[0:1].zero_()
+        out = self._train_step_once(feed)
+        if guarded and self.range_exceeded():
+            self._adam["step"] -= 1     # (Adam skipped the update on the device: theta, m, v and t are untouched)
+            with self.model["gnn"].forced_off_h2():
+                out = self._train_step_once(feed)
+        return out
+
+    def _train_step_once(self, feed):
         out = self.loss_and_grads(feed)
         self.allreduce_grads(out["batch"].B, out["stats"])
         out["global_norm"] = self.apply_gradients()
@@ -599,8 +624,23 @@ class Session(object):
         b = batch if isinstance(batch, DeviceBatch) else self.prepare(batch)
         self._ensure_adam()
         self._sync_replicas_once()
+        gnn, store = self.model["gnn"], self.store
+        store.h2_guard()[0:1].zero_()         # (a flag left by an earlier unchecked forward() is not this capture's)
         self.loss_and_grads(b)                # warm-up outside the capture (allocator, caches)
         torch.cuda.synchronize()
+        # did the warm-up leave the f16x2 range?  Then the step is captured on bf16x3 (and stays there for these
+        # variables).  Decided together in a data-parallel session: the ranks' batches differ, their graphs must not.
+        bits = int(store.h2_guard()[0].item()) & 3
+        if self.world_size > 1:
+            import torch.distributed as dist
+            agreed = torch.tensor([bits], dtype=torch.int32, device=self.device)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MAX, group=self.process_group)
+            bits = int(agreed.item())
+        if bits and gnn.active_arith() == "h2":
+            self.last_range_bits = bits
+            store.h2_guard()[0:1].zero_()
+            gnn._h2_off_at = store.assignments
+            return self.capture_train_step(b)
         side = torch.cuda.Stream(device=self.device)
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         self.store.version += 1               # force every packed-weight copy to be rebuilt INSIDE graph A
@@ -611,31 +651,41 @@ class Session(object):
         self._adam["step"] -= 1               # capture does not execute: undo the host mirror's increment
         out["global_norm"] = gnorm
 
-        # f16x2 range guard under replay: the packings happen inside graph A, so the guard words are looked at one
-        # replay LATE, through a pinned copy and an event (no synchronisation).  That is safe: the weight word trips at
-        # half the fp16 range (Adam moves a weight by ~lr per step), and a step whose activations overflowed was
-        # skipped by the optimiser kernel on the device (skip_flag).  Either way f16x2 is switched off for these
-        # variables and the caller is asked to capture again (the new capture runs on bf16x3).
-        gnn, store = self.model["gnn"], self.store
-        guard_host = torch.zeros(4, dtype=torch.int32).pin_memory()
-        pending = []
+        # f16x2 range guard under replay: the packings happen inside graph A, so the guard words are looked at LATE --
+        # replay i looks at the words as replay i - LAG left them, through a pinned copy and an event recorded then (long
+        # complete: no stall).  A FIXED lag, not "whenever the copy happens to have landed": the flag word rides in the
+        # all-reduced bucket and the weights are replicated, so every rank of a data-parallel session sees the same words
+        # at the same replay index and raises at the same index -- no rank is left alone in the next all-reduce.  Looking
+        # late is safe: the weight word trips at half the fp16 range (Adam moves a weight by ~lr per step), and a flagged
+        # step -- and every step after it, the flag stays up -- was skipped by the optimiser kernel on the device.
+        LAG = 2
+        ring = [torch.zeros(4, dtype=torch.int32).pin_memory() for _ in range(LAG + 1)]
+        inflight = []                         # [(event, pinned words)] of the last LAG replays, oldest first
+        count = [0]
 
         def replay():
-            if pending and pending[0].query():
-                pending.clear()
-                if (int(guard_host[0]) & 1) or int(guard_host[1]) >= store.H2_WEIGHT_LIMIT_BITS:
+            if len(inflight) >= LAG:
+                ev, words = inflight.pop(0)
+                ev.synchronize()
+                if (int(words[0]) & 3) or int(words[1]) >= store.H2_WEIGHT_LIMIT_BITS:
+                    torch.cuda.synchronize()
+                    self.last_range_bits = int(words[0]) & 3
                     gnn._h2_off_at = store.assignments
                     store.h2_guard().zero_()
+                    del inflight[:]
+                    self._adam["step"] = int(self._adam["t"].item())   # the device counter did not count the skipped steps
                     raise RuntimeError("f16x2 range exceeded during replayed training steps (the affected steps were "
                                        "not applied): capture_train_step() again -- it will run on bf16x3")
             ga.replay()
             self.allreduce_grads(b.B, out["stats"])   # device-side only: no host sync between the two graphs
             gb.replay()
-            if not pending and gnn.active_arith() == "h2":
-                guard_host.copy_(store.h2_guard(), non_blocking=True)
+            if gnn.active_arith() == "h2":
+                words = ring[count[0] % (LAG + 1)]
+                count[0] += 1
+                words.copy_(store.h2_guard(), non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-                pending.append(ev)
+                inflight.append((ev, words))
             self._adam["step"] += 1
             self.store.touch()
             return out

@@ -101,6 +101,7 @@ class VariableStore(object):
         self._offsets = offsets
         self.device = torch.device(device)
         self.theta = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.h2_guard()   # allocated (and zeroed) NOW: a first use inside a HIP-graph capture would capture the memset
         return self
 
     @property
