@@ -503,6 +503,19 @@ long long tspgnn_host_pack_batch(const void* const* Ma, const int* ma_kind, cons
  */
 int tspgnn_host_read_graph(const char* path, int* n_out, int* route_len_out, int64_t* Ma, double* Mw, int64_t* route);
 
+/*
+ * The data-parallel bucket of a training step (the reference has no counterpart: model.py:157-167 run in
+ * one process).  bucket = [ gradient of the rank's mean loss (n floats) | 8-float tail ].  pack: gradient *= local_batch
+ * (with_grad != 0), tail = { local_batch, local_batch * stats[0] (loss), local_batch * stats[1] (acc), stats[2..5] (TP,
+ * FP, TN, FN), (float) *range_flag }; stats / range_flag may be NULL (zeros).  After ONE all-reduce(sum) of the bucket --
+ * of the tail alone when only statistics are reduced: with_grad == 0 and the gradient part is not touched -- unpack
+ * divides the gradient and the two means by the reduced batch size tail[0], copies the four counts, and sets
+ * *range_flag = (reduced flag != 0): every rank's optimiser launch then skips or applies the step together.
+ */
+int tspgnn_bucket_pack_f32(float* bucket, int n, int with_grad, float local_batch, const float* stats,
+                           const unsigned* range_flag, void* stream);
+int tspgnn_bucket_unpack_f32(float* bucket, int n, int with_grad, float* stats, unsigned* range_flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -281,3 +281,42 @@ def test_spmm_properties_at_full_c2_size(cuda_device):
     ref.index_add_(0, uv[:, 0].long(), Z.double()); ref.index_add_(0, uv[:, 1].long(), Z.double())
     assert (out.double() - ref).abs().max().item() < 1e-4
     assert torch.equal(Y, X[uv[:, 0].long()] + X[uv[:, 1].long()])
+
+
+@pytest.mark.parametrize("n", [0, 5, 115529])
+@pytest.mark.parametrize("with_grad", [True, False])
+def test_bucket_pack_unpack(cuda_device, n, with_grad):
+    """tspgnn_bucket_pack_f32 / _unpack_f32 against the tensor arithmetic of Session._pack_bucket / _unpack_bucket (the
+    CPU plumbing path of the gloo tests), with a two-rank sum done by hand in between."""
+    rng = np.random.RandomState(n + 3)
+    g = [rng.randn(n).astype(np.float32) for _ in range(2)]
+    stats = [np.array([0.7, 0.5, 3, 1, 2, 0], np.float32), np.array([0.4, 0.75, 1, 0, 5, 2], np.float32)]
+    nb, flags = [6.0, 10.0], [0, 2]
+    buckets = []
+    for r in range(2):
+        b = dev(np.concatenate([g[r], np.full(8, 123.0, np.float32)]), cuda_device)
+        fl = dev(np.array([flags[r]], np.uint32), cuda_device, dtype=np.uint32)
+        _lib.call("tspgnn_bucket_pack_f32", _lib.ptr(b), n, int(with_grad), nb[r], _lib.ptr(dev(stats[r], cuda_device)),
+                  _lib.ptr(fl), None)
+        got = b.cpu().numpy()
+        want_tail = np.array([nb[r], nb[r] * stats[r][0], nb[r] * stats[r][1], *stats[r][2:6], flags[r]], np.float32)
+        assert np.array_equal(got[n:], want_tail)
+        assert np.array_equal(got[:n], g[r] * np.float32(nb[r]) if with_grad else g[r])
+        buckets.append(b)
+    total = buckets[0] + buckets[1]
+    _KEEP.append(total)
+    st_out = torch.full((6,), -1.0, device=cuda_device)
+    fl_out = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    _KEEP.extend([st_out, fl_out])
+    before = total.cpu().numpy().copy()
+    _lib.call("tspgnn_bucket_unpack_f32", _lib.ptr(total), n, int(with_grad), _lib.ptr(st_out), _lib.ptr(fl_out), None)
+    got = total.cpu().numpy()
+    inv = np.float32(1.0) / np.float32(16.0)
+    assert np.array_equal(got[:n], before[:n] * inv if with_grad else before[:n])
+    want_stats = np.concatenate([before[n + 1:n + 3] * inv, before[n + 3:n + 7]])
+    assert np.array_equal(st_out.cpu().numpy(), want_stats)
+    assert int(fl_out.item()) == 1
+    # no statistics, no flag: nothing is dereferenced
+    _lib.call("tspgnn_bucket_pack_f32", _lib.ptr(total), n, 0, 4.0, None, None, None)
+    _lib.call("tspgnn_bucket_unpack_f32", _lib.ptr(total), n, 0, None, None, None)
+    assert float(total[n].item()) == 4.0

@@ -374,3 +374,57 @@ extern "C" int tspgnn_adam_clip_step_f32(float* theta, float* g, float* m, float
                                              gnorm_out, n, step_counter, skip_flag);
     return launched("tspgnn_adam_clip_step_f32");
 }
+
+// ---------------------------------------------------------------- data-parallel bucket (Session.allreduce_grads)
+// bucket = [ grad (n floats) | tail: B_r, B_r*loss_r, B_r*acc_r, TP_r, FP_r, TN_r, FN_r, range flag_r ].  One launch each side
+// of the one all-reduce of a training step: pack weights the rank's gradient and statistics by its batch
+// size, unpack divides by the reduced batch size -- on the device, so the step's two HIP graphs run back to back around
+// the collective -- and hands the (summed) range flag back to the guard word every rank's optimiser launch looks at.
+__global__ __launch_bounds__(256) void bucket_pack_kernel(float* __restrict__ bucket, int n, int with_grad, float nb,
+                                                          const float* __restrict__ stats,
+                                                          const unsigned* __restrict__ flag) {
+    if (with_grad)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bucket[i] *= nb;
+    if (blockIdx.x == 0 && threadIdx.x < 8) {
+        const int k = threadIdx.x;
+        float v = 0.f;
+        if (k == 0) v = nb;
+        else if (k < 3) v = stats ? nb * stats[k - 1] : 0.f;
+        else if (k < 7) v = stats ? stats[k - 1] : 0.f;
+        else v = flag ? (float)flag[0] : 0.f;
+        bucket[n + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bucket_unpack_kernel(float* __restrict__ bucket, int n, int with_grad,
+                                                            float* __restrict__ stats, unsigned* __restrict__ flag) {
+    const float inv = 1.0f / bucket[n];
+    if (with_grad)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bucket[i] *= inv;
+    if (blockIdx.x == 0 && threadIdx.x < 8) {
+        const int k = threadIdx.x;
+        if (k >= 1 && k < 3 && stats) stats[k - 1] = bucket[n + k] * inv;
+        if (k >= 3 && k < 7 && stats) stats[k - 1] = bucket[n + k];
+        if (k == 7 && flag) flag[0] = bucket[n + 7] != 0.f ? 1u : 0u;
+    }
+}
+
+extern "C" int tspgnn_bucket_pack_f32(float* bucket, int n, int with_grad, float local_batch, const float* stats,
+                                      const unsigned* range_flag, void* stream) {
+    TSPGNN_REQUIRE(n >= 0 && bucket, "bucket_pack: n=%d, bucket=%p", n, (void*)bucket);
+    int blocks = with_grad ? (n + 255) / 256 : 1;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    bucket_pack_kernel<<<blocks, 256, 0, as_stream(stream)>>>(bucket, n, with_grad, local_batch, stats, range_flag);
+    return launched("tspgnn_bucket_pack_f32");
+}
+
+extern "C" int tspgnn_bucket_unpack_f32(float* bucket, int n, int with_grad, float* stats, unsigned* range_flag,
+                                        void* stream) {
+    TSPGNN_REQUIRE(n >= 0 && bucket, "bucket_unpack: n=%d, bucket=%p", n, (void*)bucket);
+    int blocks = with_grad ? (n + 255) / 256 : 1;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    bucket_unpack_kernel<<<blocks, 256, 0, as_stream(stream)>>>(bucket, n, with_grad, stats, range_flag);
+    return launched("tspgnn_bucket_unpack_f32");
+}

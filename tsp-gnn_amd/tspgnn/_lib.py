@@ -73,6 +73,8 @@ SIGNATURES = {
     "tspgnn_einit_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_adam_clip_step_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
                                   c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "tspgnn_bucket_pack_f32": [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "tspgnn_bucket_unpack_f32": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
 }
 
 HOST_FUNCTIONS = ("tspgnn_host_pack_instance", "tspgnn_host_route_cost", "tspgnn_host_csr_by_vertex",

@@ -475,7 +475,13 @@ class Session(object):
         if store.grad is None:
             store.zero_grad()
         nb = float(local_batch)
-        tail = store.bucket[store.theta.numel():]
+        n = store.theta.numel()
+        tail = store.bucket[n:]
+        if self.device.type == "cuda":     # one launch (tspgnn_bucket_pack_f32): no at::native node in the captured step
+            _lib.call("tspgnn_bucket_pack_f32", _lib.ptr(store.bucket), n, 1 if with_grad else 0, nb, _lib.ptr(stats),
+                      store.h2_flag_ptr(), _lib.current_stream())
+            return tail
+        # device="cpu" (plumbing: the gloo tests): the same arithmetic as tensor ops
         if with_grad:
             store.grad.mul_(nb)
         tail.zero_()
@@ -489,7 +495,12 @@ class Session(object):
 
     def _unpack_bucket(self, stats, with_grad):
         store = self.store
-        tail = store.bucket[store.theta.numel():]
+        n = store.theta.numel()
+        if self.device.type == "cuda":
+            _lib.call("tspgnn_bucket_unpack_f32", _lib.ptr(store.bucket), n, 1 if with_grad else 0, _lib.ptr(stats),
+                      store.h2_flag_ptr(), _lib.current_stream())
+            return
+        tail = store.bucket[n:]
         inv = torch.reciprocal(tail[0:1])
         if with_grad:
             store.grad.mul_(inv)
