@@ -36,18 +36,13 @@
 
 namespace tspgnn {
 
-// The cell launch's output rows (KIND 0: the states h', c'; KIND 1: the next step's messages).  st4o() is the one place their
-// store flavour is chosen.
-template <int KIND>
-__device__ __forceinline__ void st4o(float* p, f32x4 v) {
-#if defined(H2_WT)   // (round-4 A/B, see DESIGN 7: write-through `sc0 sc1` stores leave no dirty lines for the kernel boundary;
-    // H2_WT = 1: states and messages, 2: messages only, 3: states only)
-    if constexpr (H2_WT == 1 || (H2_WT == 2 && KIND == 1) || (H2_WT == 3 && KIND == 0)) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-        return;
-    }
-#endif
-    st4(p, v);
+// The cell launch's output rows.  The states h', c' (st4s) go out as write-through `sc0 sc1` stores: nothing in this launch
+// reads them again, and a line stored that way does not sit dirty in the XCD's L2 until the end-of-kernel release has to
+// write it back (round 4, alternating runs on one box: C2 forward 1.457-1.483 -> 1.430-1.454 ms, the launch itself
+// 37.3 -> 36.6 us; C4 unchanged).  The next step's MESSAGES keep plain stores: written through they gave two populations of
+// runs, 1.41-1.44 ms and 1.97-1.99 ms (C4: 10.3 / 12.9 ms), process by process -- DESIGN 7.
+__device__ __forceinline__ void st4s(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
 
 #if H2_TRACE
@@ -378,8 +373,8 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
             float* cd = c_out + h2_state_row<D>(rc, g, out_blk);
 #pragma unroll
             for (int t = 0; t < TPG; ++t) {
-                st4o<0>(hd + t * out_ts, hn[t]);
-                st4o<0>(cd + t * out_ts, nc[t]);
+                st4s(hd + t * out_ts, hn[t]);
+                st4s(cd + t * out_ts, nc[t]);
             }
         }
     };
@@ -450,7 +445,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 }
                 if (valid && mlp_out != nullptr) {
 #pragma unroll
-                    for (int t = 0; t < TPG; ++t) st4o<1>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                    for (int t = 0; t < TPG; ++t) st4(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
             }
 #if H2_TRACE
