@@ -323,13 +323,13 @@ def test_bucket_pack_unpack(cuda_device, n, with_grad):
 
 
 @pytest.mark.parametrize("split", [4, 8])
-@pytest.mark.parametrize("d", [32, 64, 128])
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
 @pytest.mark.parametrize("name", ["ragged_B6", "sparse_B4", "n200"])
 def test_rowsum_with_columns_split_over_the_xcds(cuda_device, name, d, split):
     """tspgnn_csr_rowsum_split_f32 (columns dealt out over the XCDs: the row-sum for graphs whose rows do not stay in one
     L2) against the float64 oracle and the plain kernel: same sums up to the summation order; empty rows; an odd number of
     vertices (vertex parts of unequal size); degree above one wavefront of edge ids."""
-    if d % (4 * split):
+    if d % (4 * split) or d // (4 * split) > 8:
         pytest.skip("d=%d has no %d-way split" % (d, split))
     if name == "n200":
         n = 200

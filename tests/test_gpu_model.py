@@ -14,6 +14,7 @@ from oracle import torch_oracle as TO
 pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-5
+MOVE_TOL = 0.05    # three Adam steps: error of a variable's movement relative to its largest movement (see the test)
 
 
 def run_hip(d, params, batch_tuple, T, fetch=("loss", "acc", "predictions", "TP", "FP", "TN", "FN", "last_states"),
@@ -255,8 +256,9 @@ def test_gradient_parity_with_autograd_oracle(cuda_device, name, d, T):
         err = np.abs(g[k] - ref).max() / scale
         err32 = np.abs(f32_g[k] - ref_g[k]).max() / scale
         worst, worst32 = max(worst, err), max(worst32, err32)
-        # 2e-5, or -- for sums with heavy cancellation -- what an op-for-op fp32 autograd run loses itself
-        assert err < max(2e-5, 3 * err32), (k, err, err32)
+        # 1e-5 (the forward's own budget; measured <= 6e-6), or -- for sums with heavy cancellation -- twice what an
+        # op-for-op fp32 autograd run loses itself
+        assert err < max(1e-5, 2 * err32), (k, err, err32)
     print("\n[%s d=%d T=%d] worst per-variable gradient rel err: HIP %.2e, fp32 restatement %.2e"
           % (name, d, T, worst, worst32))
 
@@ -322,13 +324,17 @@ def test_train_steps_follow_the_oracle(cuda_device):
         assert vals[0] is None and abs(float(vals[1]) - ref_out["loss"].item()) < REL_TOL
         assert abs(float(sess._adam["gnorm"].item()) - gn) < 2e-5 * gn
     now = model.store.state_dict()
+    worst = 0.0
     for k in p:
         # three Adam steps move every weight by ~6e-5; compare the MOVEMENT, not just the value
         moved_ref = p[k] - params[k]
         moved = now[k].astype(np.float64) - params[k]
         # (Adam normalises by sqrt(v): an entry whose gradient sits at the fp32 noise level moves by a
         # noise-dependent fraction of the step, hence a budget relative to the largest movement)
-        assert np.abs(moved - moved_ref).max() < 2e-7 + 0.05 * np.abs(moved_ref).max(), k
+        ratio = np.abs(moved - moved_ref).max() / np.abs(moved_ref).max()
+        worst = max(worst, ratio)
+        assert np.abs(moved - moved_ref).max() < 2e-7 + MOVE_TOL * np.abs(moved_ref).max(), (k, ratio)
+    print("\n[train steps] worst movement error relative to the largest movement of its variable: %.2e" % worst)
 
 
 def test_captured_graph_replay_matches_eager(cuda_device):

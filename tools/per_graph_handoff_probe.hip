@@ -30,7 +30,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int G = 128, NV = 40, ROWS = 784, REAL_ROWS = NV * (NV - 1) / 2, P = 2, D4 = 16;   // 16 float4 = 256 B per row
 
 __device__ __forceinline__ void st_wt(f32x4* p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+    // (s_nop: the store reads its 16 bytes of data up to two wait states after issue -- a hazard the compiler cannot see
+    // inside an asm)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ f32x4 ld_sc1(const f32x4* p) {
     f32x4 v;

@@ -191,7 +191,7 @@ int rowsum_split_for(long long M, int N, int row_bytes) {
     const int lanes = row_bytes / 16;
     auto ok = [&](int S) { return lanes % S == 0 && (lanes / S == 1 || lanes / S == 2 || lanes / S == 4 || lanes / S == 8); };
     if (forced == 0 || N <= 0) return 0;
-    if (forced == 4 || forced == 8) return ok(forced) ? forced : 0;
+    if (forced == 2 || forced == 4 || forced == 8) return ok(forced) ? forced : 0;
     const double in_flight = N / 8 < 1024 ? N / 8.0 : 1024.0;            // vertices an XCD keeps in flight
     const double footprint = in_flight * (2.0 * (double)M / N) * row_bytes / 2.0;   // bytes of rows between their two reads
     const double l2 = 3.5 * 1024 * 1024;
@@ -205,13 +205,18 @@ int launch_csr_split(const int32_t* rowptr, const int32_t* eid, const void* X, v
                      hipStream_t st) {
     const int vparts = 8 / S, per = (N + vparts - 1) / vparts;
     const unsigned grid = 8u * (unsigned)((per + 3) / 4);
+    static const int lds_kb = [] {   // (development switch: dynamic LDS per workgroup = a cap on the workgroups a CU holds)
+        const char* e = getenv("TSPGNN_ROWSUM_LDS_KB");
+        return e ? atoi(e) : 0;
+    }();
+    const size_t lds = (size_t)lds_kb * 1024;
     const uint4* X4 = reinterpret_cast<const uint4*>(X);
     uint4* Y4 = reinterpret_cast<uint4*>(Y);
     switch (row_bytes / 16 / S) {
-        case 1: csr_rowsum_split_kernel<1, BF16><<<grid, 256, 0, st>>>(rowptr, eid, X4, Y4, N, S); break;
-        case 2: csr_rowsum_split_kernel<2, BF16><<<grid, 256, 0, st>>>(rowptr, eid, X4, Y4, N, S); break;
-        case 4: csr_rowsum_split_kernel<4, BF16><<<grid, 256, 0, st>>>(rowptr, eid, X4, Y4, N, S); break;
-        default: csr_rowsum_split_kernel<8, BF16><<<grid, 256, 0, st>>>(rowptr, eid, X4, Y4, N, S); break;
+        case 1: csr_rowsum_split_kernel<1, BF16><<<grid, 256, lds, st>>>(rowptr, eid, X4, Y4, N, S); break;
+        case 2: csr_rowsum_split_kernel<2, BF16><<<grid, 256, lds, st>>>(rowptr, eid, X4, Y4, N, S); break;
+        case 4: csr_rowsum_split_kernel<4, BF16><<<grid, 256, lds, st>>>(rowptr, eid, X4, Y4, N, S); break;
+        default: csr_rowsum_split_kernel<8, BF16><<<grid, 256, lds, st>>>(rowptr, eid, X4, Y4, N, S); break;
     }
     return launched(BF16 ? "tspgnn_csr_rowsum_bf16(split)" : "tspgnn_csr_rowsum_f32(split)");
 }
@@ -333,7 +338,7 @@ extern "C" int tspgnn_csr_rowsum_f32(const int32_t* rowptr, const int32_t* eid, 
     TSPGNN_REQUIRE(d > 0 && d % 4 == 0, "csr_rowsum: d=%d must be a positive multiple of 4", d);
     if (N == 0) return TSPGNN_OK;
     TSPGNN_REQUIRE(rowptr && Y && (M == 0 || (eid && X)), "csr_rowsum: null pointer");
-    if (d % 4 == 0 && d <= 128) {   // (wider rows -- the training pass's [M, 4d] gate gradients -- keep their column blocks)
+    if (d % 4 == 0 && d <= 256) {   // (d = 256: the training pass's [M, 4d] gate gradients, 1 KB rows: 8 parts of 128 B)
         const int S = rowsum_split_for(M, N, d * 4);
         if (S) return launch_csr_split<false>(rowptr, eid, X, Y, N, d * 4, S, as_stream(stream));
     }
@@ -352,7 +357,7 @@ extern "C" int tspgnn_csr_spmm_f32(const int32_t* rowptr, const int32_t* col, co
 extern "C" int tspgnn_csr_rowsum_split_f32(const int32_t* rowptr, const int32_t* eid, const float* X, float* Y, int N,
                                            int M, int d, int split, void* stream) {
     TSPGNN_REQUIRE(M >= 0 && N >= 0, "csr_rowsum_split: negative size (N=%d M=%d)", N, M);
-    TSPGNN_REQUIRE(split == 4 || split == 8, "csr_rowsum_split: split=%d must be 4 or 8", split);
+    TSPGNN_REQUIRE(split == 2 || split == 4 || split == 8, "csr_rowsum_split: split=%d must be 2, 4 or 8", split);
     TSPGNN_REQUIRE(d > 0 && d % (4 * split) == 0 && d / (4 * split) <= 8 && ((d / (4 * split)) & (d / (4 * split) - 1)) == 0,
                    "csr_rowsum_split: d=%d must be split * {4, 8, 16, 32}", d);
     if (N == 0) return TSPGNN_OK;
@@ -363,7 +368,7 @@ extern "C" int tspgnn_csr_rowsum_split_f32(const int32_t* rowptr, const int32_t*
 extern "C" int tspgnn_csr_rowsum_split_bf16(const int32_t* rowptr, const int32_t* eid, const void* X, void* Y, int N, int M,
                                             int d, int split, void* stream) {
     TSPGNN_REQUIRE(M >= 0 && N >= 0, "csr_rowsum_split_bf16: negative size (N=%d M=%d)", N, M);
-    TSPGNN_REQUIRE(split == 4 || split == 8, "csr_rowsum_split_bf16: split=%d must be 4 or 8", split);
+    TSPGNN_REQUIRE(split == 2 || split == 4 || split == 8, "csr_rowsum_split_bf16: split=%d must be 2, 4 or 8", split);
     TSPGNN_REQUIRE(d > 0 && d % (8 * split) == 0 && d / (8 * split) <= 8 && ((d / (8 * split)) & (d / (8 * split) - 1)) == 0,
                    "csr_rowsum_split_bf16: d=%d must be split * {8, 16, 32, 64}", d);
     if (N == 0) return TSPGNN_OK;

@@ -36,13 +36,22 @@
 
 namespace tspgnn {
 
-// The cell launch's output rows.  The states h', c' (st4s) go out as write-through `sc0 sc1` stores: nothing in this launch
-// reads them again, and a line stored that way does not sit dirty in the XCD's L2 until the end-of-kernel release has to
-// write it back (round 4, alternating runs on one box: C2 forward 1.457-1.483 -> 1.430-1.454 ms, the launch itself
-// 37.3 -> 36.6 us; C4 unchanged).  The next step's MESSAGES keep plain stores: written through they gave two populations of
-// runs, 1.41-1.44 ms and 1.97-1.99 ms (C4: 10.3 / 12.9 ms), process by process -- DESIGN 7.
-__device__ __forceinline__ void st4s(float* p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+// The cell launch's output rows through one store helper (round-4 experiment switch, resolved before the round ends:
+// H2_ST bit 0: the states h', c' as write-through `sc0 sc1` stores, bit 1: the next step's messages as well).
+// The trailing s_nop is NOT optional: a VMEM store of more than 8 bytes reads its data registers up to two wait states
+// after issue on gfx940+, the compiler's hazard recogniser covers that for its own stores (GCNHazardRecognizer,
+// "store data overwritten by the next VALU") and cannot see inside an asm -- without it the first build of this helper
+// stored garbage whenever the register allocator reused a data register at once (anchor C1: loss off by 2.4e-3).
+#ifndef H2_ST
+#define H2_ST 0
+#endif
+template <int KIND>   // 0: state rows, 1: message rows
+__device__ __forceinline__ void st4o(float* p, f32x4 v) {
+    if constexpr ((H2_ST >> KIND) & 1) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    } else {
+        st4(p, v);
+    }
 }
 
 #if H2_TRACE
@@ -373,8 +382,8 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
             float* cd = c_out + h2_state_row<D>(rc, g, out_blk);
 #pragma unroll
             for (int t = 0; t < TPG; ++t) {
-                st4s(hd + t * out_ts, hn[t]);
-                st4s(cd + t * out_ts, nc[t]);
+                st4o<0>(hd + t * out_ts, hn[t]);
+                st4o<0>(cd + t * out_ts, nc[t]);
             }
         }
     };
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 }
                 if (valid && mlp_out != nullptr) {
 #pragma unroll
-                    for (int t = 0; t < TPG; ++t) st4(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                    for (int t = 0; t < TPG; ++t) st4o<1>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
             }
 #if H2_TRACE
