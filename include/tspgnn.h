@@ -504,19 +504,6 @@ long long tspgnn_host_pack_batch(const void* const* Ma, const int* ma_kind, cons
 int tspgnn_host_read_graph(const char* path, int* n_out, int* route_len_out, int64_t* Ma, double* Mw, int64_t* route);
 
 /*
- * The V <- E row-sum (tspgnn_csr_rowsum_f32 / _bf16: same arguments, same result up to summation order) with the COLUMNS
- * of the rows dealt out over the 8 XCDs: XCD x sums column part x % split of vertex part x / split, split = 4 or 8, so
- * that the two reads of an edge row's 64- or 32-byte part (one per endpoint, graphnn.py:156-160 adjoint_a=True) meet in
- * one 4 MB L2 when a graph's rows do not fit it whole (n >= 64 or so; BASELINE configs 3 and 4).  The plain entry points
- * choose a split by themselves from (M, N, d); these take it explicitly.  d must be split * {4, 8, 16, 32} floats
- * (fp32) or split * {8, 16, 32, 64} (bf16); deterministic.
- */
-int tspgnn_csr_rowsum_split_f32(const int32_t* rowptr, const int32_t* eid, const float* X, float* Y, int N, int M, int d,
-                                int split, void* stream);
-int tspgnn_csr_rowsum_split_bf16(const int32_t* rowptr, const int32_t* eid, const void* X, void* Y, int N, int M, int d,
-                                 int split, void* stream);
-
-/*
  * The data-parallel bucket of a training step (the reference has no counterpart: model.py:157-167 run in
  * one process).  bucket = [ gradient of the rank's mean loss (n floats) | 8-float tail ].  pack: gradient *= local_batch
  * (with_grad != 0), tail = { local_batch, local_batch * stats[0] (loss), local_batch * stats[1] (acc), stats[2..5] (TP,

@@ -207,37 +207,3 @@ def test_lnlstm_bf16_gather_and_plain_tasks(cuda_device, d, c_blocked):
     rh, rc = NO.lnlstm(rb(xv), rb(hv), cv.astype(np.float64), rb(Kv), lnd_v)
     assert rel_err(c_host(cv_o, N, cout), rc) < F32_TOL
     assert rel_err(h_host(hv_o, N, cout), rb(rh)) < 2.0 ** -7
-
-
-@pytest.mark.parametrize("split", [4, 8])
-@pytest.mark.parametrize("d", [64, 128])
-def test_rowsum_bf16_with_columns_split_over_the_xcds(cuda_device, d, split):
-    """tspgnn_csr_rowsum_split_bf16 against the exact sum of the bf16-rounded rows (one rounding at the store) and the plain
-    kernel, on a random CSR with empty rows and an odd number of vertices, and on an n = 200 complete graph."""
-    rng = np.random.RandomState(d + split)
-    for case in ("random", "n200"):
-        if case == "random":
-            N, M = 257, 3001
-            counts = rng.randint(0, 50, N)
-            counts[3] = 0
-            rowptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-            eid = rng.randint(0, M, int(rowptr[-1])).astype(np.int32)
-        else:
-            from tspgnn.instance_loader import SparseEV
-            n = 200
-            ev = SparseEV(np.stack(np.triu_indices(n, 1), 1).astype(np.int32), n)
-            M, N = ev.shape
-            rowptr, eid = ev.csr_by_vertex()
-        Z = rng.randn(M, d)
-        rp, ei, Zd = dev(rowptr, cuda_device, np.int32), dev(eid, cuda_device, np.int32), dev_bf16(Z, cuda_device)
-        out = torch.empty((N, d), dtype=torch.bfloat16, device=cuda_device)
-        plain = torch.empty((N, d), dtype=torch.bfloat16, device=cuda_device)
-        _lib.call("tspgnn_csr_rowsum_split_bf16", _lib.ptr(rp), _lib.ptr(ei), _lib.ptr(Zd), _lib.ptr(out), N, M, d, split, None)
-        _lib.call("tspgnn_csr_rowsum_bf16", _lib.ptr(rp), _lib.ptr(ei), _lib.ptr(Zd), _lib.ptr(plain), N, M, d, None)
-        torch.cuda.synchronize()
-        ref = np.stack([rb(Z)[eid[rowptr[r]:rowptr[r + 1]]].sum(0) for r in range(N)])
-        got = f64(out)
-        if case == "random":
-            assert np.all(got[3] == 0)
-        assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) < 2.0 ** -8 + 1e-5
-        assert np.max(np.abs(got - f64(plain)) / np.maximum(np.abs(ref), 1e-3)) < 2.0 ** -7

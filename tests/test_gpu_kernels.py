@@ -320,40 +320,3 @@ def test_bucket_pack_unpack(cuda_device, n, with_grad):
     _lib.call("tspgnn_bucket_pack_f32", _lib.ptr(total), n, 0, 4.0, None, None, None)
     _lib.call("tspgnn_bucket_unpack_f32", _lib.ptr(total), n, 0, None, None, None)
     assert float(total[n].item()) == 4.0
-
-
-@pytest.mark.parametrize("split", [4, 8])
-@pytest.mark.parametrize("d", [32, 64, 128, 256])
-@pytest.mark.parametrize("name", ["ragged_B6", "sparse_B4", "n200"])
-def test_rowsum_with_columns_split_over_the_xcds(cuda_device, name, d, split):
-    """tspgnn_csr_rowsum_split_f32 (columns dealt out over the XCDs: the row-sum for graphs whose rows do not stay in one
-    L2) against the float64 oracle and the plain kernel: same sums up to the summation order; empty rows; an odd number of
-    vertices (vertex parts of unequal size); degree above one wavefront of edge ids."""
-    if d % (4 * split) or d // (4 * split) > 8:
-        pytest.skip("d=%d has no %d-way split" % (d, split))
-    if name == "n200":
-        n = 200
-        uv = np.stack(np.triu_indices(n, 1), 1).astype(np.int32)
-        ev = SparseEV(uv, n + 3)            # 3 trailing vertices without edges
-    else:
-        g = load_pack(name, 1)
-        ev = SparseEV(g["ev_uv"], int(g["ev_shape"][1]))
-    M, N = ev.shape
-    rowptr, eid = ev.csr_by_vertex()
-    Z = np.random.RandomState(d + split).randn(M, d).astype(np.float32)
-    rp, ei, Zd = dev(rowptr, cuda_device, np.int32), dev(eid, cuda_device, np.int32), dev(Z, cuda_device)
-    plain = torch.full((N, d), 7.0, dtype=torch.float32, device=cuda_device)
-    out = torch.full((N, d), 7.0, dtype=torch.float32, device=cuda_device)
-    _lib.call("tspgnn_csr_rowsum_f32", _lib.ptr(rp), _lib.ptr(ei), _lib.ptr(Zd), _lib.ptr(plain), N, M, d, None)
-    _lib.call("tspgnn_csr_rowsum_split_f32", _lib.ptr(rp), _lib.ptr(ei), _lib.ptr(Zd), _lib.ptr(out), N, M, d, split, None)
-    torch.cuda.synchronize()
-    ref = NO.rowsum_by_vertex(ev.uv.astype(np.int64), Z.astype(np.float64), N)
-    assert rel_err(out.cpu().numpy(), ref) < F32_TOL
-    assert rel_err(out.cpu().numpy(), plain.cpu().numpy().astype(np.float64)) < F32_TOL
-    if name == "n200":
-        assert np.all(out.cpu().numpy()[-3:] == 0)
-    # deterministic: a second launch gives the same bits
-    again = torch.empty_like(out)
-    _lib.call("tspgnn_csr_rowsum_split_f32", _lib.ptr(rp), _lib.ptr(ei), _lib.ptr(Zd), _lib.ptr(again), N, M, d, split, None)
-    torch.cuda.synchronize()
-    assert torch.equal(out, again)

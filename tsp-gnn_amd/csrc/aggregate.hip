@@ -106,123 +106,6 @@ __global__ __launch_bounds__(256) void csr_rowsum_kernel(const int* __restrict__
     csr_rowsum_body<LPR, VALUED, CB>(rowptr, eid, val, X, Y, N, blockIdx.x, gridDim.x);
 }
 
-// ---------------------------------------------------------------- V <- E : CSR row-sum, columns split over the XCDs
-// Every edge row is read twice (once per endpoint), and the second read only hits if the row is still in the reading
-// XCD's 4 MB L2.  With one wavefront per vertex an XCD keeps ~1 000 vertices in flight, i.e. ~1 000 * degree / 2 rows:
-// 3.2 MB at C2 (n = 40: fits, traffic 1.00x algorithmic), 7 MB at C4 (n up to 80: 1.27x) and 26 MB at a C5 shard (n = 200:
-// 1.76x; one graph's 5.1 MB of bf16 rows alone exceed an L2).  Reordering vertices cannot help -- vertex w reads one row of
-// EVERY earlier vertex's run -- but the COLUMNS can be dealt out: here XCD x (workgroup b runs on XCD b % 8; speed only)
-// sums column part x % S of vertex part x / S, S = 4 or 8, so that a row's two reads of a 64- or 32-byte part meet in one
-// L2 and the footprint per XCD shrinks S-fold while the number of wavefronts -- the kernel is latency-bound, it needs them
-// -- grows.  LQ = 16-byte lanes per row part; 64 / LQ rows per load instruction; the same fixed summation order per
-// element on every run (ascending edge id within a lane group, then a butterfly over the groups).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-template <int LQ, bool BF16>
-__global__ __launch_bounds__(256) void csr_rowsum_split_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
-                                                               const uint4* __restrict__ X, uint4* __restrict__ Y, int N,
-                                                               int S) {
-    constexpr int RPW = kWave / LQ;
-    constexpr int NV = BF16 ? 8 : 4;   // fp32 accumulators per lane
-    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const int part = (int)(xcd % (unsigned)S), vparts = 8 / S, vpart = (int)(xcd / (unsigned)S);
-    const int per = (N + vparts - 1) / vparts;                 // vertices per vertex part
-    const int vi = (int)slot * 4 + (int)(threadIdx.x >> 6);
-    const int v = vpart * per + vi;
-    if (vi >= per || v >= N) return;   // wave-uniform
-    const int lane = threadIdx.x & 63, sub = lane / LQ;
-    const int lpr = LQ * S;                                    // 16-byte lanes per whole row
-    const int c = part * LQ + lane % LQ;
-    const int beg = rowptr[v], end = rowptr[v + 1];
-    float acc[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
-    for (int base = beg; base < end; base += kWave) {
-        const int cnt = min(kWave, end - base);
-        const int my_e = (lane < cnt) ? eid[base + lane] : 0;
-#pragma unroll 4
-        for (int k0 = 0; k0 < cnt; k0 += RPW) {
-            const int k = k0 + sub;
-            const int e = __shfl(my_e, min(k, cnt - 1));
-            if (k < cnt) {
-                const uint4 w = X[(long long)e * lpr + c];
-                if constexpr (BF16) {
-                    const unsigned u[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[2 * i] += __uint_as_float(u[i] << 16);
-                        acc[2 * i + 1] += __uint_as_float(u[i] & 0xffff0000u);
-                    }
-                } else {
-                    acc[0] += __uint_as_float(w.x);
-                    acc[1] += __uint_as_float(w.y);
-                    acc[2] += __uint_as_float(w.z);
-                    acc[3] += __uint_as_float(w.w);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int off = LQ; off < kWave; off <<= 1) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) acc[i] += __shfl_xor(acc[i], off);
-    }
-    if (sub == 0) {
-        uint4 o;
-        if constexpr (BF16) {
-            bf16x8 r;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = (__bf16)acc[i];
-            o = *reinterpret_cast<uint4*>(&r);
-        } else {
-            o = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3]));
-        }
-        Y[(long long)v * lpr + c] = o;
-    }
-}
-
-// Column split to use for [M, row_bytes] rows summed into N vertices: 0 (the plain kernel), 4 or 8.  TSPGNN_ROWSUM_SPLIT
-// overrides (development switch: 0 / 4 / 8).
-int rowsum_split_for(long long M, int N, int row_bytes) {
-    static const int forced = [] {
-        const char* e = getenv("TSPGNN_ROWSUM_SPLIT");
-        return e ? atoi(e) : -1;
-    }();
-    const int lanes = row_bytes / 16;
-    auto ok = [&](int S) { return lanes % S == 0 && (lanes / S == 1 || lanes / S == 2 || lanes / S == 4 || lanes / S == 8); };
-    if (forced == 0 || N <= 0) return 0;
-    if (forced == 2 || forced == 4 || forced == 8) return ok(forced) ? forced : 0;
-    const double in_flight = N / 8 < 1024 ? N / 8.0 : 1024.0;            // vertices an XCD keeps in flight
-    const double footprint = in_flight * (2.0 * (double)M / N) * row_bytes / 2.0;   // bytes of rows between their two reads
-    const double l2 = 3.5 * 1024 * 1024;
-    if (footprint <= l2) return 0;
-    if (footprint / 4 <= l2 && ok(4)) return 4;
-    return ok(8) ? 8 : (ok(4) ? 4 : 0);
-}
-
-template <bool BF16>
-int launch_csr_split(const int32_t* rowptr, const int32_t* eid, const void* X, void* Y, int N, int row_bytes, int S,
-                     hipStream_t st) {
-    const int vparts = 8 / S, per = (N + vparts - 1) / vparts;
-    const unsigned grid = 8u * (unsigned)((per + 3) / 4);
-    static const int lds_kb = [] {   // (development switch: dynamic LDS per workgroup = a cap on the workgroups a CU holds)
-        const char* e = getenv("TSPGNN_ROWSUM_LDS_KB");
-        return e ? atoi(e) : 0;
-    }();
-    const size_t lds = (size_t)lds_kb * 1024;
-    const uint4* X4 = reinterpret_cast<const uint4*>(X);
-    uint4* Y4 = reinterpret_cast<uint4*>(Y);
-    switch (row_bytes / 16 / S) {
-        case 1: csr_rowsum_split_kernel<1, BF16><<<grid, 256, lds, st>>>(rowptr, eid, X4, Y4, N, S); break;
-        case 2: csr_rowsum_split_kernel<2, BF16><<<grid, 256, lds, st>>>(rowptr, eid, X4, Y4, N, S); break;
-        case 4: csr_rowsum_split_kernel<4, BF16><<<grid, 256, lds, st>>>(rowptr, eid, X4, Y4, N, S); break;
-        default: csr_rowsum_split_kernel<8, BF16><<<grid, 256, lds, st>>>(rowptr, eid, X4, Y4, N, S); break;
-    }
-    return launched(BF16 ? "tspgnn_csr_rowsum_bf16(split)" : "tspgnn_csr_rowsum_f32(split)");
-}
-template int launch_csr_split<true>(const int32_t*, const int32_t*, const void*, void*, int, int, int, hipStream_t);
-template int launch_csr_split<false>(const int32_t*, const int32_t*, const void*, void*, int, int, int, hipStream_t);
-
 // Both directions of one message-passing step's aggregation in ONE launch: E <- V gather and V <- E
 // row-sum read disjoint inputs and write disjoint outputs (both updates read the OLD states,
 // graphnn.py:143), so their workgroups can share the chip and the HBM pipe instead of paying two
@@ -338,10 +221,6 @@ extern "C" int tspgnn_csr_rowsum_f32(const int32_t* rowptr, const int32_t* eid, 
     TSPGNN_REQUIRE(d > 0 && d % 4 == 0, "csr_rowsum: d=%d must be a positive multiple of 4", d);
     if (N == 0) return TSPGNN_OK;
     TSPGNN_REQUIRE(rowptr && Y && (M == 0 || (eid && X)), "csr_rowsum: null pointer");
-    if (d % 4 == 0 && d <= 256) {   // (d = 256: the training pass's [M, 4d] gate gradients, 1 KB rows: 8 parts of 128 B)
-        const int S = rowsum_split_for(M, N, d * 4);
-        if (S) return launch_csr_split<false>(rowptr, eid, X, Y, N, d * 4, S, as_stream(stream));
-    }
     return launch_csr<false>(rowptr, eid, nullptr, X, Y, N, d, as_stream(stream));
 }
 
@@ -352,26 +231,4 @@ extern "C" int tspgnn_csr_spmm_f32(const int32_t* rowptr, const int32_t* col, co
     if (R == 0) return TSPGNN_OK;
     TSPGNN_REQUIRE(rowptr && Y && (C == 0 || (col && val && X)), "csr_spmm: null pointer");
     return launch_csr<true>(rowptr, col, val, X, Y, R, d, as_stream(stream));
-}
-
-extern "C" int tspgnn_csr_rowsum_split_f32(const int32_t* rowptr, const int32_t* eid, const float* X, float* Y, int N,
-                                           int M, int d, int split, void* stream) {
-    TSPGNN_REQUIRE(M >= 0 && N >= 0, "csr_rowsum_split: negative size (N=%d M=%d)", N, M);
-    TSPGNN_REQUIRE(split == 2 || split == 4 || split == 8, "csr_rowsum_split: split=%d must be 2, 4 or 8", split);
-    TSPGNN_REQUIRE(d > 0 && d % (4 * split) == 0 && d / (4 * split) <= 8 && ((d / (4 * split)) & (d / (4 * split) - 1)) == 0,
-                   "csr_rowsum_split: d=%d must be split * {4, 8, 16, 32}", d);
-    if (N == 0) return TSPGNN_OK;
-    TSPGNN_REQUIRE(rowptr && Y && (M == 0 || (eid && X)), "csr_rowsum_split: null pointer");
-    return launch_csr_split<false>(rowptr, eid, X, Y, N, d * 4, split, as_stream(stream));
-}
-
-extern "C" int tspgnn_csr_rowsum_split_bf16(const int32_t* rowptr, const int32_t* eid, const void* X, void* Y, int N, int M,
-                                            int d, int split, void* stream) {
-    TSPGNN_REQUIRE(M >= 0 && N >= 0, "csr_rowsum_split_bf16: negative size (N=%d M=%d)", N, M);
-    TSPGNN_REQUIRE(split == 2 || split == 4 || split == 8, "csr_rowsum_split_bf16: split=%d must be 2, 4 or 8", split);
-    TSPGNN_REQUIRE(d > 0 && d % (8 * split) == 0 && d / (8 * split) <= 8 && ((d / (8 * split)) & (d / (8 * split) - 1)) == 0,
-                   "csr_rowsum_split_bf16: d=%d must be split * {8, 16, 32, 64}", d);
-    if (N == 0) return TSPGNN_OK;
-    TSPGNN_REQUIRE(rowptr && Y && (M == 0 || (eid && X)), "csr_rowsum_split_bf16: null pointer");
-    return launch_csr_split<true>(rowptr, eid, X, Y, N, d * 2, split, as_stream(stream));
 }

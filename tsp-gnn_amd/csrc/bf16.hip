@@ -520,10 +520,6 @@ extern "C" int tspgnn_csr_rowsum_bf16(const int32_t* rowptr, const int32_t* eid,
     hipStream_t st = as_stream(stream);
     const uint4* Xp = reinterpret_cast<const uint4*>(X);
     uint4* Yp = reinterpret_cast<uint4*>(Y);
-    if (d <= 256) {
-        const int S = rowsum_split_for(M, N, d * 2);
-        if (S) return launch_csr_split<true>(rowptr, eid, X, Y, N, d * 2, S, st);
-    }
     switch (d / 8) {
         case 4: csr_rowsum_bf16_kernel<4><<<grid, 256, 0, st>>>(rowptr, eid, Xp, Yp, N); break;
         case 8: csr_rowsum_bf16_kernel<8><<<grid, 256, 0, st>>>(rowptr, eid, Xp, Yp, N); break;

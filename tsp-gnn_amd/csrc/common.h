@@ -66,11 +66,4 @@ __device__ __forceinline__ float sum_over_lane_groups16(float v) {
     return v;
 }
 
-// aggregate.hip: the V <- E row-sum with its columns split over the XCDs (see csr_rowsum_split_kernel).  rowsum_split_for:
-// the split to use for [M, row_bytes] rows summed into N vertices (0: none); launch_csr_split: fp32 or bf16 rows.
-int rowsum_split_for(long long M, int N, int row_bytes);
-template <bool BF16>
-int launch_csr_split(const int32_t* rowptr, const int32_t* eid, const void* X, void* Y, int N, int row_bytes, int S,
-                     hipStream_t st);
-
 }  // namespace tspgnn

@@ -36,18 +36,18 @@
 
 namespace tspgnn {
 
-// The cell launch's output rows through one store helper (round-4 experiment switch, resolved before the round ends:
-// H2_ST bit 0: the states h', c' as write-through `sc0 sc1` stores, bit 1: the next step's messages as well).
+// The cell launch's output rows (the states h', c' and the next step's messages) through one store helper.  WT: as
+// write-through `sc0 sc1` stores -- nothing in the launch reads them again, and a line stored that way does not sit dirty
+// in the XCD's L2 until the end-of-kernel release writes it back.  Pays when the loop's arrays live in the Infinity Cache
+// (C2: forward 1.467-1.485 -> 1.425-1.441 ms, five alternating runs on one box), costs when they do not (C4: 10.31-10.43 ->
+// 10.43-10.82 ms), so the launcher chooses by footprint (launch_cell_h2); profiles/r04_store_flavour_ab.txt.
 // The trailing s_nop is NOT optional: a VMEM store of more than 8 bytes reads its data registers up to two wait states
-// after issue on gfx940+, the compiler's hazard recogniser covers that for its own stores (GCNHazardRecognizer,
-// "store data overwritten by the next VALU") and cannot see inside an asm -- without it the first build of this helper
-// stored garbage whenever the register allocator reused a data register at once (anchor C1: loss off by 2.4e-3).
-#ifndef H2_ST
-#define H2_ST 0
-#endif
-template <int KIND>   // 0: state rows, 1: message rows
+// after issue on gfx940+; the compiler's hazard recogniser covers that for its own stores (GCNHazardRecognizer, "store
+// data overwritten by the next VALU") and cannot see inside an asm -- without it the first build of this helper stored
+// garbage whenever the register allocator reused a data register at once (anchor C1: loss off by 2.4e-3).
+template <bool WT>
 __device__ __forceinline__ void st4o(float* p, f32x4 v) {
-    if constexpr ((H2_ST >> KIND) & 1) {
+    if constexpr (WT) {
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
     } else {
         st4(p, v);
@@ -272,8 +272,10 @@ struct CellTaskTableH2 {
 
 // CENTERED: every task of the launch promises z_centered (include/tspgnn.h) -- the gate LayerNorms run without their
 // mean pass (a compile-time variant: the same choice as a branch inside the tile loop cost 47 spilled registers).
-template <int D, int MAXT, bool CENTERED>
-__global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTableH2 tt) {
+// WT: write-through output stores (st4o).  12 wavefronts per workgroup (<= 168 registers; a 16-wavefront build spilled and
+// was 4 % slower).
+template <int D, bool CENTERED, bool WT>
+__global__ __launch_bounds__(768) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTableH2 tt) {
     constexpr int NT4 = D / 4, TPG = D / 16, KBH = D / 32;
     constexpr int LAYER_BYTES = 2 * D * D * 2 + D * 4;  // { hi, lo, bias } of one MLP layer
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -382,8 +384,8 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
             float* cd = c_out + h2_state_row<D>(rc, g, out_blk);
 #pragma unroll
             for (int t = 0; t < TPG; ++t) {
-                st4o<0>(hd + t * out_ts, hn[t]);
-                st4o<0>(cd + t * out_ts, nc[t]);
+                st4o<WT>(hd + t * out_ts, hn[t]);
+                st4o<WT>(cd + t * out_ts, nc[t]);
             }
         }
     };
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 }
                 if (valid && mlp_out != nullptr) {
 #pragma unroll
-                    for (int t = 0; t < TPG; ++t) st4o<1>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                    for (int t = 0; t < TPG; ++t) st4o<WT>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
             }
 #if H2_TRACE
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(MAXT) void lnlstm_mlp_fwd_h2_kernel(const CellTaskT
                 }
                 if (valid && mlp_out != nullptr) {
 #pragma unroll
-                    for (int t = 0; t < TPG; ++t) st4(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
+                    for (int t = 0; t < TPG; ++t) st4o<WT>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
 #if H2_TRACE
 #pragma unroll
@@ -649,18 +651,6 @@ static int launch_mlp_h2(const tspgnn_mlp_task* tasks, int n, hipStream_t st) {
     return launched("tspgnn_mlp_fwd_multi_h2");
 }
 
-// Wavefronts per workgroup of the cell launch.  The kernel is compiled for 12 (<= 168 registers) and for 16
-// (<= 128 registers) wavefronts; TSPGNN_H2_WAVES picks one (development switch; final build, A/B/A/B on one box: 12
-// wavefronts 1.68-1.69 ms vs 1.75-1.77 ms at C2, 11.0 vs 11.4 ms at C4 -- the 16-wavefront build spills 16 registers).
-static int h2_cell_waves() {
-    static const int nw = [] {
-        const char* e = getenv("TSPGNN_H2_WAVES");
-        const int v = e ? atoi(e) : 0;
-        return (v == 12 || v == 16) ? v : 12;
-    }();
-    return nw;
-}
-
 // Working wavefronts per workgroup of a lock-step task (development switch TSPGNN_H2_LOCK_TILES; default: all of them --
 // 8 / 6 / 4 measured 40.3 / 54.1 / 52.3 us per C2 launch against 37.9: the edge task misses the CUs more than the vertex
 // chain gains from emptier matrix pipes).
@@ -722,7 +712,7 @@ static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
     tt.n = n;
     const size_t lds_bytes = lds_w + head;
     int grid = n_cus();
-    const int nw_max = h2_cell_waves();
+    const int nw_max = 12;
     const int nw = tiles_all <= (long long)grid * 4 ? 4 : (tiles_all <= (long long)grid * 8 ? 8 : nw_max);
     const long long max_grid = (tiles_all + nw - 1) / nw;
     if (grid > max_grid) grid = (int)max_grid;
@@ -770,20 +760,21 @@ static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
         }
     }
     bool centered = true;
-    for (int k = 0; k < n; ++k) centered = centered && tasks[k].cell.z_centered != 0;
-    const void* fn = nw_max == 16 ? (centered ? reinterpret_cast<const void*>(&lnlstm_mlp_fwd_h2_kernel<D, 1024, true>)
-                                              : reinterpret_cast<const void*>(&lnlstm_mlp_fwd_h2_kernel<D, 1024, false>))
-                                  : (centered ? reinterpret_cast<const void*>(&lnlstm_mlp_fwd_h2_kernel<D, 768, true>)
-                                              : reinterpret_cast<const void*>(&lnlstm_mlp_fwd_h2_kernel<D, 768, false>));
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute(%d B): %s", what, (int)lds_bytes, hipGetErrorString(e));
-    if (nw_max == 16) {
-        if (centered) lnlstm_mlp_fwd_h2_kernel<D, 1024, true><<<grid, nw * 64, lds_bytes, st>>>(tt);
-        else lnlstm_mlp_fwd_h2_kernel<D, 1024, false><<<grid, nw * 64, lds_bytes, st>>>(tt);
-    } else {
-        if (centered) lnlstm_mlp_fwd_h2_kernel<D, 768, true><<<grid, nw * 64, lds_bytes, st>>>(tt);
-        else lnlstm_mlp_fwd_h2_kernel<D, 768, false><<<grid, nw * 64, lds_bytes, st>>>(tt);
+    long long out_bytes = 0;   // h', c' of every task and its messages: what the launch stores (and the next ones re-read)
+    for (int k = 0; k < n; ++k) {
+        centered = centered && tasks[k].cell.z_centered != 0;
+        out_bytes += (long long)tasks[k].cell.rows * D * 4 * (tasks[k].mlp_out ? 3 : 2);
     }
+    // write-through output stores while the loop's arrays (two copies of the states, two of the messages: ~2x out_bytes)
+    // stay inside the 256 MB Infinity Cache; plain stores beyond (see st4o)
+    const bool wt = 2 * out_bytes <= (long long)200 * 1024 * 1024;
+    void (*fn)(const CellTaskTableH2) =
+        centered ? (wt ? &lnlstm_mlp_fwd_h2_kernel<D, true, true> : &lnlstm_mlp_fwd_h2_kernel<D, true, false>)
+                 : (wt ? &lnlstm_mlp_fwd_h2_kernel<D, false, true> : &lnlstm_mlp_fwd_h2_kernel<D, false, false>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute(%d B): %s", what, (int)lds_bytes, hipGetErrorString(e));
+    fn<<<grid, nw * 64, lds_bytes, st>>>(tt);
     return launched(what);
 }
 

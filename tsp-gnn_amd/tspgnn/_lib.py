@@ -73,8 +73,6 @@ SIGNATURES = {
     "tspgnn_einit_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_adam_clip_step_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
                                   c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
-    "tspgnn_csr_rowsum_split_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
-    "tspgnn_csr_rowsum_split_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "tspgnn_bucket_pack_f32": [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "tspgnn_bucket_unpack_f32": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
 }
