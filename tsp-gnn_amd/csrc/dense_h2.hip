@@ -36,23 +36,10 @@
 
 namespace tspgnn {
 
-// The cell launch's output rows (the states h', c' and the next step's messages) through one store helper.  WT: as
-// write-through `sc0 sc1` stores -- nothing in the launch reads them again, and a line stored that way does not sit dirty
-// in the XCD's L2 until the end-of-kernel release writes it back.  Pays when the loop's arrays live in the Infinity Cache
-// (C2: forward 1.467-1.485 -> 1.425-1.441 ms, five alternating runs on one box), costs when they do not (C4: 10.31-10.43 ->
-// 10.43-10.82 ms), so the launcher chooses by footprint (launch_cell_h2); profiles/r04_store_flavour_ab.txt.
-// The trailing s_nop is NOT optional: a VMEM store of more than 8 bytes reads its data registers up to two wait states
-// after issue on gfx940+; the compiler's hazard recogniser covers that for its own stores (GCNHazardRecognizer, "store
-// data overwritten by the next VALU") and cannot see inside an asm -- without it the first build of this helper stored
-// garbage whenever the register allocator reused a data register at once (anchor C1: loss off by 2.4e-3).
-template <bool WT>
-__device__ __forceinline__ void st4o(float* p, f32x4 v) {
-    if constexpr (WT) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-    } else {
-        st4(p, v);
-    }
-}
+// The cell launch's output rows (the states h', c' and the next step's messages) go through st4o<WT> (h2_tile.h).  WT --
+// write-through stores -- pays when the loop's arrays live in the Infinity Cache (C2: forward 1.467-1.485 -> 1.425-1.441 ms,
+// five alternating runs on one box) and costs when they do not (C4: 10.31-10.43 -> 10.43-10.82 ms), so the launcher chooses by
+// footprint (launch_cell_h2); profiles/r04_store_flavour_ab.txt.
 
 #if H2_TRACE
 __device__ unsigned long long h2_trace_buf[16 * 8];   // [wavefront][phase] of workgroup H2_TRACE_BLOCK, summed over its tiles
@@ -767,7 +754,11 @@ static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
     }
     // write-through output stores while the loop's arrays (two copies of the states, two of the messages: ~2x out_bytes)
     // stay inside the 256 MB Infinity Cache; plain stores beyond (see st4o)
-    const bool wt = 2 * out_bytes <= (long long)200 * 1024 * 1024;
+    static const int wt_forced = [] {   // (development switch TSPGNN_H2_WT=0/1)
+        const char* e = getenv("TSPGNN_H2_WT");
+        return e ? atoi(e) : -1;
+    }();
+    const bool wt = wt_forced >= 0 ? wt_forced != 0 : 2 * out_bytes <= (long long)200 * 1024 * 1024;
     void (*fn)(const CellTaskTableH2) =
         centered ? (wt ? &lnlstm_mlp_fwd_h2_kernel<D, true, true> : &lnlstm_mlp_fwd_h2_kernel<D, true, false>)
                  : (wt ? &lnlstm_mlp_fwd_h2_kernel<D, false, true> : &lnlstm_mlp_fwd_h2_kernel<D, false, false>);

@@ -104,6 +104,21 @@ __device__ __forceinline__ int opaque_lane() {
 
 __device__ __forceinline__ f16x8 ldw(const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); }
 
+// A 16-byte store of a row nothing in this launch reads again, optionally write-through (`sc0 sc1`): the line then does
+// not sit dirty in the XCD's L2 until the end-of-kernel release writes it back.
+// The trailing s_nop is NOT optional: a VMEM store of more than 8 bytes reads its data registers up to two wait states
+// after issue on gfx940+; the compiler's hazard recogniser covers that for its own stores (GCNHazardRecognizer, "store
+// data overwritten by the next VALU") and cannot see inside an asm -- without it the first build of this helper stored
+// garbage whenever the register allocator reused a data register at once (anchor C1: loss off by 2.4e-3).
+template <bool WT>
+__device__ __forceinline__ void st4o(float* p, f32x4 v) {
+    if constexpr (WT) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    } else {
+        *reinterpret_cast<f32x4*>(p) = v;
+    }
+}
+
 // acc[t] += W-block(kb, all NT tiles) x B for one 32-feature k-block; wh / wl = the two pieces of the packed matrix
 // (LDS), (bh, bl) = split2 of the lane's eight B values.  The fragments of tile t+1 are fetched while the three
 // (dependent) MFMAs of tile t run.
