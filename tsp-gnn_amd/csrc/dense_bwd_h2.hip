@@ -14,10 +14,6 @@
 //     the 16 outputs of the row are scaled back.
 #include "common.h"
 #include "h2_tile.h"
-
-#ifndef H2B_WT
-#define H2B_WT 0   // (round-4 experiment: write-through stores for dz, dc, dh; resolved before the round ends)
-#endif
 #include "lstm_bwd_tile.h"
 #include "mfma_tile.h"
 
@@ -127,10 +123,10 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
                 f32x4 v;
                 v.lo = acc[t].lo * sc2;
                 v.hi = acc[t].hi * sc2;
-                st4o<H2B_WT != 0>(dz + (size_t)rc * 4 * D + t * 16 + g * 4, v);
+                st4(dz + (size_t)rc * 4 * D + t * 16 + g * 4, v);
             }
 #pragma unroll
-            for (int t = 0; t < TPG; ++t) st4o<H2B_WT != 0>(dc_in + o + t * 16, dco[t]);
+            for (int t = 0; t < TPG; ++t) st4(dc_in + o + t * 16, dco[t]);
         }
         if (KT != nullptr) {
             // dh = dz' (2^s Kh)^T with the row of dz' normalised to [0.5, 1) by a power of two
@@ -157,7 +153,7 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
             }
             if (valid) {
 #pragma unroll
-                for (int t = 0; t < TPG; ++t) st4o<H2B_WT != 0>(dxh + (size_t)rc * D + t * 16 + g * 4, out[t] * down);
+                for (int t = 0; t < TPG; ++t) st4(dxh + (size_t)rc * D + t * 16 + g * 4, out[t] * down);
             }
         }
     }
