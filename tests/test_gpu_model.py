@@ -14,7 +14,8 @@ from oracle import torch_oracle as TO
 pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-5
-MOVE_TOL = 0.05    # three Adam steps: error of a variable's movement relative to its largest movement (see the test)
+MOVE_TOL = 0.05    # three Adam steps: error of a variable's movement relative to its largest movement (see the test;
+                   # measured 3.9e-2 in round 4 -- entries whose gradient sits at fp32 noise level, normalised by sqrt(v))
 
 
 def run_hip(d, params, batch_tuple, T, fetch=("loss", "acc", "predictions", "TP", "FP", "TN", "FN", "last_states"),
