@@ -220,7 +220,8 @@ int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_task
  *              gather-init mode): producer tiles store 1 KiB contiguous, and the edges' gathers find consecutive
  *              vertices in one 64-byte segment;
  *   lstm task: K packed [dx+d, 4d]; Zx in the projected-message format above; zbias unscaled; c may be NULL = the
- *     zero cell state (LSTM_initial_states' default at the first step of a run): nothing is read for it.
+ *     zero cell state (LSTM_initial_states' default at the first step of a run): nothing is read for it (the same in
+ *     tspgnn_lstm_task_bf16).
  *     The cell normalises the scaled z with epsilon 2^2s * 1e-12, which reproduces the gates of the unscaled z
  *     bit for bit (power-of-two scaling commutes with rounding).
  */
@@ -502,6 +503,14 @@ long long tspgnn_host_pack_batch(const void* const* Ma, const int* ma_kind, cons
  * range, -6 malformed weight matrix.
  */
 int tspgnn_host_read_graph(const char* path, int* n_out, int* route_len_out, int64_t* Ma, double* Mw, int64_t* route);
+
+/*
+ * Storage conversions of the bf16-storage mode (BASELINE config 5; graphnn.py:18 float_dtype): y[i] = bf16(x[i]), round to
+ * nearest even / y[i] = float(x[i]), n elements, both pointers 16-byte aligned.  The mode needs them at its two ends -- the
+ * caller's fp32 initial embeddings in, E.h out to the fp32 vote head (model.py:118-128).
+ */
+int tspgnn_convert_f32_to_bf16(const float* x, void* y, long long n, void* stream);
+int tspgnn_convert_bf16_to_f32(const void* x, float* y, long long n, void* stream);
 
 /*
  * The data-parallel bucket of a training step (the reference has no counterpart: model.py:157-167 run in

@@ -207,3 +207,56 @@ def test_lnlstm_bf16_gather_and_plain_tasks(cuda_device, d, c_blocked):
     rh, rc = NO.lnlstm(rb(xv), rb(hv), cv.astype(np.float64), rb(Kv), lnd_v)
     assert rel_err(c_host(cv_o, N, cout), rc) < F32_TOL
     assert rel_err(h_host(hv_o, N, cout), rb(rh)) < 2.0 ** -7
+
+
+@pytest.mark.parametrize("n", [0, 5, 8, 1000003])
+def test_storage_conversions(cuda_device, n):
+    """tspgnn_convert_f32_to_bf16 / _bf16_to_f32: round to nearest even exactly as the reference type conversion, widening
+    exact; tails that are not a multiple of 8."""
+    rng = np.random.RandomState(n + 1)
+    x = (rng.randn(n) * np.exp(rng.uniform(-20, 20, n))).astype(np.float32)
+    if n >= 5:
+        x[:5] = [0.0, -0.0, 1.00390625, 1.01171875, -65504.0]     # ties between two bf16 values among them
+    xd = dev(x, cuda_device)
+    y = torch.full((max(n, 1),), 7.0, dtype=torch.bfloat16, device=cuda_device)
+    _lib.call("tspgnn_convert_f32_to_bf16", _lib.ptr(xd) if n else None, _lib.ptr(y), n, None)
+    torch.cuda.synchronize()
+    want = torch.from_numpy(x).to(torch.bfloat16)
+    assert torch.equal(y[:n].cpu(), want)
+    back = torch.full((max(n, 1),), 7.0, dtype=torch.float32, device=cuda_device)
+    _lib.call("tspgnn_convert_bf16_to_f32", _lib.ptr(y), _lib.ptr(back), n, None)
+    torch.cuda.synchronize()
+    assert torch.equal(back[:n].cpu(), want.to(torch.float32))
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_lnlstm_bf16_null_cell_state_is_zero(cuda_device, d):
+    """tspgnn_lstm_task_bf16.c == NULL (no LSTM_initial_states at the first step of a run): bit-identical to a zero array."""
+    rng = np.random.RandomState(d)
+    N, M = 77, 1003
+    uv = np.stack([rng.randint(0, N, M), rng.randint(0, N, M)], 1).astype(np.int32)
+    Zx, he = rng.randn(N, 4 * d), rng.randn(M, d)
+    Kh = (rng.randn(d, 4 * d) / np.sqrt(d)).astype(np.float32)
+    ln_e, _ = ln_params(rng, d)
+    xv, hv = rng.randn(N, d), rng.randn(N, d)
+    Kv = (rng.randn(2 * d, 4 * d) / np.sqrt(2 * d)).astype(np.float32)
+    ln_v, _ = ln_params(rng, d)
+    outs = []
+    for null_c in (False, True):
+        ce = None if null_c else dev(np.zeros((M, d), np.float32), cuda_device)
+        cv = None if null_c else dev(np.zeros((N, d), np.float32), cuda_device)
+        he_o = torch.zeros((M, d), dtype=torch.bfloat16, device=cuda_device)
+        ce_o = torch.zeros((M, d), dtype=torch.float32, device=cuda_device)
+        hv_o = torch.zeros((N, d), dtype=torch.bfloat16, device=cuda_device)
+        cv_o = torch.zeros((N, d), dtype=torch.float32, device=cuda_device)
+        te = _lib.LstmTaskB(None, 0, _lib.ptr(dev_bf16(he, cuda_device)), _lib.ptr(ce), _lib.ptr(packed_bf16(Kh, cuda_device)),
+                            _lib.ptr(dev(ln_e, cuda_device)), _lib.ptr(he_o), _lib.ptr(ce_o), M,
+                            _lib.ptr(dev(uv, cuda_device, np.int32)), _lib.ptr(dev_bf16(h2_zx_pack(rb(Zx), 1.0), cuda_device)), 0, 0)
+        tv = _lib.LstmTaskB(_lib.ptr(dev_bf16(xv, cuda_device)), d, _lib.ptr(dev_bf16(hv, cuda_device)), _lib.ptr(cv),
+                            _lib.ptr(packed_bf16(Kv, cuda_device)), _lib.ptr(dev(ln_v, cuda_device)), _lib.ptr(hv_o), _lib.ptr(cv_o),
+                            N, None, None, 0, 0)
+        _lib.call_multi("tspgnn_lnlstm_fwd_multi_bf16", [te, tv], d)
+        torch.cuda.synchronize()
+        outs.append((he_o, ce_o, hv_o, cv_o))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -93,6 +93,29 @@ __global__ __launch_bounds__(256) void csr_rowsum_bf16_kernel(const int* __restr
     if (sub == 0) Y[(long long)v * LPR + c] = round8(acc);
 }
 
+// ---------------------------------------------------------------------------------- storage conversions
+// fp32 <-> bf16 (round to nearest even), 8 elements per lane: what the bf16-storage mode needs at its two ends (the caller's
+// fp32 embeddings in, the vote head's fp32 input out) without borrowing a tensor library's kernels.
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, long long n) {
+    const long long n8 = n >> 3, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const f32x4 a = ld4(x + i * 8), b = ld4(x + i * 8 + 4);
+        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        *reinterpret_cast<uint4*>(y + i * 8) = round8(v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[(n8 << 3) + threadIdx.x] = (__bf16)x[(n8 << 3) + threadIdx.x];
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const __bf16* __restrict__ x, float* __restrict__ y, long long n) {
+    const long long n8 = n >> 3, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        add8(v, *reinterpret_cast<const uint4*>(x + i * 8));
+        st4(y + i * 8, f32x4{v[0], v[1], v[2], v[3]});
+        st4(y + i * 8 + 4, f32x4{v[4], v[5], v[6], v[7]});
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[(n8 << 3) + threadIdx.x] = (float)x[(n8 << 3) + threadIdx.x];
+}
+
 // ---------------------------------------------------------------------------------- MLP (bf16)
 // wb: n_layers blocks of { bf16 packed[D*D] (piece 0 of pack_weights_x3), float bias[D] }; proj_w: bf16 packed [D,4D].
 struct MlpTableB {
@@ -320,7 +343,8 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTabl
     auto cell = [&](f32x4 (&acc)[NT4], size_t rc, bool valid) {
         f32x4 cf[TPG], hn[TPG], nc[TPG];
 #pragma unroll
-        for (int t = 0; t < TPG; ++t) cf[t] = ld4(c + c_blocked<D>((unsigned)rc, g, c_in_blk) + t * (c_in_blk ? 256 : 16));
+        for (int t = 0; t < TPG; ++t)
+            cf[t] = c != nullptr ? ld4(c + c_blocked<D>((unsigned)rc, g, c_in_blk) + t * (c_in_blk ? 256 : 16)) : f32x4{0.f, 0.f, 0.f, 0.f};
         lstm_gates<D, true, true>(acc, cf, lds_ln, g, hn, nc);
         if (valid) {
 #pragma unroll
@@ -361,7 +385,8 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_fwd_bf16_kernel(const LstmTabl
                 for (int kb = 0; kb < D / 32; ++kb) bv[kb] = row_operand(hrow, kb, c_in_blk);
                 f32x4 cs[TPG];
 #pragma unroll
-                for (int t = 0; t < TPG; ++t) cs[t] = ld4(c + c_blocked<D>(rc, g, c_in_blk) + t * (c_in_blk ? 256 : 16));
+                for (int t = 0; t < TPG; ++t)
+                    cs[t] = c != nullptr ? ld4(c + c_blocked<D>(rc, g, c_in_blk) + t * (c_in_blk ? 256 : 16)) : f32x4{0.f, 0.f, 0.f, 0.f};
                 ends = uv[row_of(ntile < t_end ? ntile : tile)];   // the next tile's endpoints, a tile ahead
                 bf16x4 iu[2 * TPG], iv[2 * TPG];
                 zx_load_part<0, 2 * TPG>(iu, iv, zu, zv);           // stage (i, j)'s rows behind stage f's product
@@ -576,7 +601,8 @@ extern "C" int tspgnn_lnlstm_fwd_multi_bf16(const tspgnn_lstm_task_bf16* tasks, 
         TSPGNN_REQUIRE(t.rows >= 0, "lnlstm_fwd_bf16: rows=%d", t.rows);
         TSPGNN_REQUIRE(t.dx >= 0 && t.dx % 32 == 0, "lnlstm_fwd_bf16: dx=%d must be a non-negative multiple of 32", t.dx);
         if (t.rows == 0) continue;
-        TSPGNN_REQUIRE(t.h && t.c && t.K && t.ln && t.h_out && t.c_out && (t.dx == 0 || t.x), "lnlstm_fwd_bf16: null pointer");
+        // (c == NULL: the zero cell state of a run's first step, nothing is read)
+        TSPGNN_REQUIRE(t.h && t.K && t.ln && t.h_out && t.c_out && (t.dx == 0 || t.x), "lnlstm_fwd_bf16: null pointer");
         TSPGNN_REQUIRE(t.h_out != t.h && t.c_out != t.c, "lnlstm_fwd_bf16: outputs may not alias inputs");
         TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx), "lnlstm_fwd_bf16: gather-init mode needs dx == 0 and Zx");
         live[n++] = t;
@@ -589,4 +615,28 @@ extern "C" int tspgnn_lnlstm_fwd_multi_bf16(const tspgnn_lstm_task_bf16* tasks, 
     if (d == 32) return launch_lstm_b<32, 8, false>(live, n, st);
     if (d == 64) return staged ? launch_lstm_b<64, 12, true>(live, n, st) : launch_lstm_b<64, 8, false>(live, n, st);
     return staged ? launch_lstm_b<128, 8, true>(live, n, st) : launch_lstm_b<128, 8, false>(live, n, st);
+}
+
+extern "C" int tspgnn_convert_f32_to_bf16(const float* x, void* y, long long n, void* stream) {
+    TSPGNN_REQUIRE(n >= 0, "convert_f32_to_bf16: n=%lld", n);
+    if (n == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(x && y, "convert_f32_to_bf16: null pointer");
+    TSPGNN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "convert_f32_to_bf16: pointers must be 16-byte aligned");
+    long long blocks = ((n >> 3) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    f32_to_bf16_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(x, reinterpret_cast<__bf16*>(y), n);
+    return launched("tspgnn_convert_f32_to_bf16");
+}
+
+extern "C" int tspgnn_convert_bf16_to_f32(const void* x, float* y, long long n, void* stream) {
+    TSPGNN_REQUIRE(n >= 0, "convert_bf16_to_f32: n=%lld", n);
+    if (n == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(x && y, "convert_bf16_to_f32: null pointer");
+    TSPGNN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "convert_bf16_to_f32: pointers must be 16-byte aligned");
+    long long blocks = ((n >> 3) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    bf16_to_f32_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const __bf16*>(x), y, n);
+    return launched("tspgnn_convert_bf16_to_f32");
 }

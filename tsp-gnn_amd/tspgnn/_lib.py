@@ -73,6 +73,8 @@ SIGNATURES = {
     "tspgnn_einit_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_adam_clip_step_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
                                   c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "tspgnn_convert_f32_to_bf16": [c_void_p, c_void_p, c_longlong, c_void_p],
+    "tspgnn_convert_bf16_to_f32": [c_void_p, c_void_p, c_longlong, c_void_p],
     "tspgnn_bucket_pack_f32": [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "tspgnn_bucket_unpack_f32": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
 }

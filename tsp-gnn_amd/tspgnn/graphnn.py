@@ -39,6 +39,39 @@ def _pad16(rows):
     return (int(rows) + 15) // 16 * 16
 
 
+def to_storage(x, dtype, out=None):
+    """``x`` (fp32) in the storage type of the embeddings: itself for fp32, rounded to bf16 (nearest even) by the library's
+    own kernel on the device (tspgnn_convert_f32_to_bf16) -- torch only converts on the CPU plumbing path."""
+    if dtype == torch.float32 or x.dtype == dtype:
+        x = x.contiguous()
+        if out is None:
+            return x
+        out.copy_(x)
+        return out
+    if dtype == torch.bfloat16 and x.is_cuda and x.dtype == torch.float32:
+        x = x.contiguous()
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        _lib.call("tspgnn_convert_f32_to_bf16", _lib.ptr(x), _lib.ptr(out), x.numel(), _lib.current_stream())
+        return out
+    y = x.to(dtype).contiguous()
+    if out is None:
+        return y
+    out.copy_(y)
+    return out
+
+
+def to_f32(x):
+    """Stored embeddings as fp32 (bf16 storage: widened once by tspgnn_convert_bf16_to_f32)."""
+    if x.dtype == torch.float32:
+        return x
+    if x.dtype == torch.bfloat16 and x.is_cuda and x.is_contiguous():
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        _lib.call("tspgnn_convert_bf16_to_f32", _lib.ptr(x), _lib.ptr(out), x.numel(), _lib.current_stream())
+        return out
+    return x.to(torch.float32)
+
+
 def _pack_split(store, arith, W, out, krows, ncols):
     """tspgnn_pack_weights_x3 / _h2 of W [krows, ncols] into the byte tensor ``out``; an f16x2 packing also raises the
     store's range guard word to max |2^s W| (VariableStore.h2_guard)."""
@@ -810,7 +843,7 @@ class GraphNN(object):
                         raise NotImplementedError("a matrix appended as a cell input must be dense")
                     dense_mats[m] = torch.as_tensor(a, dtype=torch.float32).to(device).contiguous()
         T = int(time_steps)
-        h0 = {v: init.to(self.float_dtype).contiguous() for v, init in initial_embeddings.items()}   # storage type
+        h0 = {v: to_storage(init, self.float_dtype) for v, init in initial_embeddings.items()}   # storage type
         c0 = {v: LSTM_initial_states[v].to(torch.float32).contiguous() if v in LSTM_initial_states else None for v in h0}
         folded = {v: self._folded(v, mats) for v in self.var}
         if T > 0 and self.float_dtype == torch.float32:
@@ -821,10 +854,10 @@ class GraphNN(object):
                 plan = self._plan_fused({v: LSTMStateTuple(c=c0[v], h=h0[v]) for v in h0}, mats, folded)
             if plan is not None:
                 return _States(plan(T), self._plan_keep)
+        if self.float_dtype == torch.bfloat16:   # (no initial cell state = a null pointer to the bf16 cell kernel: no zero fill)
+            return self._run_bf16({v: LSTMStateTuple(c=c0[v], h=h0[v]) for v in h0}, mats, dense_mats, T)
         states = {v: LSTMStateTuple(c=torch.zeros(h0[v].shape, dtype=torch.float32, device=h0[v].device) if c0[v] is None
                                     else c0[v], h=h0[v]) for v in h0}     # the cell state stays fp32
-        if self.float_dtype == torch.bfloat16:
-            return self._run_bf16(states, mats, dense_mats, T)
         if T > 0:
             plan = self._plan(states, mats, folded)
             if plan is not None and not self.check_h2_weights():
@@ -856,7 +889,9 @@ class GraphNN(object):
                     if m._plan[0] != "square" or m._plan[3] or not (1 <= m.n_square <= 4) or m.input_size != m.sizes[-1]:
                         raise NotImplementedError("bf16 storage needs square message MLPs of at most 4 layers")
         if T == 0:
-            return states
+            return {v: LSTMStateTuple(c=st.c if st.c is not None else torch.zeros(st.h.shape, dtype=torch.float32,
+                                                                                    device=st.h.device), h=st.h)
+                    for v, st in states.items()}
         # Between the steps the states live in two ping-pong buffers BLOCKED by 16 rows (include/tspgnn.h: the lstm
         # task's state_*_blocked, the mlp task's x_blocked) -- only the loop's own launches read them, and a tile is then
         # loaded and stored in contiguous runs instead of as pieces of 16 rows.  The first step reads the caller's
@@ -869,7 +904,7 @@ class GraphNN(object):
             return [{v: torch.empty((_pad16(st.h.shape[0]) if blocked[v] else st.h.shape[0], st.h.shape[1]),
                                     dtype=dtype, device=st.h.device) for v, st in states.items()} for _ in (0, 1)]
         hbuf, cbuf = buffers(torch.bfloat16), buffers(torch.float32)
-        last = {v: LSTMStateTuple(c=torch.empty_like(st.c), h=torch.empty_like(st.h)) for v, st in states.items()}
+        last = {v: LSTMStateTuple(c=torch.empty(st.h.shape, **f32), h=torch.empty_like(st.h)) for v, st in states.items()}
 
         def folds(v):   # single gather over a two-ones-per-row matrix behind a message MLP: Zx = msg(y) Kx on source rows
             if not self.fold_adjacency or len(self.loop[v]) != 1:
@@ -1403,7 +1438,8 @@ class GraphNN(object):
                 tape.ZX[v] = torch.empty((T, _pad16(rows_x), 4 * self.var[v]), **stored)
         tape.acts = {}
         for v in self.var:
-            tape.H[v][0].copy_(initial_embeddings[v])     # (bf16 storage: rounded here, as the inference mode does)
+            to_storage(initial_embeddings[v], self.float_dtype, out=tape.H[v][0])   # (bf16 storage: rounded here, as the
+                                                                                    # inference mode does)
             tape.C[v][0].zero_()
             for i, u in enumerate(self.loop[v]):
                 if "msg" in u:

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from . import variables as V
-from .graphnn import GEMM_ARITH, GraphNN, LSTMStateTuple
+from .graphnn import GEMM_ARITH, GraphNN, LSTMStateTuple, to_f32
 from .instance_loader import SparseEV
 from .mlp import Mlp
 
@@ -292,7 +292,7 @@ class Session(object):
         _lib.call("tspgnn_tile_rows_f32", _lib.ptr(self.store.view("V_init")), 1.0 / math.sqrt(float(d)),
                   _lib.ptr(V0), b.N, d, st)
         last = m["gnn"]({"EV": b.adj}, {"V": V0, "E": E0}, b.T)               # model.py:118-122
-        Eh = last["E"].h.to(torch.float32)                                    # (bf16 storage: widened once)
+        Eh = to_f32(last["E"].h)                                              # (bf16 storage: widened once)
         arith = m["gnn"].active_arith()
         vote = (m.E_vote_MLP.forward_split(Eh, arith) if arith else m.E_vote_MLP(Eh)).view(-1)   # model.py:128
         if arith == "h2" and not m["gnn"].check_h2_weights():     # (the vote head's packing vetoed f16x2: bf16x3)
@@ -418,7 +418,7 @@ class Session(object):
         # vote head: three relu Dense(d) + Dense(1) (model.py:107-115,128), keeping the hidden activations
         mv = m.E_vote_MLP
         n_sq = mv.n_square
-        EhT = last["E"].h.to(torch.float32)      # (bf16 storage: widened once; the vote head is fp32)
+        EhT = to_f32(last["E"].h)                # (bf16 storage: widened once; the vote head is fp32)
         Y3 = torch.empty((b.M, d), **f32)
         acts = torch.empty((max(n_sq - 1, 1), b.M, d), **f32)
         mv.forward_saving(EhT, Y3, acts, acts.stride(0))
