@@ -623,7 +623,7 @@ extern "C" int tspgnn_convert_f32_to_bf16(const float* x, void* y, long long n, 
     TSPGNN_REQUIRE(x && y, "convert_f32_to_bf16: null pointer");
     TSPGNN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "convert_f32_to_bf16: pointers must be 16-byte aligned");
     long long blocks = ((n >> 3) + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > (1ll << 30)) blocks = 1ll << 30;
     if (blocks < 1) blocks = 1;
     f32_to_bf16_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(x, reinterpret_cast<__bf16*>(y), n);
     return launched("tspgnn_convert_f32_to_bf16");
@@ -634,8 +634,8 @@ extern "C" int tspgnn_convert_bf16_to_f32(const void* x, float* y, long long n, 
     if (n == 0) return TSPGNN_OK;
     TSPGNN_REQUIRE(x && y, "convert_bf16_to_f32: null pointer");
     TSPGNN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "convert_bf16_to_f32: pointers must be 16-byte aligned");
-    long long blocks = ((n >> 3) + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    long long blocks = ((n >> 3) + 255) / 256;   // (one 16-byte load per thread: a pure stream, no grid-stride cap)
+    if (blocks > (1ll << 30)) blocks = 1ll << 30;
     if (blocks < 1) blocks = 1;
     bf16_to_f32_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const __bf16*>(x), y, n);
     return launched("tspgnn_convert_bf16_to_f32");
