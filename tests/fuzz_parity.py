@@ -67,6 +67,8 @@ def run_case(idx, case, with_grads, strict=True):
                 rel_err(last["E"].h, ref["last_states"]["E"][0].numpy()), rel_err(last["E"].c, ref["last_states"]["E"][1].numpy()),
                 rel_err(last["V"].h, ref["last_states"]["V"][0].numpy()), rel_err(last["V"].c, ref["last_states"]["V"][1].numpy()))
         errs[gemm] = e
+        if gemm == "f16x2":   # did the range guard send this batch to bf16x3?  (1: top of the range, 2: the variance floor)
+            errs["guard_bits"] = float(sess.last_range_bits)
         assert e < REL_TOL, ("forward", gemm, case, e)
         assert abs(float(loss) - ref["loss"].item()) < REL_TOL, ("loss", gemm, case)
         if gemm == "f16x2" and with_grads:
@@ -166,6 +168,7 @@ def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
     worst = {}
+    flagged = 0
     for i in range(n_cases):
         case = draw_case(rng)
         if os.environ.get("BF16"):
@@ -174,12 +177,14 @@ def main():
             errs = run_case_determinism(case)
         else:
             errs = run_case(i, case, with_grads=(i % 3 == 0), strict=False)
+        flagged += 1 if errs.get("guard_bits") else 0
         for k, v in errs.items():
             worst[k] = max(worst.get(k, 0.0), v)
         print("case %3d  B=%2d n=%s conn=%.1f d=%d T=%d  %s" % (
             i, len(case[0]), "%d..%d" % (min(case[0]), max(case[0])), case[1], case[2], case[3],
             "  ".join("%s %.2e" % kv for kv in sorted(errs.items()))), flush=True)
     print("worst over %d cases: %s" % (n_cases, "  ".join("%s %.2e" % kv for kv in sorted(worst.items()))))
+    print("f16x2 batches the range guard sent to bf16x3: %d of %d" % (flagged, n_cases))
 
 
 if __name__ == "__main__":
