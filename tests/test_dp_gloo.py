@@ -67,10 +67,16 @@ def _worker(rank, world, port, bounds, q):
     slots_ok = (float(sess._adam["m"].min()) == 3.0 and float(sess._adam["v"].max()) == 5.0
                 and int(sess._adam["t"]) == 7 and sess._adam["step"] == 7)
     # an assignment of the variables after the first sync (store.load on rank 0) triggers a new broadcast
-    sess._sync_replicas_once()         # nothing changed: no collective on any rank
+    sess._sync_replicas_once()         # nothing changed: the ranks agree on that (one 1-int all-reduce), no broadcast
     store.load({"V_init": np.full((1, d), float(rank + 2), dtype=np.float32)})
     sess._sync_replicas_once()
     resynced = float(store.view("V_init").min()) == 2.0 and float(store.view("V_init").max()) == 2.0
+    # ... and so does an assignment on rank 0 ALONE (a restore there only): its peers' counters did not move, the
+    # decision to broadcast is taken together -- before round 4 rank 0 broadcast while the others went on: a hang
+    if rank == 0:
+        store.load({"V_init": np.full((1, d), 9.0, dtype=np.float32)})
+    sess._sync_replicas_once()
+    resynced = resynced and float(store.view("V_init").min()) == 9.0 and float(store.view("V_init").max()) == 9.0
     store.load({"V_init": theta0[store.offset("V_init"):store.offset("V_init") + d].numpy()})
     sess._sync_replicas_once()
     means = sess.allreduce_host_sums(np.array([float(hi - lo), 1.0]))
