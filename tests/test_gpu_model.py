@@ -1117,3 +1117,40 @@ def test_train_step_clears_a_stale_range_flag(cuda_device):
         assert int(sess._adam["t"].item()) == k + 1 and sess._adam["step"] == k + 1
     assert not torch.equal(before, model.store.theta)
     assert model["gnn"].active_arith() == "h2"
+
+
+def test_replayed_training_raises_at_a_fixed_lag(cuda_device):
+    """The range guard under capture_train_step: replay i looks at the guard words as replay i - 2 left them (a fixed lag, so
+    that every rank of a data-parallel session raises at the same replay index).  A flag that goes up after replay 2 makes
+    the device skip replays 3 and 4 (variables and step counter untouched) and replay 5 raise; the host mirror of the step
+    counter is then the device's, f16x2 is off for these variables, and a new capture runs (on bf16x3)."""
+    t = pack_tuple("ragged_B6", 1)
+    model = tspgnn.build_network(64)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(P.init_params(64, seed=9, perturb=True))
+    EV, W, C, route_exists, n_vertices, n_edges = t
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: 2,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    b = sess.prepare(feed)
+    sess.store.h2_guard()[0:1].fill_(1)          # a stale flag from an unchecked forward(): not this capture's business
+    step = sess.capture_train_step(b)
+    assert model["gnn"].active_arith() == "h2"
+    for _ in range(3):                           # replays 0, 1, 2: applied
+        step()
+    torch.cuda.synchronize()
+    assert int(sess._adam["t"].item()) == 3 and sess._adam["step"] == 3
+    theta3 = model.store.theta.clone()
+    sess.store.h2_guard()[0:1].fill_(2)          # what a kernel of replay 3 would raise (here: the variance floor's bit)
+    step()                                       # replay 3: looks at replay 1's words (clean); skipped on the device
+    step()                                       # replay 4: looks at replay 2's words (clean); skipped on the device
+    torch.cuda.synchronize()
+    assert int(sess._adam["t"].item()) == 3 and torch.equal(model.store.theta, theta3)
+    with pytest.raises(RuntimeError, match="capture_train_step\\(\\) again"):
+        step()                                   # replay 5: replay 3's words carry the flag
+    assert sess._adam["step"] == 3 and sess.last_range_bits == 2
+    assert model["gnn"].active_arith() == "x3" and int(sess.store.h2_guard()[0].item()) == 0
+    step = sess.capture_train_step(b)
+    step()
+    torch.cuda.synchronize()
+    assert int(sess._adam["t"].item()) == 4 and sess._adam["step"] == 4 and not torch.equal(model.store.theta, theta3)
