@@ -130,6 +130,7 @@ def main():
                     help="fresh-batch ('serve') leg: this many batches of NEW instances go host instances -> native packer "
                          "-> BatchPrefetcher (worker thread, side-stream upload) -> DeviceBatch.copy_from -> replayed graph; "
                          "0 skips it.  Reported under 'serve', never in 'value'.")
+    ap.add_argument("--serve-workers", type=int, default=2, help="packer threads of the serve leg's BatchPrefetcher")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (bounded sample)")
     args = ap.parse_args()
@@ -239,22 +240,27 @@ def main():
             pool = {n: [tspgnn.random_instance(n, rng) for _ in range(min(len(sizes), 64) if len(uniq) > 1 else 3 * len(sizes))]
                     for n in uniq}
 
-            def fresh_batches(nb):
+            def fresh_instances(nb):
                 for i in range(nb):
-                    inst = [pool[int(n)][(i * 37 + j) % len(pool[int(n)])] for j, n in enumerate(sizes)]
-                    yield tspgnn.InstanceLoader.create_batch(inst, dev=0.02)
+                    yield [pool[int(n)][(i * 37 + j) % len(pool[int(n)])] for j, n in enumerate(sizes)]
+
+            def pack(inst):   # runs on the prefetcher's worker threads (native packer: the GIL is released inside)
+                return tspgnn.InstanceLoader.create_batch(inst, dev=0.02)
+
+            def prefetched(nb):
+                return tspgnn.BatchPrefetcher(sess, fresh_instances(nb), T, workers=args.serve_workers, pack=pack)
 
             t_p0 = time.perf_counter()
-            for _ in fresh_batches(4):
-                pass
+            for inst in fresh_instances(4):
+                pack(inst)
             pack_ms = 1e3 * (time.perf_counter() - t_p0) / 4
-            for bb in tspgnn.BatchPrefetcher(sess, fresh_batches(3), T):      # warm-up: allocator, worker thread
+            for bb in prefetched(3):      # warm-up: allocator, worker threads
                 dev_batch.copy_from(bb)
                 replay()
             barrier()
             t_s0 = time.perf_counter()
             keep = []
-            for bb in tspgnn.BatchPrefetcher(sess, fresh_batches(args.serve_batches), T):
+            for bb in prefetched(args.serve_batches):
                 dev_batch.copy_from(bb)
                 keep.append(replay()["predictions"].clone())
             barrier()
@@ -263,9 +269,9 @@ def main():
                 tmax = torch.tensor([dt_serve, pack_ms], dtype=torch.float64, device=device)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 dt_serve, pack_ms = float(tmax[0].item()), float(tmax[1].item())
-            serve = {"what": "fresh instances every batch: host instances -> native packer (worker thread) -> side-stream "
-                             "upload -> DeviceBatch.copy_from -> replayed forward graph; one packer + prefetcher per rank; "
-                             "max over ranks", "batches": args.serve_batches,
+            serve = {"what": "fresh instances every batch: host instances -> native packer (%d worker threads) -> side-stream "
+                             "upload -> DeviceBatch.copy_from -> replayed forward graph; one prefetcher per rank; "
+                             "max over ranks" % args.serve_workers, "batches": args.serve_batches,
                      "ms_per_batch": round(1e3 * dt_serve / args.serve_batches, 4),
                      "value": round(world * args.serve_batches * T / dt_serve, 2), "unit": "mp-steps/s",
                      "host_pack_ms_per_batch_one_thread": round(pack_ms, 3), "n_gpus": world,

@@ -482,9 +482,10 @@ def test_batch_prefetcher_feeds_identical_batches(cuda_device):
     # many batches without any synchronisation between them (batches are dropped while their kernels are still
     # queued: the uploads' memory must not be recycled underneath them), and a failing producer is reported
     stream = [host_batches[i % 4] for i in range(40)]
-    got = [sess.forward_device(b)["predictions"] for b in tspgnn.BatchPrefetcher(sess, stream, 3)]
-    torch.cuda.synchronize()
-    assert all(torch.equal(g, want[i % 4]) for i, g in enumerate(got))
+    for workers in (1, 3):   # (several packer threads, each with its own upload stream: still in order)
+        got = [sess.forward_device(b)["predictions"] for b in tspgnn.BatchPrefetcher(sess, stream, 3, workers=workers)]
+        torch.cuda.synchronize()
+        assert all(torch.equal(g, want[i % 4]) for i, g in enumerate(got))
 
     def broken():
         yield host_batches[0]

@@ -107,3 +107,34 @@ def test_shard_instances_balances_edges_and_keeps_pairs():
     by_count = [len(instances) // 8] * 8                         # what naive equal-count sharding would give
     naive = [sum(np.count_nonzero(instances[i][0]) for i in range(r * 16, r * 16 + 16)) for r in range(8)]
     assert max(loads) <= max(naive)
+
+
+def test_batch_prefetcher_keeps_the_order_with_several_workers():
+    """parallel.BatchPrefetcher with ``workers`` packer threads and ``pack=``: batches come out in the iterator's order
+    whatever order the workers finish in, and a failing item surfaces in the consumer after the batches before it
+    (device="cpu": plumbing only, nothing is launched)."""
+    import time
+    import numpy as np
+    import pytest
+    import tspgnn
+    model = tspgnn.build_network(32)
+    sess = tspgnn.Session(model, device="cpu")
+    rng = np.random.RandomState(0)
+    insts = [[tspgnn.random_instance(int(rng.randint(4, 9)), rng) for _ in range(2)] for _ in range(9)]
+    delays = rng.rand(len(insts)) * 0.01
+
+    def pack(inst):
+        time.sleep(delays[[i is inst for i in insts].index(True)])
+        return tspgnn.InstanceLoader.create_batch(inst, dev=0.02)
+    got = [b.M for b in tspgnn.BatchPrefetcher(sess, iter(insts), 2, workers=3, pack=pack)]
+    assert got == [tspgnn.InstanceLoader.create_batch(i)[0].shape[0] for i in insts]
+
+    def bad(inst):
+        if inst is insts[4]:
+            raise ValueError("boom")
+        return tspgnn.InstanceLoader.create_batch(inst)
+    seen = []
+    with pytest.raises(RuntimeError, match="worker failed"):
+        for b in tspgnn.BatchPrefetcher(sess, iter(insts), 2, workers=2, pack=bad):
+            seen.append(b.M)
+    assert seen == got[:4]

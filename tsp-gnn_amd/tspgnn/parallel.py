@@ -5,8 +5,8 @@
   (the cost of a message-passing step is proportional to M = sum n(n-1)/2, not to the number of graphs) and the
   reference's +/- pair -- the same graph with target cost (1-dev) and (1+dev) at consecutive positions
   (instance_loader.py:21-23,73) -- stays on one rank so labels keep alternating 0/1 inside every shard.
-* ``BatchPrefetcher``: packs the next batch on a background thread (native packer) and uploads it on a side
-  stream while the GPU works on the current one (double buffering); a failure of the worker is re-raised in the
+* ``BatchPrefetcher``: packs the next batches on background threads (native packer) and uploads them on side
+  streams while the GPU works on the current one (double buffering; batches come out in order); a failure of the worker is re-raised in the
   consumer, and the uploaded tensors are registered with the consumer's stream (record_stream) so that the caching
   allocator does not recycle them under kernels that still read them.
 """
@@ -45,18 +45,28 @@ def shard_instances(instances, world_size, pair=True):
 class BatchPrefetcher(object):
     """Iterates device-resident batches: ``for dev_batch in BatchPrefetcher(sess, batch_iter, time_steps)``.
 
-    ``batch_iter`` yields create_batch 6-tuples (host).  While the caller runs step i on the main stream, a
-    worker thread packs batch i+1 (CSR build included) and enqueues its upload on a side stream."""
+    ``batch_iter`` yields create_batch 6-tuples (host) -- or, with ``pack=``, whatever ``pack(item)`` turns into one (e.g.
+    lists of instances with ``pack=lambda inst: InstanceLoader.create_batch(inst, dev)``: the packing then runs on the
+    workers, in parallel, instead of inside the iterator).  While the caller runs step i on the main stream, ``workers``
+    threads pack the next batches (CSR build included; the native packer releases the GIL) and enqueue their uploads on
+    side streams; batches come out in the iterator's order."""
 
-    def __init__(self, sess, batch_iter, time_steps, depth=2, pinned=False):
+    def __init__(self, sess, batch_iter, time_steps, depth=2, pinned=False, workers=1, pack=None):
         """``pinned``: stage uploads through pinned host memory (non-blocking copies).  Off by default: measured on
         this stack, pinning fresh buffers for every batch costs ~20 ms per C2 batch, while the worker thread's
         blocking copies from pageable memory (the GIL is released) keep up: 2.5 ms per batch end to end."""
-        self.sess, self.it, self.T, self.depth, self.pinned = sess, iter(batch_iter), time_steps, depth, bool(pinned)
-        self.stream = torch.cuda.Stream(device=sess.device) if sess.device.type == "cuda" else None
-        self._queue, self._lock, self._done = [], threading.Condition(), False
-        self._thread = threading.Thread(target=self._work, daemon=True)
-        self._thread.start()
+        self.sess, self.it, self.T, self.pinned, self.pack = sess, iter(batch_iter), time_steps, bool(pinned), pack
+        self.workers = max(1, int(workers))
+        self.depth = max(int(depth), self.workers)
+        self._lock = threading.Condition()
+        self._ready = {}            # sequence number -> (batch, event)
+        self._next_in = 0           # next sequence number a worker takes from the iterator
+        self._next_out = 0          # next sequence number the consumer hands out
+        self._exhausted_at = None   # sequence number at which the iterator ended
+        self._error = None
+        self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(self.workers)]
+        for t in self._threads:
+            t.start()
 
     def _feed(self, t):
         m = self.sess.model
@@ -65,27 +75,38 @@ class BatchPrefetcher(object):
                 m["n_vertices"]: n_vertices, m["n_edges"]: n_edges}
 
     def _work(self):
+        stream = torch.cuda.Stream(device=self.sess.device) if self.sess.device.type == "cuda" else None
         try:
-            self._error = None
-            for t in self.it:
+            while True:
                 with self._lock:
-                    while len(self._queue) >= self.depth:
+                    # at most ``depth`` batches taken but not yet handed out; the iterator itself is advanced by one
+                    # thread at a time (generators are not re-entrant)
+                    while self._error is None and self._exhausted_at is None and self._next_in - self._next_out >= self.depth:
                         self._lock.wait()
-                if self.stream is not None:
-                    with torch.cuda.stream(self.stream):
+                    if self._error is not None or self._exhausted_at is not None:
+                        return
+                    try:
+                        item = next(self.it)
+                    except StopIteration:
+                        self._exhausted_at = self._next_in
+                        self._lock.notify_all()
+                        return
+                    seq = self._next_in
+                    self._next_in += 1
+                t = self.pack(item) if self.pack is not None else item
+                if stream is not None:
+                    with torch.cuda.stream(stream):
                         b = self.sess.prepare(self._feed(t), pinned=self.pinned)
                         ev = torch.cuda.Event()
-                        ev.record(self.stream)
+                        ev.record(stream)
                 else:
                     b, ev = self.sess.prepare(self._feed(t)), None
                 with self._lock:
-                    self._queue.append((b, ev))
+                    self._ready[seq] = (b, ev)
                     self._lock.notify_all()
         except BaseException as exc:   # handed to the consumer: a dead worker must not look like an empty dataset
-            self._error = exc
-        finally:
             with self._lock:
-                self._done = True
+                self._error = exc
                 self._lock.notify_all()
 
     def __iter__(self):
@@ -93,15 +114,20 @@ class BatchPrefetcher(object):
 
     def __next__(self):
         with self._lock:
-            while not self._queue and not self._done:
-                self._lock.wait()
-            if not self._queue:
-                if getattr(self, "_error", None) is not None:
+            while True:
+                if self._next_out in self._ready:
+                    b, ev = self._ready.pop(self._next_out)
+                    self._next_out += 1
+                    self._lock.notify_all()
+                    break
+                if self._error is not None:
                     err, self._error = self._error, None
+                    self._exhausted_at = self._next_out      # (the remaining workers stop)
+                    self._lock.notify_all()
                     raise RuntimeError("BatchPrefetcher worker failed") from err
-                raise StopIteration
-            b, ev = self._queue.pop(0)
-            self._lock.notify_all()
+                if self._exhausted_at is not None and self._next_out >= self._exhausted_at:
+                    raise StopIteration
+                self._lock.wait()
         if ev is not None:
             cur = torch.cuda.current_stream()
             cur.wait_event(ev)   # the upload must land before the main stream reads it
