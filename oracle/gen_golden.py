@@ -143,7 +143,7 @@ def gen_anchors():
         print("anchor", name, "T", T, "M", EV.shape[0], "loss %.9f" % data["loss"], "%.1f s" % (time.time() - t0))
 
 
-def gen_bf16_anchors():
+def gen_bf16_anchors(only=None):
     """anchor_bf16_*.npz: the bf16-storage oracle (torch_oracle.forward(bf16=True)) and the plain float64 oracle at the
     depth and width of BASELINE config 5 (tests/test_gpu_anchors.py::test_bf16_storage_at_config5_depth)."""
     import time
@@ -152,6 +152,8 @@ def gen_bf16_anchors():
 
     torch.set_num_threads(os.cpu_count() or 1)
     for name in BF16_ANCHORS:
+        if only and name not in only:
+            continue
         batch, params, d, T, finger = bf16_anchor_inputs(name)
         EV, W, C, route_exists, n_vertices, n_edges = batch
         ob = {"ev_uv": EV.uv, "W": W, "C": C, "route_exists": route_exists, "n_vertices": n_vertices, "n_edges": n_edges}
@@ -215,3 +217,6 @@ if __name__ == "__main__":
         gen_graph()
     if "bf16" in what:
         gen_bf16_anchors()
+    for w in what:   # "bf16:<name>": one bf16 anchor only (the others take minutes and do not change)
+        if w.startswith("bf16:"):
+            gen_bf16_anchors(only=w[5:].split(","))

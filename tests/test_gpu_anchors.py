@@ -48,10 +48,12 @@ def test_full_size_forward_matches_float64_anchor(cuda_device, name, gemm):
         assert v < REL_TOL, (k, v)
 
 
-def test_bf16_storage_at_config5_depth(cuda_device):
+@pytest.mark.parametrize("name", ["c5", "c5shard"])
+def test_bf16_storage_at_config5_depth(cuda_device, name):
     """BASELINE config 5's mode (bf16 embeddings, fp32 accumulate) at ITS graph size, width and depth -- n=200, d=128,
-    T=64 -- on 4 graphs of a shard (M = 79 600 edges), against committed outputs of the oracle that rounds to bf16 at the
-    same points (oracle/torch_oracle.message_passing_bf16; 2 min of float64 on the build host, so it is an anchor).
+    T=64 -- on 4 graphs of a shard (M = 79 600 edges; "c5"), and on ALL 32 graphs of one GPU's shard -- M = 636 800 edges,
+    the size `bench.py --workload c5` runs -- at T = 2 ("c5shard"), against committed outputs of the oracle that rounds to
+    bf16 at the same points (oracle/torch_oracle.message_passing_bf16; minutes of float64 on the build host: anchors).
     Two kinds of bars: the bulk of the values (rms, relative to the tensor's largest entry) must agree to a small
     fraction of a bf16 ulp; single entries may land on the other side of a rounding boundary and then differ by whole
     ulps at the top of the range (2^-8 = 3.9e-3 each), so the max bar is a few ulps.  The fp32 semantics (plain float64
@@ -59,8 +61,8 @@ def test_bf16_storage_at_config5_depth(cuda_device):
     import torch
     import tspgnn
     from oracle.anchors import anchor_rows, bf16_anchor_inputs
-    z = np.load(os.path.join(GOLDEN, "anchor_bf16_c5.npz"))
-    batch, params, d, T, finger = bf16_anchor_inputs("c5")
+    z = np.load(os.path.join(GOLDEN, "anchor_bf16_%s.npz" % name))
+    batch, params, d, T, finger = bf16_anchor_inputs(name)
     assert T == int(z["T"]) and d == int(z["d"]) and np.array_equal(finger, z["fingerprint"]), "inputs differ from the anchor's"
     EV, W, C, route_exists, n_vertices, n_edges = batch
     model = tspgnn.build_network(d, float_dtype=torch.bfloat16)
@@ -87,7 +89,7 @@ def test_bf16_storage_at_config5_depth(cuda_device):
             assert fmx < 4e-2 and frms < 6e-3, (var, part, fmx, frms)
     e_pred = np.abs(pred - z["bf16_predictions"]).max() / np.abs(z["bf16_predictions"]).max()
     f_pred = np.abs(pred - z["f64_predictions"]).max() / np.abs(z["f64_predictions"]).max()
-    print("bf16 @ config-5 depth: pred %.1e (fp32 semantics %.1e)  loss diff %.1e  %s"
-          % (e_pred, f_pred, abs(float(loss) - float(z["bf16_loss"])), "  ".join(report)))
+    print("bf16 @ config-5 %s: pred %.1e (fp32 semantics %.1e)  loss diff %.1e  %s"
+          % (name, e_pred, f_pred, abs(float(loss) - float(z["bf16_loss"])), "  ".join(report)))
     assert e_pred < 5e-4 and abs(float(loss) - float(z["bf16_loss"])) < 2e-4
     assert f_pred < 1e-2
