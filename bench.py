@@ -130,7 +130,9 @@ def main():
                     help="fresh-batch ('serve') leg: this many batches of NEW instances go host instances -> native packer "
                          "-> BatchPrefetcher (worker thread, side-stream upload) -> DeviceBatch.copy_from -> replayed graph; "
                          "0 skips it.  Reported under 'serve', never in 'value'.")
-    ap.add_argument("--serve-workers", type=int, default=2, help="packer threads of the serve leg's BatchPrefetcher")
+    ap.add_argument("--serve-workers", type=int, default=1,
+                    help="packer threads of the serve leg's BatchPrefetcher (measured: one keeps up at C2 / C4 and a second one's "
+                         "uploads disturb the forward -- 1.51-1.55 vs 1.56-1.89 ms per C2 batch, 11.3-11.6 vs 16.5-18.2 ms at C4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (bounded sample)")
     args = ap.parse_args()

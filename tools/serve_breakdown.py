@@ -36,15 +36,21 @@ t0 = time.perf_counter()
 for inst in instances(8): pack(inst)
 res["pack_ms_one_thread"] = round(1e3 * (time.perf_counter() - t0) / 8, 3)
 t0 = time.perf_counter()
-for inst in instances(8): sess.prepare(dict(feed, **{model["EV"]: pack(inst)[0]}))
+def feed_of(t):
+    EV, W, C, r, nv, ne = t
+    return {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T, model["route_exists"]: r, model["n_vertices"]: nv, model["n_edges"]: ne}
+for inst in instances(8): sess.prepare(feed_of(pack(inst)))
 torch.cuda.synchronize(); res["pack_plus_prepare_ms_one_thread"] = round(1e3 * (time.perf_counter() - t0) / 8, 3)
-for workers in (1, 2, 3):
-    for _ in tspgnn.BatchPrefetcher(sess, instances(4), T, workers=workers, pack=pack): pass
+for pinned in (False, True):
+  for workers in (1, 2):
+    tag = "w%d%s" % (workers, "_pinned" if pinned else "")
+    for _ in tspgnn.BatchPrefetcher(sess, instances(6), T, workers=workers, pack=pack, pinned=pinned): pass
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for b in tspgnn.BatchPrefetcher(sess, instances(nb), T, workers=workers, pack=pack): pass
-    torch.cuda.synchronize(); res["prefetcher_alone_ms_w%d" % workers] = round(1e3 * (time.perf_counter() - t0) / nb, 4)
-    t0 = time.perf_counter()
-    for b in tspgnn.BatchPrefetcher(sess, instances(nb), T, workers=workers, pack=pack):
-        dev_batch.copy_from(b); replay()["predictions"].clone()
-    torch.cuda.synchronize(); res["serve_ms_w%d" % workers] = round(1e3 * (time.perf_counter() - t0) / nb, 4)
+    for b in tspgnn.BatchPrefetcher(sess, instances(nb), T, workers=workers, pack=pack, pinned=pinned): pass
+    torch.cuda.synchronize(); res["prefetcher_alone_ms_" + tag] = round(1e3 * (time.perf_counter() - t0) / nb, 4)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        for b in tspgnn.BatchPrefetcher(sess, instances(nb), T, workers=workers, pack=pack, pinned=pinned):
+            dev_batch.copy_from(b); replay()["predictions"].clone()
+        torch.cuda.synchronize(); res["serve_ms_%s_run%d" % (tag, rep)] = round(1e3 * (time.perf_counter() - t0) / nb, 4)
 print(json.dumps(res))

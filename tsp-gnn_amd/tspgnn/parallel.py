@@ -54,7 +54,11 @@ class BatchPrefetcher(object):
     def __init__(self, sess, batch_iter, time_steps, depth=2, pinned=False, workers=1, pack=None):
         """``pinned``: stage uploads through pinned host memory (non-blocking copies).  Off by default: measured on
         this stack, pinning fresh buffers for every batch costs ~20 ms per C2 batch, while the worker thread's
-        blocking copies from pageable memory (the GIL is released) keep up: 2.5 ms per batch end to end."""
+        blocking copies from pageable memory (the GIL is released) keep up: 2.5 ms per batch end to end.  (Round 4: ONE
+        reusable pinned buffer and one asynchronous copy per batch was built and is slower still -- 3.4 vs 1.3 ms per C2
+        batch for the prefetcher alone: the CPU's writes INTO pinned memory are the slow part on this stack; not kept.
+        ``workers`` > 1 packs faster -- 0.97 vs 1.31 ms per batch -- but its concurrent uploads disturb the forward:
+        leave it at 1 unless packing is what you wait for.)"""
         self.sess, self.it, self.T, self.pinned, self.pack = sess, iter(batch_iter), time_steps, bool(pinned), pack
         self.workers = max(1, int(workers))
         self.depth = max(int(depth), self.workers)
