@@ -193,3 +193,28 @@ def test_lnlstm_cell_reproduces_tensorflow_unit_test_constants():
         for got_h, got_c in ((h_t.numpy(), c_t.numpy()), (h_n, c_n)):
             assert np.abs(got_h - want_h).max() < 5e-9 and np.abs(got_c - want_c).max() < 5e-9
         inp_t, inp_n = h_t, h_n
+
+
+def test_tensorflow_published_constants_for_clip_round_and_l2():
+    """More of the little that TensorFlow 1.x itself publishes as numbers for ops on this path (the reference pins none):
+    * tf.clip_by_global_norm -- clip_ops_test.ClipTest.testClipByGlobalNormClipped: x0 = [[-2, 0, 0], [4, 0, 0]],
+      x1 = [1, -2], clip_norm 4 -> global norm 5, answers [[-1.6, 0, 0], [3.2, 0, 0]] and [0.8, -1.6];
+    * tf.round -- its docstring: [0.9, 2.5, 2.3, 1.5, -4.5] -> [1, 2, 2, 2, -4] (half to even), which the oracle's metrics
+      (model.py:150-154) take from torch.round and the device from rintf;
+    * tf.nn.l2_loss -- nn_test.L2LossTest.testL2Loss: [1, 0, 3, 2] -> 7 (sum of squares / 2, no square root), the form
+      the oracle's vars_cost (model.py:163) is written in.
+    They narrow the 'parity unpinned' gap for model.py:150-167; they do not close it."""
+    g = {"x0": np.array([[-2.0, 0.0, 0.0], [4.0, 0.0, 0.0]]), "x1": np.array([1.0, -2.0])}
+    clipped, gn = TO.clip_by_global_norm(g, 4.0)
+    assert gn == 5.0
+    assert np.allclose(clipped["x0"], [[-1.6, 0.0, 0.0], [3.2, 0.0, 0.0]], rtol=0, atol=1e-15)
+    assert np.allclose(clipped["x1"], [0.8, -1.6], rtol=0, atol=1e-15)
+    x = torch.tensor([0.9, 2.5, 2.3, 1.5, -4.5], dtype=torch.float64)
+    assert torch.round(x).tolist() == [1.0, 2.0, 2.0, 2.0, -4.0]
+    assert np.rint(x.numpy()).tolist() == [1.0, 2.0, 2.0, 2.0, -4.0]
+    # the oracle's vars_cost term, evaluated as loss_and_grads does: d/dp (sum p^2 / 2) = p, and the value is 7
+    p = torch.tensor([1.0, 0.0, 3.0, 2.0], dtype=torch.float64, requires_grad=True)
+    cost = (p ** 2).sum() / 2
+    assert float(cost) == 7.0
+    (grad,) = torch.autograd.grad(cost, [p])
+    assert grad.tolist() == [1.0, 0.0, 3.0, 2.0]
