@@ -19,7 +19,7 @@ model = tspgnn.build_network(64)
 sess = tspgnn.Session(model)
 sess.run(tspgnn.global_variables_initializer(seed=0))
 out = []
-for B in (88, 96, 104, 112, 116, 120, 124, 128, 132, 136, 144, 152, 160, 176):
+for B in [int(x) for x in os.environ.get("GRAPHS", "88,96,104,112,116,120,124,128,132,136,144,152,160,176").split(",")]:
     EV, W, C, r, nv, ne = tspgnn.synthetic_batch([40] * B, seed=1234)
     feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T, model["route_exists"]: r,
             model["n_vertices"]: nv, model["n_edges"]: ne}
