@@ -611,11 +611,12 @@ class Session(object):
         back.  In a data-parallel session the flag every rank reads is the all-reduced one, so all ranks repeat
         together."""
         self._sync_replicas_once()
-        guarded = self.device.type == "cuda" and self.model["gnn"].active_arith() == "h2"   # (only f16x2 launches raise it)
-        if guarded:
-            self.store.h2_guard()[0:1].zero_()
+        on_gpu = self.device.type == "cuda"
+        h2 = on_gpu and self.model["gnn"].active_arith() == "h2"   # (only f16x2 launches raise the flag: no read-back without)
+        if on_gpu:
+            self.store.h2_guard()[0:1].zero_()     # always: the optimiser kernel skips on a non-zero word whatever set it
         out = self._train_step_once(feed)
-        if guarded and self.range_exceeded():
+        if h2 and self.range_exceeded():
             self._adam["step"] -= 1     # (Adam skipped the update on the device: theta, m, v and t are untouched)
             with self.model["gnn"].forced_off_h2():
                 out = self._train_step_once(feed)
