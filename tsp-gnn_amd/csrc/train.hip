@@ -2,6 +2,7 @@
 // loss -> edge votes, the vote head's Dense(1), column sums, E_init_MLP weight gradients,
 // L2 term + global-norm clip + Adam on the flat parameter buffer.
 #include "common.h"
+#include "mfma_tile.h"
 
 namespace tspgnn {
 
@@ -69,23 +70,32 @@ __global__ __launch_bounds__(256) void wcolsum_kernel(const float4* __restrict__
 }
 
 // ------------------------------------------------------------- E_init_MLP weight gradients
-// Persistent workgroups over chunks of 64 edges; every thread owns a strided set of the NP parameters (2 824 at d=64,
-// 11 088 at d=128) and keeps their sums in registers across ALL of the workgroup's chunks -- one partial row per
-// workgroup (512 rows) instead of one per chunk (9 950 rows = 441 MB at the C5 shard's 636 800 edges).  Per chunk:
-//   1a (all 256 threads, four per edge): recompute the forward chain of the edge, then a quarter of
-//      d3 = relu'(a3) . (dE0 W4^T) -- the 64x128x64 product that dominated the one-thread-per-edge version -- with W4
-//      staged in LDS once per workgroup (the same element for every edge: broadcast reads);
-//   1b (one thread per edge): d2, d1 through the two small layers;
-//   2  (all threads): outer-product sums of the chunk into the thread's parameters.
-// Fixed chunk -> workgroup assignment and fixed summation order: deterministic.
+// Persistent workgroups over chunks of 64 edges; one partial row of the NP parameter gradients per workgroup, summed
+// over ALL of its chunks in registers (fixed chunk -> workgroup assignment, fixed summation order: deterministic).
+// Round 4: the two products that are 95 % of the arithmetic -- the last layer's data gradient
+// d3 = relu'(a3) . (dE0 W4^T) and weight gradient dW4 = a3^T dE0, and (from d = 64 on, where the layer before is wide
+// enough for 16-wide tiles) d2 = relu'(a2) . (d3 W3^T) and dW3 = a2^T d3 -- run on the fp32 matrix instruction
+// (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains, the edges of a chunk are the contraction of the weight gradients);
+// the scalar loops keep the narrow first layers and the bias sums.  d = 128, 636 800 edges: 8.4 ms -> see DESIGN.
+// Per chunk:
+//   A  (256 threads, four per edge): the forward chain of the edge -> a1, a2, a3 in LDS;
+//   B  (wavefront w = edge tile w): d3 by MFMA over the D columns of dE0, masked by a3 > 0;
+//   B' (d >= 64): d2 by MFMA over d3 (else one thread per edge), then d1 (four threads per edge);
+//   C  dW4 (+ dW3) tiles accumulated by MFMA over the chunk's 64 edges, the other parameters by scalar sums.
 template <int D>
 __global__ __launch_bounds__(256) void einit_bwd_kernel(const float2* __restrict__ WC, const float* __restrict__ wb,
                                                         const float* __restrict__ dE0, float* __restrict__ P, int M,
                                                         int n_chunks) {
     constexpr int H1 = D / 8, H2 = D / 4, H3 = D / 2;
     constexpr int NP = 2 * H1 + H1 + H1 * H2 + H2 + H2 * H3 + H3 + H3 * D + D;
+    constexpr int O_W3 = 2 * H1 + H1 + H1 * H2 + H2, O_B3 = O_W3 + H2 * H3, O_W4 = O_B3 + H3, O_B4 = O_W4 + H3 * D;
     constexpr int NPT = (NP + 255) / 256;
-    constexpr int E = 64, KQ = H3 / 4;
+    constexpr int E = 64;
+    constexpr bool M3 = (H2 % 16) == 0;                       // level 3 on the matrix instruction as well
+    constexpr int T4 = (H3 / 16) * (D / 16);                  // 16x16 tiles of dW4
+    constexpr int TPW4 = T4 >= 4 ? T4 / 4 : 1;                // ... per wavefront
+    constexpr int T3 = M3 ? (H2 / 16) * (H3 / 16) : 0;
+    constexpr int TPW3 = T3 >= 4 ? T3 / 4 : 1;
     const float* W1 = wb;
     const float* b1 = W1 + 2 * H1;
     const float* W2 = b1 + H1;
@@ -96,113 +106,237 @@ __global__ __launch_bounds__(256) void einit_bwd_kernel(const float2* __restrict
     __shared__ float s_in[E][2 + 1];
     __shared__ float s_a1[E][H1 + 1], s_a2[E][H2 + 1], s_a3[E][H3 + 1];
     __shared__ float s_d1[E][H1 + 1], s_d2[E][H2 + 1], s_d3[E][H3 + 1], s_d4[E][D + 1];
-    __shared__ __attribute__((aligned(16))) float s_w4[H3 * D];
-    const int t = threadIdx.x;
-    for (int i = t; i < H3 * D / 4; i += blockDim.x) reinterpret_cast<float4*>(s_w4)[i] = reinterpret_cast<const float4*>(W4)[i];
+    __shared__ float s_w4[H3][D + 1];                         // (padded: the MFMA operand reads walk the rows)
+    __shared__ float s_w3[H2][H3 + 1];
+    __shared__ float s_w12[2 * H1 + H1 + H1 * H2 + H2 + H3];  // W1, b1, W2, b2 as in wb, then b3
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 15, lk = lane >> 4;
+    for (int i = t; i < H3 * D; i += blockDim.x) s_w4[i / D][i % D] = W4[i];
+    for (int i = t; i < H2 * H3; i += blockDim.x) s_w3[i / H3][i % H3] = W3[i];
+    for (int i = t; i < 2 * H1 + H1 + H1 * H2 + H2; i += blockDim.x) s_w12[i] = wb[i];
+    for (int i = t; i < H3; i += blockDim.x) s_w12[2 * H1 + H1 + H1 * H2 + H2 + i] = b3[i];
+    const float* l_W1 = s_w12;
+    const float* l_b1 = l_W1 + 2 * H1;
+    const float* l_W2 = l_b1 + H1;
+    const float* l_b2 = l_W2 + H1 * H2;
+    const float* l_b3 = l_b2 + H2;
     float acc[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) acc[i] = 0.f;
+    f32x4 accW4[TPW4], accW3[TPW3];
+#pragma unroll
+    for (int i = 0; i < TPW4; ++i) accW4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TPW3; ++i) accW3[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the dE0 tile of the NEXT chunk is fetched into registers while the current one is worked on (one workgroup of four
+    // wavefronts per CU at d = 128: nothing else would hide the HBM round trip)
+    constexpr int NPRE = E * D / 256;
+    float pre[NPRE];
+    auto fetch = [&](int chunk) {
+        const int e0n = chunk * E;
+#pragma unroll
+        for (int r = 0; r < NPRE; ++r) {
+            const int i = t + r * 256, le = i / D, j = i % D;
+            pre[r] = (chunk < n_chunks && e0n + le < M) ? dE0[(size_t)(e0n + le) * D + j] : 0.f;   // rows past M are zero
+        }
+    };
+    fetch(blockIdx.x);
     for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int e0 = chunk * E;
-        __syncthreads();   // (the previous chunk's phase 2 has read the tiles; first pass: s_w4 is complete)
-        for (int i = t; i < E * D; i += blockDim.x) {   // dE0 tile -> LDS (coalesced)
-            const int le = i / D, j = i % D;
-            s_d4[le][j] = (e0 + le < M) ? dE0[(size_t)(e0 + le) * D + j] : 0.f;
+        __syncthreads();   // (the previous chunk's phase C has read the tiles; first pass: the staged weights are complete)
+#pragma unroll
+        for (int r = 0; r < NPRE; ++r) {
+            const int i = t + r * 256;
+            s_d4[i / D][i % D] = pre[r];
         }
-        __syncthreads();
-        {   // 1a
+        fetch(chunk + (int)gridDim.x);
+        {   // A: a1 and a quarter of a2 per thread (four threads per edge; the small weights come from LDS)
             const int le = t >> 2, q = t & 3;
             const int e = e0 + le;
-            const bool ok = e < M;
-            const float2 wc = ok ? WC[e] : make_float2(0.f, 0.f);
-            float a1[H1], a2[H2];
+            const float2 wc = e < M ? WC[e] : make_float2(0.f, 0.f);
+            float a1[H1];
 #pragma unroll
-            for (int j = 0; j < H1; ++j) a1[j] = fmaxf(fmaf(wc.y, W1[H1 + j], fmaf(wc.x, W1[j], 0.f)) + b1[j], 0.f);
+            for (int j = 0; j < H1; ++j) a1[j] = fmaxf(fmaf(wc.y, l_W1[H1 + j], fmaf(wc.x, l_W1[j], 0.f)) + l_b1[j], 0.f);
 #pragma unroll
-            for (int j = 0; j < H2; ++j) {
-                float s = 0.f;
+            for (int jj = 0; jj < H2 / 4; ++jj) {
+                const int j = q * (H2 / 4) + jj;
+                float sum = 0.f;
 #pragma unroll
-                for (int k = 0; k < H1; ++k) s = fmaf(a1[k], W2[k * H2 + j], s);
-                a2[j] = fmaxf(s + b2[j], 0.f);
-            }
-            // this thread's quarter of the third layer: a3[k] and d3[k] = relu'(a3[k]) * (W4[k,:] . dE0[e,:])
-            for (int kk = 0; kk < KQ; ++kk) {
-                const int k = q * KQ + kk;
-                float a3k = b3[k];
-#pragma unroll
-                for (int j = 0; j < H2; ++j) a3k = fmaf(a2[j], W3[j * H3 + k], a3k);
-                a3k = fmaxf(a3k, 0.f);
-                float s = 0.f;
-                _Pragma("unroll 8") for (int j = 0; j < D; ++j) s = fmaf(s_w4[k * D + j], s_d4[le][j], s);
-                s_a3[le][k] = a3k;
-                s_d3[le][k] = (ok && a3k > 0.f) ? s : 0.f;
+                for (int k = 0; k < H1; ++k) sum = fmaf(a1[k], l_W2[k * H2 + j], sum);
+                s_a2[le][j] = fmaxf(sum + l_b2[j], 0.f);
             }
             if (q == 0) {
                 s_in[le][0] = wc.x, s_in[le][1] = wc.y;
 #pragma unroll
                 for (int k = 0; k < H1; ++k) s_a1[le][k] = a1[k];
-#pragma unroll
-                for (int k = 0; k < H2; ++k) s_a2[le][k] = a2[k];
             }
         }
         __syncthreads();
-        if (t < E) {   // 1b
-            const bool ok = e0 + t < M;
-            float d2[H2];
+        {   // A': a3 = relu(a2 W3 + b3) by MFMA, wavefront w = edge tile w
+            f32x4 c[H3 / 16];
+#pragma unroll
+            for (int nt = 0; nt < H3 / 16; ++nt) {
+                const float b = l_b3[16 * nt + lm];
+                c[nt] = f32x4{b, b, b, b};
+            }
+#pragma unroll
+            for (int ks = 0; ks < H2 / 4; ++ks) {
+                const float a = s_a2[16 * wave + lm][4 * ks + lk];
+#pragma unroll
+                for (int nt = 0; nt < H3 / 16; ++nt) c[nt] = MFMA16(a, s_w3[4 * ks + lk][16 * nt + lm], c[nt]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < H3 / 16; ++nt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_a3[16 * wave + 4 * lk + i][16 * nt + lm] = fmaxf(c[nt][i], 0.f);
+            }
+        }
+        __syncthreads();
+        {   // B: d3[e][k3] = (a3 > 0) * sum_j dE0[e][j] W4[k3][j]   (rows past M: dE0 is zero, so is d3)
+            f32x4 c[H3 / 16];
+#pragma unroll
+            for (int nt = 0; nt < H3 / 16; ++nt) c[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int js = 0; js < D / 4; ++js) {
+                const float a = s_d4[16 * wave + lm][4 * js + lk];
+#pragma unroll
+                for (int nt = 0; nt < H3 / 16; ++nt) c[nt] = MFMA16(a, s_w4[16 * nt + lm][4 * js + lk], c[nt]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < H3 / 16; ++nt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int le = 16 * wave + 4 * lk + i, k3 = 16 * nt + lm;
+                    s_d3[le][k3] = s_a3[le][k3] > 0.f ? c[nt][i] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if constexpr (M3) {   // B': d2[e][k2] = (a2 > 0) * sum_j d3[e][j] W3[k2][j]
+            f32x4 c[H2 / 16];
+#pragma unroll
+            for (int nt = 0; nt < H2 / 16; ++nt) c[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int js = 0; js < H3 / 4; ++js) {
+                const float a = s_d3[16 * wave + lm][4 * js + lk];
+#pragma unroll
+                for (int nt = 0; nt < H2 / 16; ++nt) c[nt] = MFMA16(a, s_w3[16 * nt + lm][4 * js + lk], c[nt]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < H2 / 16; ++nt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int le = 16 * wave + 4 * lk + i, k2 = 16 * nt + lm;
+                    s_d2[le][k2] = s_a2[le][k2] > 0.f ? c[nt][i] : 0.f;
+                }
+            }
+        } else if (t < E) {
 #pragma unroll
             for (int k = 0; k < H2; ++k) {
-                float s = 0.f;
-                _Pragma("unroll 8") for (int j = 0; j < H3; ++j) s = fmaf(W3[k * H3 + j], s_d3[t][j], s);
-                d2[k] = (ok && s_a2[t][k] > 0.f) ? s : 0.f;
-                s_d2[t][k] = d2[k];
-            }
-#pragma unroll
-            for (int k = 0; k < H1; ++k) {
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < H2; ++j) s = fmaf(W2[k * H2 + j], d2[j], s);
-                s_d1[t][k] = (ok && s_a1[t][k] > 0.f) ? s : 0.f;
+                float sum = 0.f;
+                _Pragma("unroll 8") for (int j = 0; j < H3; ++j) sum = fmaf(s_w3[k][j], s_d3[t][j], sum);
+                s_d2[t][k] = s_a2[t][k] > 0.f ? sum : 0.f;
             }
         }
         __syncthreads();
+        {   // d1, four threads per edge
+            const int le = t >> 2, q = t & 3;
+            for (int kk = 0; kk < (H1 + 3) / 4; ++kk) {
+                const int k = q * ((H1 + 3) / 4) + kk;
+                if (k < H1) {
+                    float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < NPT; ++i) {   // 2
+                    for (int j = 0; j < H2; ++j) sum = fmaf(l_W2[k * H2 + j], s_d2[le][j], sum);
+                    s_d1[le][k] = s_a1[le][k] > 0.f ? sum : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        // C: weight-gradient tiles over the chunk's 64 edges: dW[m][n] += sum_e left[e][m] right[e][n]
+        {
+            const int t0 = wave * TPW4;
+            if (t0 < T4) {
+                const int mt = t0 / (D / 16);           // (a wavefront's tiles share their row of tiles)
+#pragma unroll 4
+                for (int es = 0; es < E / 4; ++es) {
+                    const float a = s_a3[4 * es + lk][16 * mt + lm];
+#pragma unroll
+                    for (int i = 0; i < TPW4; ++i)
+                        accW4[i] = MFMA16(a, s_d4[4 * es + lk][16 * ((t0 + i) % (D / 16)) + lm], accW4[i]);
+                }
+            }
+        }
+        if constexpr (M3) {
+            const int t0 = wave * TPW3;
+            if (t0 < T3) {
+                const int mt = t0 / (H3 / 16);
+#pragma unroll 4
+                for (int es = 0; es < E / 4; ++es) {
+                    const float a = s_a2[4 * es + lk][16 * mt + lm];
+#pragma unroll
+                    for (int i = 0; i < TPW3; ++i)
+                        accW3[i] = MFMA16(a, s_d3[4 * es + lk][16 * ((t0 + i) % (H3 / 16)) + lm], accW3[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {   // the other parameters: scalar sums over the chunk
             const int p = t + i * 256;
             if (p >= NP) break;
+            if ((p >= O_W4 && p < O_B4) || (M3 && p >= O_W3 && p < O_B3)) continue;   // (on the matrix instruction above)
             int q = p;
-            float s = 0.f;
+            float sum = 0.f;
             if (q < 2 * H1) {  // W1[k][j]
                 const int k = q / H1, j = q % H1;
-                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s = fmaf(s_in[e][k], s_d1[e][j], s);
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) sum = fmaf(s_in[e][k], s_d1[e][j], sum);
             } else if ((q -= 2 * H1) < H1) {
-                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s += s_d1[e][q];
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) sum += s_d1[e][q];
             } else if ((q -= H1) < H1 * H2) {
                 const int k = q / H2, j = q % H2;
-                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s = fmaf(s_a1[e][k], s_d2[e][j], s);
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) sum = fmaf(s_a1[e][k], s_d2[e][j], sum);
             } else if ((q -= H1 * H2) < H2) {
-                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s += s_d2[e][q];
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) sum += s_d2[e][q];
             } else if ((q -= H2) < H2 * H3) {
                 const int k = q / H3, j = q % H3;
-                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s = fmaf(s_a2[e][k], s_d3[e][j], s);
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) sum = fmaf(s_a2[e][k], s_d3[e][j], sum);
             } else if ((q -= H2 * H3) < H3) {
-                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s += s_d3[e][q];
-            } else if ((q -= H3) < H3 * D) {
-                const int k = q / D, j = q % D;
-                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s = fmaf(s_a3[e][k], s_d4[e][j], s);
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) sum += s_d3[e][q];
             } else {
-                q -= H3 * D;
-                _Pragma("unroll 4") for (int e = 0; e < E; ++e) s += s_d4[e][q];
+                q -= H3 + H3 * D;
+                _Pragma("unroll 4") for (int e = 0; e < E; ++e) sum += s_d4[e][q];
             }
-            acc[i] += s;
+            acc[i] += sum;
         }
     }
     float* Pb = P + (size_t)blockIdx.x * NP;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const int p = t + i * 256;
-        if (p < NP) Pb[p] = acc[i];
+        if (p < NP && !((p >= O_W4 && p < O_B4) || (M3 && p >= O_W3 && p < O_B3))) Pb[p] = acc[i];
+    }
+    {   // the MFMA tiles: lane holds rows 4 lk + i, column lm of its 16x16 tile
+        const int t0 = wave * TPW4;
+        if (t0 < T4) {
+#pragma unroll
+            for (int i = 0; i < TPW4; ++i) {
+                const int mt = (t0 + i) / (D / 16), nt = (t0 + i) % (D / 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Pb[O_W4 + (16 * mt + 4 * lk + r) * D + 16 * nt + lm] = accW4[i][r];
+            }
+        }
+    }
+    if constexpr (M3) {
+        const int t0 = wave * TPW3;
+        if (t0 < T3) {
+#pragma unroll
+            for (int i = 0; i < TPW3; ++i) {
+                const int mt = (t0 + i) / (H3 / 16), nt = (t0 + i) % (H3 / 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Pb[O_W3 + (16 * mt + 4 * lk + r) * H3 + 16 * nt + lm] = accW3[i][r];
+            }
+        }
     }
 }
+
 
 // ------------------------------------------------------------- optimiser (model.py:160-167)
 // g <- g + l2 * theta ; partial sums of g^2 (fixed order per workgroup).
