@@ -2,22 +2,22 @@
 // edge-embedding initialisation, vertex-embedding tiling, the vote head's final Dense(1),
 // per-problem segment mean, and sigmoid / cross-entropy / confusion counts.
 #include "common.h"
+#include "mfma_tile.h"
 
 namespace tspgnn {
 
 // ------------------------------------------------------------- E0 = E_init_MLP([W, C])
-// 256 edges per workgroup.  Phase 1: one thread per edge runs the three narrow layers (2 -> D/8 -> D/4 -> D/2, weights read
-// with wave-uniform indices = scalar loads) and parks its D/2 activations in LDS.  Phase 2 is the wide layer (D/2 -> D,
-// three quarters of the flops and ALL of the output bytes) with D/4 lanes per row: lane j keeps columns 4j..4j+3 of W4 in
-// registers (LDS when D > 64), reads the row's activations as LDS broadcasts, and the lanes of a row store 4D contiguous
-// bytes -- full-line stores (the one-thread-per-row version wrote 16 B pieces of 64 different rows per instruction:
-// 39 us for a 25.6 MB array at C2).
+// 256 edges per workgroup.  Phase 1: one thread per edge runs the two narrow layers (2 -> D/8 -> D/4, weights read with
+// wave-uniform indices = scalar loads) and parks its D/4 activations in LDS.  Phase 2 (round 4): the two wide layers
+// (D/4 -> D/2 -> D: 97 % of the flops and ALL of the output bytes) on the fp32 matrix instruction
+// (v_mfma_f32_16x16x4_f32, exact fp32 FMA chains): a wavefront takes 16 edges at a time, forms a3 = relu(a2 W3 + b3) in the
+// accumulator layout, turns it into the next product's operand layout through its own 4 KB of LDS, and stores the
+// 16 x D tile of a4 = a3 W4 + b4 as 64-byte runs (four rows per store instruction).  (Before: D/4 lanes per row with W4
+// in registers / LDS and scalar FMAs: 17 us at C2 for a 25.6 MB array, 410 us at the C5 shard.)
 template <int D>
 __global__ __launch_bounds__(256) void einit_fwd_kernel(const float2* __restrict__ WC, const float* __restrict__ wb,
                                                         float* __restrict__ E0, int M) {
     constexpr int H1 = D / 8, H2 = D / 4, H3 = D / 2;
-    constexpr int LPR = D / 4, RPP = 256 / LPR;  // lanes per row, rows per pass
-    constexpr bool W4_LDS = D > 64;
     const float* W1 = wb;
     const float* b1 = W1 + 2 * H1;
     const float* W2 = b1 + H1;
@@ -26,15 +26,18 @@ __global__ __launch_bounds__(256) void einit_fwd_kernel(const float2* __restrict
     const float* b3 = W3 + H2 * H3;
     const float* W4 = b3 + H3;
     const float* b4 = W4 + H3 * D;
-    __shared__ __attribute__((aligned(16))) float a3s[256][H3 + 4];  // (+4: rows 16 B aligned, bank-staggered)
-    __shared__ __attribute__((aligned(16))) float w4s[W4_LDS ? H3 * D : 4];
-    const int tid = threadIdx.x;
+    __shared__ float s_a2[256][H2 + 1];
+    __shared__ float s_w3[H2][H3 + 1], s_w4[H3][D + 1];
+    __shared__ float s_a3[4][16][H3 + 1];   // one tile per wavefront
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lk = lane >> 4;
     const int e0 = blockIdx.x * 256;
+    for (int i = tid; i < H2 * H3; i += 256) s_w3[i / H3][i % H3] = W3[i];
+    for (int i = tid; i < H3 * D; i += 256) s_w4[i / D][i % D] = W4[i];
     {
         const int e = min(e0 + tid, M - 1);
         const float2 wc = WC[e];
         const float w = wc.x, c = wc.y;
-        float a1[H1], a2[H2];
+        float a1[H1];
 #pragma unroll
         for (int j = 0; j < H1; ++j) a1[j] = fmaxf(fmaf(c, W1[H1 + j], fmaf(w, W1[j], 0.f)) + b1[j], 0.f);
 #pragma unroll
@@ -42,45 +45,50 @@ __global__ __launch_bounds__(256) void einit_fwd_kernel(const float2* __restrict
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < H1; ++k) s = fmaf(a1[k], W2[k * H2 + j], s);
-            a2[j] = fmaxf(s + b2[j], 0.f);
+            s_a2[tid][j] = fmaxf(s + b2[j], 0.f);
         }
-#pragma unroll
-        for (int j = 0; j < H3; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < H2; ++k) s = fmaf(a2[k], W3[k * H3 + j], s);
-            a3s[tid][j] = fmaxf(s + b3[j], 0.f);
-        }
-    }
-    if constexpr (W4_LDS) {
-        for (int i = tid; i < H3 * D / 4; i += 256) reinterpret_cast<float4*>(w4s)[i] = reinterpret_cast<const float4*>(W4)[i];
     }
     __syncthreads();
-    const int j = tid % LPR, sub = tid / LPR;
-    const float4 bv = *reinterpret_cast<const float4*>(b4 + j * 4);
-    float4 wreg[W4_LDS ? 1 : H3];
-    if constexpr (!W4_LDS) {
+    float bias3[H3 / 16], bias4[D / 16];
 #pragma unroll
-        for (int k = 0; k < H3; ++k) wreg[k] = *reinterpret_cast<const float4*>(W4 + k * D + j * 4);
-    }
-    for (int r = sub; r < 256; r += RPP) {
-        if (e0 + r >= M) break;
-        float4 s = bv;
+    for (int nt = 0; nt < H3 / 16; ++nt) bias3[nt] = b3[16 * nt + lm];
 #pragma unroll
-        for (int k4 = 0; k4 < H3 / 4; ++k4) {
-            const float4 a = *reinterpret_cast<const float4*>(&a3s[r][k4 * 4]);
-            const float av[4] = {a.x, a.y, a.z, a.w};
+    for (int nt = 0; nt < D / 16; ++nt) bias4[nt] = b4[16 * nt + lm];
+    for (int et = 0; et < 4; ++et) {
+        const int r0 = 64 * wave + 16 * et;            // first edge (within the workgroup) of this 16-edge tile
+        if (e0 + r0 >= M) break;                       // wave-uniform
+        f32x4 c3[H3 / 16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = k4 * 4 + i;
-                const float4 wv = W4_LDS ? *reinterpret_cast<const float4*>(&w4s[k * D + j * 4]) : wreg[W4_LDS ? 0 : k];
-                s.x = fmaf(av[i], wv.x, s.x);
-                s.y = fmaf(av[i], wv.y, s.y);
-                s.z = fmaf(av[i], wv.z, s.z);
-                s.w = fmaf(av[i], wv.w, s.w);
+        for (int nt = 0; nt < H3 / 16; ++nt) c3[nt] = f32x4{bias3[nt], bias3[nt], bias3[nt], bias3[nt]};
+#pragma unroll
+        for (int ks = 0; ks < H2 / 4; ++ks) {
+            const float a = s_a2[r0 + lm][4 * ks + lk];
+#pragma unroll
+            for (int nt = 0; nt < H3 / 16; ++nt) c3[nt] = MFMA16(a, s_w3[4 * ks + lk][16 * nt + lm], c3[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < H3 / 16; ++nt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_a3[wave][4 * lk + i][16 * nt + lm] = fmaxf(c3[nt][i], 0.f);
+        }
+        // (the tile is private to the wavefront and LDS operations of one wavefront complete in order: no barrier)
+        f32x4 c4[D / 16];
+#pragma unroll
+        for (int nt = 0; nt < D / 16; ++nt) c4[nt] = f32x4{bias4[nt], bias4[nt], bias4[nt], bias4[nt]};
+#pragma unroll 4
+        for (int ks = 0; ks < H3 / 4; ++ks) {
+            const float a = s_a3[wave][lm][4 * ks + lk];
+#pragma unroll
+            for (int nt = 0; nt < D / 16; ++nt) c4[nt] = MFMA16(a, s_w4[4 * ks + lk][16 * nt + lm], c4[nt]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = e0 + r0 + 4 * lk + i;
+            if (e < M) {
+#pragma unroll
+                for (int nt = 0; nt < D / 16; ++nt) E0[(size_t)e * D + 16 * nt + lm] = c4[nt][i];
             }
         }
-        *reinterpret_cast<float4*>(E0 + (size_t)(e0 + r) * D + j * 4) = s;
     }
 }
 
