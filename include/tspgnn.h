@@ -229,6 +229,11 @@ int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_task
 float tspgnn_h2_weight_scale(void);   /* 2^TSPGNN_H2_WEIGHT_SCALE_LOG2 */
 int tspgnn_pack_weights_h2(const float* W, void* P, int krows, int ncols, unsigned* absmax_bits, void* stream);
 int tspgnn_mlp_fwd_multi_h2(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream);
+/* One task followed by a Dense(1) head on the rows in hand (the vote MLP of model.py:107-115,128: three relu layers and
+ * a linear d -> 1): y[r] = <out row r, head_w[d]> + head_b[0] in fp32, where `out` is what tspgnn_mlp_fwd_multi_h2
+ * would have written to task->Y.  task->Y may be NULL (the rows are then never written); task->proj_w must be NULL. */
+int tspgnn_mlp_head_fwd_h2(const tspgnn_mlp_task* task, const float* head_w, const float* head_b, float* y, int d,
+                           void* stream);
 int tspgnn_lnlstm_fwd_multi_h2(const tspgnn_lstm_task* tasks, int n_tasks, int d, void* stream);
 int tspgnn_lnlstm_mlp_fwd_multi_h2(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream);
 

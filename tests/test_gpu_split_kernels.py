@@ -5,6 +5,8 @@ inference forward) and "x3" = three bf16 pieces on the bf16 matrix cores (csrc/d
 The tolerance is the same as for the fp32 kernels: both splits keep every term down to 2^-24 relative.  The f16x2
 conventions the tests honour: weights packed as 2^s W, Dense biases stored as 2^s b, projected messages (proj_out /
 Zx) carrying the factor 2^s."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -142,6 +144,49 @@ def test_mlp_fwd_split(cuda_device, arith, d, n_layers, mask, rows):
         if l < n_layers - 1:
             assert rel_err(acts[l].cpu().numpy(), x) < 2e-6
     assert rel_err(Y.cpu().numpy(), x) < 2e-6
+
+
+@pytest.mark.parametrize("d", [32, 64])
+@pytest.mark.parametrize("rows", [1, 16, 333, 70000])
+@pytest.mark.parametrize("keep_rows", [False, True])
+def test_mlp_head_h2(cuda_device, d, rows, keep_rows):
+    """The vote head in one launch (model.py:107-115,128: three relu layers, then Dense(1) on the rows in hand)."""
+    rng = np.random.RandomState(rows + d + 5)
+    X = rng.randn(rows, d).astype(np.float32)
+    layers = [((rng.randn(d, d) / np.sqrt(d)).astype(np.float32), (0.1 * rng.randn(d)).astype(np.float32))
+              for _ in range(3)]
+    hw = (rng.randn(d, 1) / np.sqrt(d)).astype(np.float32)
+    hb = np.array([0.3], np.float32)
+    wb = mlp_blocks("h2", layers, cuda_device)
+    Y = torch.full((rows, d), 7.0, dtype=torch.float32, device=cuda_device)
+    y = torch.full((rows,), 7.0, dtype=torch.float32, device=cuda_device)
+    flag = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    task = _lib.MlpTask(_lib.ptr(dev(X, cuda_device)), _lib.ptr(wb), _lib.ptr(Y) if keep_rows else None, None, 0, rows, 3,
+                        0b111, None, None, _lib.ptr(flag))
+    _lib.call("tspgnn_mlp_head_fwd_h2", ctypes.cast(ctypes.pointer(task), ctypes.c_void_p), _lib.ptr(dev(hw, cuda_device)),
+              _lib.ptr(dev(hb, cuda_device)), _lib.ptr(y), d, None)
+    torch.cuda.synchronize()
+    x = X.astype(np.float64)
+    for W, b in layers:
+        x = NO.dense(x, W.astype(np.float64), b.astype(np.float64), True)
+    want = NO.dense(x, hw.astype(np.float64), hb.astype(np.float64), False)[:, 0]
+    assert rel_err(y.cpu().numpy(), want) < 2e-6
+    if keep_rows:
+        assert rel_err(Y.cpu().numpy(), x) < 2e-6
+    else:
+        assert float(Y.min()) == 7.0 and float(Y.max()) == 7.0
+    assert int(flag.item()) == 0
+
+
+def test_mlp_head_h2_rejects_a_projection_and_null_outputs(cuda_device):
+    t = torch.zeros((16, 64), dtype=torch.float32, device=cuda_device)
+    wb = torch.zeros(3 * (2 * 64 * 64 * 2 + 64 * 4), dtype=torch.uint8, device=cuda_device)
+    bad = _lib.MlpTask(_lib.ptr(t), _lib.ptr(wb), None, None, 0, 16, 3, 7, _lib.ptr(wb), _lib.ptr(t))
+    ok = _lib.MlpTask(_lib.ptr(t), _lib.ptr(wb), None, None, 0, 16, 3, 7, None, None)
+    for task, y in ((bad, t), (ok, None)):
+        with pytest.raises(_lib.TspgnnError):
+            _lib.call("tspgnn_mlp_head_fwd_h2", ctypes.cast(ctypes.pointer(task), ctypes.c_void_p), _lib.ptr(t), _lib.ptr(t),
+                      _lib.ptr(y), 64, None)
 
 
 @pytest.mark.parametrize("d", [32, 64])

@@ -136,6 +136,11 @@ struct MlpTaskTableH2 {
     tspgnn_mlp_task task[kMaxTasksH2];
     int blk_end[kMaxTasksH2];
     int n;
+    // tspgnn_mlp_head_fwd_h2 (one task): y[row] = <last layer's output row, head_w> + head_b[0], taken while the row is
+    // still in registers; the task's Y may then be NULL (nothing is written for it)
+    const float* head_w;
+    const float* head_b;
+    float* head_y;
 };
 
 template <int D>
@@ -192,7 +197,18 @@ __global__ __launch_bounds__(1024) void mlp_fwd_h2_kernel(const MlpTaskTableH2 t
                 for (int t = 0; t < NT; ++t) st4(dst + t * 16, a[t]);
             }
         }
-        if (valid) {
+        if (tt.head_y != nullptr) {   // Dense(1) on the rows in hand: this lane holds columns t*16 + g*4 .. +3
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 wv = ld4(tt.head_w + g * 4 + t * 16);
+                s = fmaf(a[t][3], wv[3], fmaf(a[t][2], wv[2], fmaf(a[t][1], wv[1], fmaf(a[t][0], wv[0], s))));
+            }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (valid && g == 0) tt.head_y[row] = s + tt.head_b[0];
+        }
+        if (valid && Y != nullptr) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) st4(Y + rbase + t * 16, a[t]);
         }
@@ -617,8 +633,12 @@ static int split_blocks_h2(const long long* cost, int n, int grid, int* blk_end)
 }
 
 template <int D>
-static int launch_mlp_h2(const tspgnn_mlp_task* tasks, int n, hipStream_t st) {
+static int launch_mlp_h2(const tspgnn_mlp_task* tasks, int n, hipStream_t st, const float* head_w = nullptr,
+                         const float* head_b = nullptr, float* head_y = nullptr) {
     MlpTaskTableH2 tt;
+    tt.head_w = head_w;
+    tt.head_b = head_b;
+    tt.head_y = head_y;
     long long cost[kMaxTasksH2];
     long long tiles_all = 0;
     for (int k = 0; k < n; ++k) {
@@ -809,6 +829,20 @@ extern "C" int tspgnn_mlp_fwd_multi_h2(const tspgnn_mlp_task* tasks, int n_tasks
     }
     if (n == 0) return TSPGNN_OK;
     return d == 32 ? launch_mlp_h2<32>(live, n, as_stream(stream)) : launch_mlp_h2<64>(live, n, as_stream(stream));
+}
+
+extern "C" int tspgnn_mlp_head_fwd_h2(const tspgnn_mlp_task* task, const float* head_w, const float* head_b, float* y,
+                                      int d, void* stream) {
+    TSPGNN_REQUIRE(task, "mlp_head_fwd_h2: null task");
+    TSPGNN_REQUIRE(d == 32 || d == 64, "mlp_head_fwd_h2: d=%d must be 32 or 64", d);
+    const tspgnn_mlp_task& t = *task;
+    TSPGNN_REQUIRE(t.rows >= 0, "mlp_head_fwd_h2: rows=%d", t.rows);
+    TSPGNN_REQUIRE(t.n_layers >= 1 && t.n_layers <= 4, "mlp_head_fwd_h2: n_layers=%d must be in 1..4", t.n_layers);
+    TSPGNN_REQUIRE(!t.proj_w, "mlp_head_fwd_h2: a head task has no projection");
+    if (t.rows == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(t.X && t.wb && head_w && head_b && y, "mlp_head_fwd_h2: null pointer");
+    return d == 32 ? launch_mlp_h2<32>(task, 1, as_stream(stream), head_w, head_b, y)
+                   : launch_mlp_h2<64>(task, 1, as_stream(stream), head_w, head_b, y);
 }
 
 static int cell_mlp_h2(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream, const char* what) {

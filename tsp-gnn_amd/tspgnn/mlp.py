@@ -10,6 +10,8 @@ NotImplementedError rather than falling back to a generic slow path):
   * 2 -> d/8 -> d/4 -> d/2 -> d with relu x3 + linear     (E_init_MLP, model.py:33-43)
         -> tspgnn_einit_fwd_f32
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -311,15 +313,22 @@ class Mlp(object):
         if kind != "square" or d not in (32, 64) or len(self._chunks()) != 1 or x.dtype != torch.float32 \
                 or not x.is_contiguous() or x.shape[1] != self.input_size:
             return self(x)
+        last = self.layer_names[-1]
+        flag = self.store.h2_flag_ptr() if arith == "h2" else None
+        wb = _lib.ptr(self.wb_packed_split(arith, 0, n_sq - 1, d))
+        if head and arith == "h2":     # Dense(1) taken in the same launch, the hidden rows never written
+            y = torch.empty((x.shape[0], 1), dtype=torch.float32, device=x.device)
+            task = _lib.MlpTask(_lib.ptr(x), wb, None, None, 0, x.shape[0], n_sq, self.relu_mask(0, n_sq), None, None, flag)
+            _lib.call("tspgnn_mlp_head_fwd_h2", ctypes.cast(ctypes.pointer(task), ctypes.c_void_p), _lib.ptr(self.store.view(last + "/kernel")),
+                      _lib.ptr(self.store.view(last + "/bias")), _lib.ptr(y), d, _lib.current_stream())
+            return y
         out = torch.empty((x.shape[0], d), dtype=torch.float32, device=x.device)
-        task = _lib.MlpTask(_lib.ptr(x), _lib.ptr(self.wb_packed_split(arith, 0, n_sq - 1, d)), _lib.ptr(out), None, 0,
-                            x.shape[0], n_sq, self.relu_mask(0, n_sq), None, None,
-                            self.store.h2_flag_ptr() if arith == "h2" else None)
+        task = _lib.MlpTask(_lib.ptr(x), wb, _lib.ptr(out), None, 0, x.shape[0], n_sq, self.relu_mask(0, n_sq), None, None,
+                            flag)
         _lib.call_multi("tspgnn_mlp_fwd_multi_" + arith, [task], d)
         if not head:
             return out
         y = torch.empty((x.shape[0], 1), dtype=torch.float32, device=x.device)
-        last = self.layer_names[-1]
         _lib.call("tspgnn_rowdot_f32", _lib.ptr(out), _lib.ptr(self.store.view(last + "/kernel")),
                   _lib.ptr(self.store.view(last + "/bias")), _lib.ptr(y), x.shape[0], d, _lib.current_stream())
         return y
