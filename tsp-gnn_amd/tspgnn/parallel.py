@@ -80,8 +80,10 @@ class BatchPrefetcher(object):
 
     def _work(self):
         stream = torch.cuda.Stream(device=self.sess.device) if self.sess.device.type == "cuda" else None
+        seq = None
         try:
             while True:
+                seq = None
                 with self._lock:
                     # at most ``depth`` batches taken but not yet handed out; the iterator itself is advanced by one
                     # thread at a time (generators are not re-entrant)
@@ -110,7 +112,11 @@ class BatchPrefetcher(object):
                     self._lock.notify_all()
         except BaseException as exc:   # handed to the consumer: a dead worker must not look like an empty dataset
             with self._lock:
-                self._error = exc
+                # ... IN ORDER: the batches ahead of the failed one (other workers may still be packing them) are handed
+                # out first, so what the consumer saw before the exception does not depend on the workers' timing
+                at = self._next_in if seq is None else seq
+                if self._error is None or at < self._error[0]:
+                    self._error = (at, exc)
                 self._lock.notify_all()
 
     def __iter__(self):
@@ -124,8 +130,8 @@ class BatchPrefetcher(object):
                     self._next_out += 1
                     self._lock.notify_all()
                     break
-                if self._error is not None:
-                    err, self._error = self._error, None
+                if self._error is not None and self._error[0] <= self._next_out:
+                    err, self._error = self._error[1], None
                     self._exhausted_at = self._next_out      # (the remaining workers stop)
                     self._lock.notify_all()
                     raise RuntimeError("BatchPrefetcher worker failed") from err
