@@ -218,7 +218,7 @@ class Session(object):
             return t.pin_memory().to(self.device, non_blocking=True)
         return t.to(self.device)
 
-    def _adjacency(self, EV):
+    def _adjacency(self, EV, remember=True):
         """Device adjacency of a feed.  A ``DeviceAdjacency`` is used as is; a ``SparseEV`` is uploaded (CSR built)
         and remembered under a fingerprint of its CONTENT -- shape + CRC of the endpoint array, ~0.3 ms at C2 --
         so a caller that re-feeds the same edges (get_cost's probe loop) pays once while one that refills the
@@ -231,6 +231,8 @@ class Session(object):
                 return DeviceAdjacency.from_sparse_ev(SparseEV.fromdense(EV), self.device)
             except ValueError as e:
                 raise ValueError("feed for model['EV']: %s" % e)
+        if not remember:     # a stream of fresh batches (BatchPrefetcher): nothing to recognise, skip the fingerprint
+            return DeviceAdjacency.from_sparse_ev(EV, self.device)
         uv = np.ascontiguousarray(EV.uv)
         key = (tuple(EV.shape), uv.shape, zlib.crc32(uv.view(np.uint8).reshape(-1)))
         cache = self._adj_cache
@@ -241,13 +243,14 @@ class Session(object):
         return adj
 
     # ------------------------------------------------------------------ forward
-    def prepare(self, feed, pinned=False):
+    def prepare(self, feed, pinned=False, remember_adjacency=True):
         """Validates a feed_dict and makes the batch resident in HBM (adjacency in index/CSR form,
         (W,C) pairs, labels, segment offsets).  The returned DeviceBatch can be run many times.
         ``pinned``: stage through pinned host memory with non-blocking copies on the current stream
-        (used by parallel.BatchPrefetcher on its side stream)."""
+        (used by parallel.BatchPrefetcher on its side stream).  ``remember_adjacency=False`` skips the content fingerprint under
+        which the uploaded adjacency is remembered (_adjacency): a stream of fresh batches never repeats one."""
         m = self.model
-        adj = self._adjacency(feed[m["EV"]])
+        adj = self._adjacency(feed[m["EV"]], remember=remember_adjacency)
         M, N = adj.shape
         W = np.asarray(feed[m["W"]], dtype=np.float32).reshape(-1)
         C = np.asarray(feed[m["C"]], dtype=np.float32).reshape(-1)

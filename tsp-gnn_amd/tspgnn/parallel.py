@@ -102,11 +102,11 @@ class BatchPrefetcher(object):
                 t = self.pack(item) if self.pack is not None else item
                 if stream is not None:
                     with torch.cuda.stream(stream):
-                        b = self.sess.prepare(self._feed(t), pinned=self.pinned)
+                        b = self.sess.prepare(self._feed(t), pinned=self.pinned, remember_adjacency=False)
                         ev = torch.cuda.Event()
                         ev.record(stream)
                 else:
-                    b, ev = self.sess.prepare(self._feed(t)), None
+                    b, ev = self.sess.prepare(self._feed(t), remember_adjacency=False), None
                 with self._lock:
                     self._ready[seq] = (b, ev)
                     self._lock.notify_all()
