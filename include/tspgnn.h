@@ -32,7 +32,8 @@ extern "C" {
 #define TSPGNN_EINVAL (-1)      /* bad argument (null pointer, negative size, unsupported d) */
 #define TSPGNN_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
 
-#define TSPGNN_ABI_VERSION 2   /* 2: range_flag in the task structures, pack_weights_h2 / adam_clip_step arguments */
+#define TSPGNN_ABI_VERSION 3   /* 2: range_flag in the task structures, pack_weights_h2 / adam_clip_step arguments;
+                                  3: tspgnn_mp_loop_h2 (the whole T-step loop as one launch) */
 
 /* ABI version of the loaded library (== TSPGNN_ABI_VERSION of the header it was built from). */
 int tspgnn_version(void);
@@ -236,6 +237,54 @@ int tspgnn_mlp_head_fwd_h2(const tspgnn_mlp_task* task, const float* head_w, con
                            void* stream);
 int tspgnn_lnlstm_fwd_multi_h2(const tspgnn_lstm_task* tasks, int n_tasks, int d, void* stream);
 int tspgnn_lnlstm_mlp_fwd_multi_h2(const tspgnn_cell_mlp_task* tasks, int n_tasks, int d, void* stream);
+
+/*
+ * The WHOLE T-step loop of graphnn.py:175-179 (tf.while_loop over while_body, graphnn.py:142-173) as ONE launch, for the
+ * wiring of model.py:53-104: two variables, the "edge" one updated from a two-ones-per-row matrix (rows of EV,
+ * instance_loader.py:63-66) and the "vertex" one from its transpose.  Arithmetic, operand formats and summation orders
+ * are those of tspgnn_lnlstm_mlp_fwd_multi_h2 + tspgnn_csr_rowsum_f32 launched T times (bit-identical results); what
+ * changes is where the data lives and how steps are ordered:
+ *   - one workgroup per compute unit, resident for all T steps; EV is block-diagonal by instance
+ *     (instance_loader.py:56-66), so a step's dependences never leave a GROUP of consecutive instances: workgroups
+ *     synchronise per group through device counters (arrivals of message tiles, of aggregated vertex rows, of projected
+ *     vertex tiles) instead of per step through kernel boundaries, and run ahead where their inputs are ready;
+ *   - the edge states h, c stay IN REGISTERS between the steps (a wavefront owns <= 4 tiles of 16 edge rows for the whole
+ *     loop); per step an edge row only reads the projected messages of its two endpoints and writes its message row;
+ *   - the V<-E row-sum of a group is shared by the wavefronts that produced its messages; the vertex cells run on a few
+ *     workgroups of their own, one LDS residency for the cell kernel and one for the message MLP + projection per step.
+ * All buffers are caller-owned device memory; `plan` (int32, built by the host from the batch's instance sizes, see
+ * tspgnn/loop_plan.py) tells every wavefront its tiles: TSPGNN_LOOP_DESC_INTS ints per (workgroup, wavefront), then
+ * 4 ints per group {edge tiles, vertex tiles, vertex rows, 0}.  `counters` = 3 * 32 * n_groups unsigned words + 32, ZEROED
+ * by the caller before every launch (stream-ordered).  status (optional device word): |= 1 when a wait timed out (the
+ * launch's outputs are then garbage; cannot happen unless fewer than `grid` workgroups are resident).
+ * msg[0] / zx[0] hold the messages / projected messages of step 0 on entry (tspgnn_mlp_fwd_multi_h2).  T >= 1.
+ */
+#define TSPGNN_LOOP_WAVES 8
+#define TSPGNN_LOOP_DESC_INTS 24
+typedef struct tspgnn_mp_loop_args {
+    /* edge variable: rows M, gather-init cell (Kh, projected messages of the two endpoints), message MLP */
+    const float* e_h0; const float* e_c0;   /* [M,d] row-major initial states; e_c0 NULL = zeros */
+    float* e_h; float* e_c;                 /* [M,d] final states */
+    const int32_t* uv;                      /* [M,2] */
+    const void* e_K; const float* e_ln;     /* tspgnn_pack_weights_h2(Kh[d,4d]); LayerNorm block [10d] */
+    const void* e_mlp_wb; int e_mlp_layers; unsigned e_relu_mask;
+    float* msg[2];                          /* [M,d] message rows, by step parity */
+    /* vertex variable: rows N, cell over [row-sum of messages | h], message MLP, projection through the edge cell's Kx */
+    const float* v_h0; const float* v_c0; float* v_h; float* v_c;
+    const int32_t* rowptr; const int32_t* eid;   /* CSR of EV^T: [N+1], [2M] */
+    const void* v_K; const float* v_ln;     /* tspgnn_pack_weights_h2(K[2d,4d]) */
+    const float* v_zbias; const float* v_zscale;   /* optional, as tspgnn_lstm_task */
+    const void* v_mlp_wb; int v_mlp_layers; unsigned v_relu_mask;
+    const void* v_proj_w;                   /* tspgnn_pack_weights_h2(Kx[d,4d]) */
+    float* zx[2];                           /* projected messages (blocked format), by step parity */
+    float* vagg[2];                         /* [N,d] scratch: the row-sums, by step parity */
+    const int32_t* plan; unsigned* counters; int n_groups; int grid;
+    int M; int N; int T; int z_centered;
+    unsigned* range_flag; unsigned* status;
+    unsigned long long* trace;              /* optional (development): 8 words per (workgroup, wavefront), sums of
+                                               s_memrealtime ticks per phase of the loop (tools/loop_trace.py) */
+} tspgnn_mp_loop_args;
+int tspgnn_mp_loop_h2(const tspgnn_mp_loop_args* args, int d, void* stream);
 
 /* ------------------------------------------------------------------ bf16 storage, fp32 accumulate
  *

@@ -128,10 +128,13 @@ __device__ __forceinline__ void st4o(float* p, f32x4 v) {
 #ifndef H2_LN_SWAP
 #define H2_LN_SWAP 1
 #endif
-template <int NT>
-__device__ __forceinline__ void kblock_h2(f32x4 (&acc)[NT], const _Float16* wh, const _Float16* wl, int kb, int g, int jl,
-                                          const f16x8& bh, const f16x8& bl) {
-    const int off = ((kb * 4 + g) * NT * 16 + jl) * 8;
+// (NT_TOTAL = column tiles of the packed matrix, [T0, T0 + NT) = the tiles this call multiplies: a kernel that forms z one
+// gate (pair) at a time passes a slice; per output tile the three MFMAs and their order are those of the whole-matrix
+// call, so the results are bit-identical.)
+template <int NT_TOTAL, int T0, int NT>
+__device__ __forceinline__ void kblock_h2_sub(f32x4 (&acc)[NT], const _Float16* wh, const _Float16* wl, int kb, int g, int jl,
+                                              const f16x8& bh, const f16x8& bl) {
+    const int off = ((kb * 4 + g) * NT_TOTAL * 16 + jl) * 8 + T0 * 128;
     // The fragments of the next PF tiles are in flight while the three MFMAs of this one run (the compiler interleaves
     // the MFMA chains of neighbouring tiles on top of that).
     constexpr int PF = H2_PF < NT ? H2_PF : NT;
@@ -154,6 +157,11 @@ __device__ __forceinline__ void kblock_h2(f32x4 (&acc)[NT], const _Float16* wh, 
         c = MFMA_F16(a_h, bh, c);
         acc[t] = c;
     }
+}
+template <int NT>
+__device__ __forceinline__ void kblock_h2(f32x4 (&acc)[NT], const _Float16* wh, const _Float16* wl, int kb, int g, int jl,
+                                          const f16x8& bh, const f16x8& bl) {
+    kblock_h2_sub<NT, 0, NT>(acc, wh, wl, kb, g, jl, bh, bl);
 }
 
 // bytes -> LDS, 16 bytes per lane, straight from global memory (global_load_lds_dwordx4); the LDS address of a lane is

@@ -228,20 +228,20 @@ __device__ __forceinline__ void lstm_gates(f32x4 (&acc)[D / 4], f32x4 (&cf)[D / 
 //   stage f:      cs = c * sig(LN_f(z_f))                     (cs arrives holding the old c)
 //   stage (i, j): cs = LN_s(sig(LN_i(z_i)) * relu(LN_j(z_j)) + cs)   = the new (normalised) c
 //   stage o:      h' = relu(c') * sig(LN_o(z_o))
-template <int D, bool SWAP>
+template <int D, bool SWAP, bool CENTERED = false, bool TRACK = false>
 __device__ __forceinline__ void lstm_stage_f(f32x4 (&zf)[D / 16], f32x4 (&cs)[D / 16], const float* lds_ln, int g,
-                                             float eps_z = 1e-12f) {
+                                             float eps_z = 1e-12f, unsigned* vmin = nullptr) {
     constexpr int TPG = D / 16;
-    ln_gate<TPG, SWAP>(zf, lds_ln + 4 * D, lds_ln + 5 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP, CENTERED, TRACK>(zf, lds_ln + 4 * D, lds_ln + 5 * D, g, D, eps_z, vmin);
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
         cs[t].lo = cs[t].lo * sigmoid2_pre(zf[t].lo);
         cs[t].hi = cs[t].hi * sigmoid2_pre(zf[t].hi);
     }
 }
-template <int D, bool SWAP>
+template <int D, bool SWAP, bool CENTERED = false, bool TRACK = false>
 __device__ __forceinline__ void lstm_stage_ij(f32x4 (&zij)[D / 8], f32x4 (&cs)[D / 16], const float* lds_ln, int g,
-                                              float eps_z = 1e-12f) {
+                                              float eps_z = 1e-12f, unsigned* vmin = nullptr) {
     constexpr int TPG = D / 16;
     f32x4 gi[TPG], gj[TPG];
 #pragma unroll
@@ -249,8 +249,8 @@ __device__ __forceinline__ void lstm_stage_ij(f32x4 (&zij)[D / 8], f32x4 (&cs)[D
         gi[t] = zij[t];
         gj[t] = zij[TPG + t];
     }
-    ln_gate<TPG, SWAP>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D, eps_z);
-    ln_gate<TPG, SWAP>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP, CENTERED, TRACK>(gi, lds_ln + 0 * D, lds_ln + 1 * D, g, D, eps_z, vmin);
+    ln_gate<TPG, SWAP, CENTERED, TRACK>(gj, lds_ln + 2 * D, lds_ln + 3 * D, g, D, eps_z, vmin);
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
         cs[t].lo = fma2(sigmoid2_pre(gi[t].lo), relu2(gj[t].lo), cs[t].lo);
@@ -258,11 +258,11 @@ __device__ __forceinline__ void lstm_stage_ij(f32x4 (&zij)[D / 8], f32x4 (&cs)[D
     }
     ln_gate<TPG, SWAP>(cs, lds_ln + 8 * D, lds_ln + 9 * D, g, D);
 }
-template <int D, bool SWAP>
+template <int D, bool SWAP, bool CENTERED = false, bool TRACK = false>
 __device__ __forceinline__ void lstm_stage_o(f32x4 (&zo)[D / 16], const f32x4 (&nc)[D / 16], const float* lds_ln, int g,
-                                             f32x4 (&hn)[D / 16], float eps_z = 1e-12f) {
+                                             f32x4 (&hn)[D / 16], float eps_z = 1e-12f, unsigned* vmin = nullptr) {
     constexpr int TPG = D / 16;
-    ln_gate<TPG, SWAP>(zo, lds_ln + 6 * D, lds_ln + 7 * D, g, D, eps_z);
+    ln_gate<TPG, SWAP, CENTERED, TRACK>(zo, lds_ln + 6 * D, lds_ln + 7 * D, g, D, eps_z, vmin);
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
         hn[t].lo = relu2(nc[t].lo) * sigmoid2_pre(zo[t].lo);

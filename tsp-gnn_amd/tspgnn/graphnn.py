@@ -12,12 +12,14 @@ gather path.
 """
 from collections import namedtuple
 
+import ctypes
 import os
 
 import numpy as np
 import torch
 
 from . import _lib
+from . import loop_plan
 from . import variables as V
 from .instance_loader import SparseEV
 from .mlp import Mlp, wgrad
@@ -93,6 +95,34 @@ def _dev_i32(a, device):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
 
 
+def loop_enabled():
+    """The one-launch T-step loop (tspgnn_mp_loop_h2) is on unless TSPGNN_LOOP=0 (A/B runs, parity tests of the stepwise
+    launches)."""
+    return os.environ.get("TSPGNN_LOOP", "1") != "0"
+
+
+def _make_loop_plan(ev, device):
+    """Work plan of tspgnn_mp_loop_h2 for a SparseEV on a GPU: built where the batch is packed (host side, cached per
+    block structure), uploaded with the adjacency -- a captured forward then serves any batch copied into its buffers
+    (DeviceBatch.copy_from copies the plan too).  None: no GPU, switched off, or the batch does not fit the resident
+    design."""
+    dev = torch.device(device)
+    if dev.type != "cuda" or not loop_enabled() or ev.shape[0] == 0:
+        return None
+    blocks = getattr(ev, "blocks", None)
+    if blocks is None:
+        blocks = loop_plan.block_structure(ev.uv, ev.shape[1])
+        if blocks is None:
+            return None
+    grid = torch.cuda.get_device_properties(dev).multi_processor_count
+    grid -= grid % 8
+    built = loop_plan.build(blocks[0], blocks[1], grid=grid)
+    if built is None:
+        return None
+    plan, n_groups = built
+    return (torch.from_numpy(plan).to(dev), n_groups, grid)
+
+
 class _States(dict):
     """{var: LSTMStateTuple} as returned by GraphNN.__call__, carrying the scratch buffers its launch plan points at:
     the task structures hold raw device pointers, so the buffers must live as long as anything that may replay those
@@ -158,6 +188,7 @@ class DeviceAdjacency(object):
         self.csr_t = csr_t  # same for the transpose
         self.uv = uv        # int32 [R,2] if the matrix is 0/1 with exactly two ones per row
         self._degrees = {}
+        self.loop_plan = None   # (int32 device tensor, n_groups, grid): work plan of tspgnn_mp_loop_h2 (loop_plan.py)
 
     def row_degrees(self, transpose=False):
         """Stored entries per row (of the transpose) as fp32, computed once per matrix."""
@@ -173,7 +204,9 @@ class DeviceAdjacency(object):
         uv = _dev_i32(ev.uv, device)
         csr = (torch.arange(0, 2 * M + 1, 2, dtype=torch.int32, device=device), uv.view(-1), None)
         csr_t = (_dev_i32(rowptr, device), _dev_i32(eid, device), None)
-        return DeviceAdjacency((M, N), device, csr, csr_t, uv=uv)
+        adj = DeviceAdjacency((M, N), device, csr, csr_t, uv=uv)
+        adj.loop_plan = _make_loop_plan(ev, device)
+        return adj
 
     @staticmethod
     def from_dense(mat, device):
@@ -687,6 +720,9 @@ class GraphNN(object):
         self.fold_adjacency = True   # (EV y) Kx = EV (y Kx) fast path; False = op-for-op reference order
         # f16x2 fused forward: LayerNorm's mean subtraction folded into the cell kernels (TSPGNN_CENTER_GATES=0: A/B)
         self.center_gates = os.environ.get("TSPGNN_CENTER_GATES", "1") != "0"
+        # f16x2 inference forward: the whole T-step loop as ONE launch of resident workgroups (tspgnn_mp_loop_h2) where the
+        # wiring and the batch allow it (_loop_launch); False / TSPGNN_LOOP=0 = one row-sum + one cell launch per step
+        self.persistent_loop = True
         # training (f16x2): a message MLP's last linear layer pushed through the row-sum into the receiving cell, as in the
         # inference plan (one Dense layer less per edge row in the forward, the backward and the weight gradients)
         self.push_training = os.environ.get("TSPGNN_PUSH_TRAINING", "1") != "0"
@@ -1219,9 +1255,14 @@ class GraphNN(object):
             else:
                 cell._packed_split(arith, "lstm", 0, cell.dx + cell.d, cen)
 
+        loop_launch = self._loop_launch(states, mats, folded, pushed, consumers, message, first_state, arith, cen, keep) \
+            if arith == "h2" else None
+
         def run(T):
             for arr, d in pre_calls:
                 _lib.call_multi("tspgnn_mlp_fwd_multi_" + arith, arr, d)
+            if loop_launch is not None:
+                return loop_launch(T)
             for t in range(T):
                 kind = (t & 1, t < T - 1, t == 0)
                 if kind not in built:
@@ -1234,6 +1275,84 @@ class GraphNN(object):
             final = buf[T & 1]
             return {v: LSTMStateTuple(c=final[v].c[:rows_of[v]], h=final[v].h[:rows_of[v]]) for v in self.var}
         return run
+
+    def _loop_launch(self, states, mats, folded, pushed, consumers, message, first_state, arith, cen, keep):
+        """run(T) -> states through ONE launch of tspgnn_mp_loop_h2 (csrc/mp_loop_h2.hip: resident workgroups, edge
+        states in registers, per-group synchronisation), or None when the wiring or the batch is not the one that kernel
+        is written for: two variables of width 64, the "edge" one folded over a two-ones-per-row matrix that carries a
+        work plan (DeviceAdjacency.loop_plan), the "vertex" one fed by the row-sum over the same matrix's transpose.
+        Results are bit-identical to the stepwise launches of _plan_fused (tests/test_gpu_loop.py)."""
+        if not loop_enabled() or not self.persistent_loop or len(self.var) != 2:
+            return None
+        ve = [v for v in self.var if folded[v] is not None]
+        if len(ve) != 1:
+            return None
+        ve = ve[0]
+        vv = [v for v in self.var if v != ve][0]
+        if self.var[ve] != 64 or self.var[vv] != 64:
+            return None
+        ue, uvx = folded[ve], self.loop[vv]
+        if len(uvx) != 1:
+            return None
+        uvx = uvx[0]
+        if ue.get("var") != vv or uvx.get("var") != ve or uvx.get("mat") != ue["mat"] or not uvx.get("transpose?", False) \
+                or "fun" in uvx or "msg" not in uvx or "msg" not in ue:
+            return None
+        adj = mats[ue["mat"]]
+        if adj.loop_plan is None or adj.csr_t[2] is not None:
+            return None
+        plan_t, n_groups, grid = adj.loop_plan
+        cell_e, cell_v = self._RNN_cells[ve], self._RNN_cells[vv]
+        if cell_v.dx != 64 or cell_e.dx != 64:
+            return None
+        M, N = states[ve].h.shape[0], states[vv].h.shape[0]
+        f32 = dict(dtype=torch.float32, device=self.store.theta.device)
+        # the edge side's message MLP (consumed by the vertex cell) and the vertex side's (consumed, projected, by the edge cell)
+        e_wb, e_n, e_mask, e_out0, _, _ = message(vv, 0, 0)
+        _, _, _, e_out1, _, _ = message(vv, 0, 1)
+        v_wb, v_n, v_mask, _, v_pw, zx0 = message(ve, 0, 0)
+        _, _, _, _, _, zx1 = message(ve, 0, 1)
+        if e_out0 is None or zx0 is None or e_n > 4 or v_n > 4 or v_n < 1:
+            return None
+        if pushed[vv]:
+            mlp_e = self._msg_MLPs[uvx["msg"]]
+            v_K, zb = cell_v.pushed_bias_pack(mlp_e, arith=arith, centered=cen)
+            deg = adj.row_degrees(True)
+        else:
+            v_K, zb, deg = cell_v._packed_split(arith, "lstm", 0, cell_v.dx + cell_v.d, cen), None, None
+        e_K = cell_e._packed_split(arith, "lstm.kh", cell_e.dx, cell_e.dx + cell_e.d, cen)
+        out_e = LSTMStateTuple(c=torch.empty((M, 64), **f32), h=torch.empty((M, 64), **f32))
+        out_v = LSTMStateTuple(c=torch.empty((N, 64), **f32), h=torch.empty((N, 64), **f32))
+        vagg = [torch.empty((N, 64), **f32), torch.empty((N, 64), **f32)]
+        counters = torch.zeros(3 * 32 * n_groups + 32, dtype=torch.int32, device=f32["device"])
+        guard = self.store.h2_guard()
+        fs_e, fs_v = first_state[ve], first_state[vv]
+        a = _lib.MpLoopArgs()
+        a.e_h0, a.e_c0, a.e_h, a.e_c = _lib.ptr(fs_e.h), _lib.ptr(fs_e.c), _lib.ptr(out_e.h), _lib.ptr(out_e.c)
+        a.uv, a.e_K, a.e_ln = _lib.ptr(adj.uv), _lib.ptr(e_K), _lib.ptr(cell_e.ln())
+        a.e_mlp_wb, a.e_mlp_layers, a.e_relu_mask = _lib.ptr(e_wb), e_n, e_mask
+        a.msg[0], a.msg[1] = _lib.ptr(e_out0), _lib.ptr(e_out1)
+        a.v_h0, a.v_c0, a.v_h, a.v_c = _lib.ptr(fs_v.h), _lib.ptr(fs_v.c), _lib.ptr(out_v.h), _lib.ptr(out_v.c)
+        a.rowptr, a.eid = _lib.ptr(adj.csr_t[0]), _lib.ptr(adj.csr_t[1])
+        a.v_K, a.v_ln, a.v_zbias, a.v_zscale = _lib.ptr(v_K), _lib.ptr(cell_v.ln()), _lib.ptr(zb), _lib.ptr(deg)
+        a.v_mlp_wb, a.v_mlp_layers, a.v_relu_mask, a.v_proj_w = _lib.ptr(v_wb), v_n, v_mask, _lib.ptr(v_pw)
+        a.zx[0], a.zx[1] = _lib.ptr(zx0), _lib.ptr(zx1)
+        a.vagg[0], a.vagg[1] = _lib.ptr(vagg[0]), _lib.ptr(vagg[1])
+        a.plan, a.counters, a.n_groups, a.grid = _lib.ptr(plan_t), _lib.ptr(counters), n_groups, grid
+        a.M, a.N, a.z_centered = M, N, int(cen)
+        a.range_flag, a.status = guard.data_ptr(), guard.data_ptr() + 8
+        trace = None
+        if os.environ.get("TSPGNN_LOOP_TRACE"):   # development: per-wavefront phase times (tools/loop_trace.py)
+            trace = self.loop_trace = torch.zeros((grid, loop_plan.WAVES, 8), dtype=torch.int64, device=f32["device"])
+        a.trace = _lib.ptr(trace)
+        keep.extend([out_e, out_v, vagg, counters, plan_t, v_K, zb, deg, e_K, a, trace])
+
+        def launch(T):
+            a.T = int(T)
+            counters.zero_()
+            _lib.call("tspgnn_mp_loop_h2", ctypes.byref(a), 64, _lib.current_stream())
+            return {ve: out_e, vv: out_v}
+        return launch
 
     def _plan(self, states, mats, folded):
         """Pre-builds the launches of an even and an odd step over two ping-pong state buffers, so that

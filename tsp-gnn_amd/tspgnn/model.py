@@ -67,7 +67,9 @@ class DeviceBatch(object):
         """Overwrite this batch's device tensors with ``other``'s (same shapes: same numbers of graphs, vertices and
         edges) -- lets a captured forward graph, which is bound to THIS batch's buffers, serve a stream of batches."""
         mine, theirs = self.tensors(), other.tensors()
+        groups = [None if b.adj.loop_plan is None else b.adj.loop_plan[1:] for b in (self, other)]
         if (self.M, self.N, self.B, self.T) != (other.M, other.N, other.B, other.T) or len(mine) != len(theirs) \
+                or groups[0] != groups[1] \
                 or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(mine, theirs)):
             raise ValueError("copy_from: the batches differ in shape")
         for a, b in zip(mine, theirs):
@@ -82,6 +84,8 @@ class DeviceBatch(object):
             out.append(adj.uv)
             for csr in (adj.csr, adj.csr_t):
                 out.extend(csr)
+            if adj.loop_plan is not None:    # (the one-launch loop's work plan follows the batch's block structure)
+                out.append(adj.loop_plan[0])
         return [t for t in out if torch.is_tensor(t)]
 
 
@@ -319,7 +323,12 @@ class Session(object):
         if self.device.type != "cuda":
             return False
         guard = self.store.h2_guard()
-        bits = int(guard[0].item()) & 3     # bit 0: an operand beyond fp16's largest value; bit 1: a gate row whose spread
+        words = guard[:3].tolist()
+        if words[2]:                        # tspgnn_mp_loop_h2 gave up waiting: its workgroups were not all resident
+            guard[2:3].zero_()
+            raise RuntimeError("tspgnn_mp_loop_h2: a wait inside the one-launch loop timed out (status %d); the launch's "
+                               "outputs are invalid -- set TSPGNN_LOOP=0 to run the stepwise launches" % words[2])
+        bits = words[0] & 3                 # bit 0: an operand beyond fp16's largest value; bit 1: a gate row whose spread
         if bits:                            # is below the absolute error of its operands' fp16 pieces (h2_tile.h)
             self.last_range_bits = bits
             if clear:
