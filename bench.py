@@ -64,7 +64,23 @@ def dense_flops_per_step(N, M, d, folded=True):
     return mlp + M * 2 * d * 4 * d + N * 2 * 2 * d * 4 * d + N * 2 * d * 4 * d
 
 
-PROFILE_ROUNDS = ("r04", "r03")   # newest first: the rocprofv3 summaries bench.py quotes (profiles/<round>_<workload>_...)
+PROFILE_ROUNDS = ("r05", "r04", "r03")   # newest first: the rocprofv3 summaries bench.py quotes (profiles/<round>_<workload>_...)
+
+
+def csrc_fingerprint():
+    """sha256 (first 16 hex digits) over the kernel sources the shipped library is built from (tsp-gnn_amd/csrc/*.hip,
+    *.h, sorted by name).  tools/profile_r05_all.sh writes it into every rocprofv3 summary it commits (`# csrc_sha16:`
+    line): a summary whose fingerprint differs from the tree's was taken on OTHER kernels and is not quoted as this
+    build's figure (the committed profile could go stale unnoticed)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "tsp-gnn_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def profile_kernel_stats(workload):
@@ -81,6 +97,8 @@ def profile_kernel_stats(workload):
         out = {}
         with open(path) as f:
             for line in f:
+                if line.startswith("# csrc_sha16:"):
+                    out["__csrc_sha16__"] = (0, line.split(":", 1)[1].strip())
                 if line.startswith("#") or line.startswith("kernel "):
                     continue
                 parts = line.rstrip().rsplit(None, 9)   # name | grid wg lds vgpr calls avg min max pct
@@ -97,6 +115,8 @@ def profile_lookup(stats, *needles):
     """The entry with the most calls whose kernel name contains every needle."""
     best = None
     for name, (calls, avg) in stats.items():
+        if name.startswith("__"):
+            continue
         if all(n in name for n in needles) and (best is None or calls > best[1]):
             best = (name, calls, avg)
     return best
@@ -493,9 +513,20 @@ def main():
         #   marginal_cost_us: (replayed forward - replayed forward without its row-sum launches) / T -- what the pass PAYS
         #     for the aggregation (a difference of two replays, NOT a kernel time: the launch that follows starts cold).
         prof_path, prof_stats = profile_kernel_stats(args.workload)
-        rs_prof = profile_lookup(prof_stats, "csr_rowsum_bf16" if bf16 else "csr_rowsum_kernel")
+        # the committed summary counts as THIS build's only if it carries the fingerprint of the kernel sources in the tree
+        prof_sha = prof_stats.get("__csrc_sha16__", (0, None))[1]
+        prof_fresh = prof_sha is not None and prof_sha == csrc_fingerprint()
+        rs_prof_any = profile_lookup(prof_stats, "csr_rowsum_bf16" if bf16 else "csr_rowsum_kernel")
+        rs_prof = rs_prof_any if prof_fresh else None
         live_us = kernels_us[rk]["avg_us"] if rk in kernels_us else None
-        if rs_prof:
+        if rs_prof is None and rowsum_in_fwd_us and rowsum_in_fwd_us > 0:
+            # no summary of this build: the live figure -- what the replayed pass pays per row-sum launch, measured now
+            where_us = rowsum_in_fwd_us
+            where_how = ("LIVE: (replayed forward - replayed forward without its %d row-sum launches) / T, medians of 5 x 20 "
+                         "alternating HIP-graph replays on this box (the committed rocprofv3 summary %s was taken on other "
+                         "kernel sources and is reported under `rocprof_stale` only)" % (T, prof_path))
+            where_src = "live"
+        elif rs_prof:
             where_us = rs_prof[2]
             where_how = ("rocprofv3 --kernel-trace --stats of the replayed forward (tools/forward_graph.py %s 20): average "
                          "duration of %d dispatches of `%s`" % (args.workload, rs_prof[1], rs_prof[0]))
@@ -515,6 +546,9 @@ def main():
             "bound": "hbm", "achieved": round(rowsum_b / where_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(rowsum_b / where_us / 1e3 / HBM_PEAK_GBS, 4), "avg_us": round(where_us, 2), "how": where_how,
             "source": where_src,
+            "profile_matches_build": prof_fresh,
+            "rocprof_stale": None if prof_fresh or not rs_prof_any else
+                             {"avg_us": rs_prof_any[2], "source": prof_path, "csrc_sha16": prof_sha, "tree_sha16": csrc_fingerprint()},
             "live_events_us": round(live_us, 2) if live_us is not None else None,
             "live_events_frac": round(rowsum_b / live_us / 1e3 / HBM_PEAK_GBS, 4) if live_us else None,
             "marginal_cost_us": round(rowsum_in_fwd_us, 2) if rowsum_in_fwd_us and rowsum_in_fwd_us > 0 else None,
@@ -537,6 +571,11 @@ def main():
         roofline_cell = None
         cell_prof = profile_lookup(prof_stats, "lnlstm_mlp_fwd_h2_kernel") if not bf16 else \
             profile_lookup(prof_stats, "lnlstm_fwd_bf16_kernel")
+        cname_live = "tspgnn_lnlstm_mlp_fwd_multi_h2" if not bf16 else "tspgnn_lnlstm_fwd_multi_bf16"
+        if not prof_fresh and cname_live in kernels_us:
+            # (stale summary: the launch's duration by HIP events in the eager forward, measured now -- reads ~1-2 us high)
+            cell_prof = (cname_live + " (live HIP events; committed summary is of other sources)", kernels_us[cname_live]["n"],
+                         kernels_us[cname_live]["avg_us"])
         if cell_prof:
             cb = cell_launch_bytes(N, M, d, eb=2 if bf16 else 4)
             if bf16:   # bf16 storage: h and messages bf16, c fp32; the message MLP is a launch of its own
@@ -555,10 +594,11 @@ def main():
                 "frac": round(cb["total"] / cell_prof[2] / 1e3 / HBM_PEAK_GBS, 4),
                 "traffic": cell_traffic,
                 "traffic_over_compulsory": round(cell_traffic / cb["total"], 3) if cell_traffic else None,
-                "source": prof_path, "traffic_source": ("profiles/%s in_forward" % tname) if cell_traffic else None,
+                "source": prof_path if prof_fresh else "live", "traffic_source": ("profiles/%s in_forward" % tname) if cell_traffic else None,
                 "live_events_us": round(kernels_us[cname]["avg_us"], 2) if cname in kernels_us else None,
                 "share_of_forward": round(cell_prof[1] * cell_prof[2] /
-                                          max(1e-9, sum(c * a for c, a in prof_stats.values())), 4),
+                                          max(1e-9, sum(c * a for k_, (c, a) in prof_stats.items() if not k_.startswith("__"))), 4)
+                                    if prof_fresh else None,
             }
         dense_names = ("tspgnn_mlp_fwd_f32", "tspgnn_mlp_fwd_multi_f32", "tspgnn_lnlstm_fwd_f32",
                        "tspgnn_lnlstm_fwd_multi_f32", "tspgnn_lnlstm_gather_fwd_f32", "tspgnn_linear_f32",

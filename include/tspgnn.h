@@ -281,7 +281,7 @@ typedef struct tspgnn_mp_loop_args {
     const int32_t* plan; unsigned* counters; int n_groups; int grid;
     int M; int N; int T; int z_centered;
     unsigned* range_flag; unsigned* status;
-    unsigned long long* trace;              /* optional (development): 8 words per (workgroup, wavefront), sums of
+    unsigned long long* trace;              /* optional (development): 16 words per (workgroup, wavefront), sums of
                                                s_memrealtime ticks per phase of the loop (tools/loop_trace.py) */
 } tspgnn_mp_loop_args;
 int tspgnn_mp_loop_h2(const tspgnn_mp_loop_args* args, int d, void* stream);

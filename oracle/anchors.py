@@ -59,3 +59,40 @@ def anchor_inputs(name):
 
 def anchor_rows(n_rows):
     return np.unique(np.linspace(0, n_rows - 1, ANCHOR_ROWS).astype(np.int64))
+
+
+# Gradient anchors (round 5): tf.gradients(loss + 1e-10 * l2) (model.py:163-166, unclipped) of the float64 oracle at FULL
+# size -- C2 at T = 2, C1 at its own T = 8 -- for the same batches and weights as the forward anchors, but perturbed
+# LayerNorm parameters / biases (init_params(perturb=True): with gamma = 1, beta = 0 and zero biases whole gradient
+# blocks would sit at their symmetric points).  Kept per variable: its 2-norm, its largest entry, 64 sampled entries, and
+# what the op-for-op float32 autograd restatement loses on the same variable (the error budget of any fp32 backward).
+GRAD_ANCHORS = {"c2": (lambda: [40] * 128, 2), "c1": (lambda: [20] * 32, 8)}
+GRAD_SAMPLES = 64
+
+# "Far from init" weights (round 5): the float64 oracle trained for 2 000 Adam steps at lr 1e-3 (model.py:160-167 with a
+# larger step) on synthetic batches -- LayerNorm gains, biases and kernels with the statistics of a trained network, not
+# of the initialisers.  tests/golden/trained_d64.npz holds the weights; the parity tests run the oracle next to the HIP path.
+TRAINED = {"d": 64, "steps": 2000, "lr": 1e-3, "sizes": [12] * 16, "T": 8, "n_batches": 8}
+
+
+def grad_anchor_inputs(name):
+    sys.path.insert(0, os.path.join(ROOT, "tsp-gnn_amd"))
+    import tspgnn
+    from oracle import params as P
+    import zlib
+    sizes, T = GRAD_ANCHORS[name]
+    batch = tspgnn.synthetic_batch(sizes(), seed=1234)
+    params = P.init_params(64, seed=0, perturb=True)
+    EV, W, C = batch[0], batch[1], batch[2]
+    finger = np.array([float(EV.shape[0]), float(EV.shape[1]), float(zlib.crc32(np.ascontiguousarray(EV.uv).view(np.uint8).reshape(-1))),
+                       float(np.sum(W, dtype=np.float64)), float(np.sum(C, dtype=np.float64)),
+                       float(sum(np.sum(np.asarray(v, dtype=np.float64)) for v in params.values())),
+                       float(sum(np.sum(np.abs(np.asarray(v, dtype=np.float64))) for v in params.values()))])
+    return batch, params, T, finger
+
+
+def grad_sample_index(name, size):
+    """Flat indices of the sampled entries of variable ``name`` (deterministic in the name and the size)."""
+    import zlib
+    rng = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)
+    return np.sort(rng.choice(size, size=min(GRAD_SAMPLES, size), replace=False))

@@ -21,7 +21,12 @@
 4. ``graph_*.npz`` -- ``.graph`` instance files (text) together with what the REFERENCE's own ``read_graph``
    (/root/reference/instance_loader.py:95-127, imported here) parses out of them: pins the native reader.
 
-Usage:  python oracle/gen_golden.py [pack] [oracle] [anchors] [graph] [bf16]      (default: all)
+5. ``anchor_grad_*.npz`` -- float64 GRADIENTS at full size (C2 at T = 2, C1 at T = 8): per variable its norm, largest
+   entry, 64 sampled entries and the loss of the fp32 autograd restatement (oracle/anchors.py GRAD_ANCHORS; "grads").
+6. ``trained_d64.npz`` -- the oracle's own weights after 2 000 Adam steps at lr 1e-3 on synthetic batches: a network
+   whose statistics are not those of the initialisers, for parity far from init ("trained").
+
+Usage:  python oracle/gen_golden.py [pack] [oracle] [anchors] [graph] [bf16] [grads] [trained]   (default: the first five)
 """
 import os
 import sys
@@ -113,7 +118,8 @@ def gen_oracle():
         print("oracle", name, d, T, "loss", data["loss"])
 
 
-from oracle.anchors import ANCHORS, BF16_ANCHORS, anchor_inputs, anchor_rows, bf16_anchor_inputs  # noqa: E402
+from oracle.anchors import (ANCHORS, BF16_ANCHORS, GRAD_ANCHORS, TRAINED, anchor_inputs, anchor_rows,  # noqa: E402
+                            bf16_anchor_inputs, grad_anchor_inputs, grad_sample_index)
 
 
 def gen_anchors():
@@ -141,6 +147,70 @@ def gen_anchors():
                 data["%s%s_absmax" % (var, part)] = np.float64(np.abs(a).max())
         np.savez_compressed(os.path.join(OUT, "anchor_%s.npz" % name), **data)
         print("anchor", name, "T", T, "M", EV.shape[0], "loss %.9f" % data["loss"], "%.1f s" % (time.time() - t0))
+
+
+def gen_grad_anchors():
+    """anchor_grad_*.npz: float64 gradients at full size (oracle/anchors.py, GRAD_ANCHORS)."""
+    import time
+    import torch
+    from oracle import torch_oracle as TO
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    for name in GRAD_ANCHORS:
+        batch, params, T, finger = grad_anchor_inputs(name)
+        EV, W, C, route_exists, n_vertices, n_edges = batch
+        ob = {"ev_uv": EV.uv, "W": W, "C": C, "route_exists": route_exists, "n_vertices": n_vertices, "n_edges": n_edges}
+        t0 = time.time()
+        out, g = TO.loss_and_grads(params, ob, T, dtype=torch.float64)
+        _, g32 = TO.loss_and_grads(params, ob, T, dtype=torch.float32)
+        data = {"T": np.int64(T), "d": np.int64(64), "fingerprint": finger, "loss": np.float64(out["loss"].item())}
+        gmax = max(float(np.abs(v).max()) for v in g.values())
+        data["grad_absmax"] = np.float64(gmax)
+        for k, v in g.items():
+            flat = np.asarray(v, dtype=np.float64).reshape(-1)
+            idx = grad_sample_index(k, flat.size)
+            data["norm:" + k] = np.float64(np.sqrt((flat ** 2).sum()))
+            data["absmax:" + k] = np.float64(np.abs(flat).max())
+            data["sample:" + k] = flat[idx]
+            data["err32:" + k] = np.float64(np.abs(np.asarray(g32[k], dtype=np.float64).reshape(-1) - flat).max())
+        np.savez_compressed(os.path.join(OUT, "anchor_grad_%s.npz" % name), **data)
+        print("grad anchor", name, "T", T, "M", EV.shape[0], "loss %.9f" % data["loss"], "|g|max %.3e" % gmax,
+              "%.1f s" % (time.time() - t0))
+
+
+def gen_trained():
+    """trained_d64.npz: the oracle's weights after TRAINED['steps'] Adam steps (float64) -- a network far from its
+    initialisers for the parity tests (tests/test_gpu_trained.py)."""
+    import time
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tsp-gnn_amd"))
+    import tspgnn
+    from oracle import params as P
+    from oracle import torch_oracle as TO
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = TRAINED
+    batches = []
+    for s in range(cfg["n_batches"]):
+        EV, W, C, route_exists, n_vertices, n_edges = tspgnn.synthetic_batch(cfg["sizes"], seed=100 + s)
+        batches.append({"ev_uv": EV.uv, "W": W, "C": C, "route_exists": route_exists, "n_vertices": n_vertices,
+                        "n_edges": n_edges})
+    params = {k: np.asarray(v, dtype=np.float64) for k, v in P.init_params(cfg["d"], seed=42).items()}
+    m = {k: np.zeros_like(v) for k, v in params.items()}
+    v_ = {k: np.zeros_like(v) for k, v in params.items()}
+    t0 = time.time()
+    for step in range(1, cfg["steps"] + 1):
+        out, g = TO.loss_and_grads(params, batches[step % len(batches)], cfg["T"], dtype=torch.float64)
+        g, gn = TO.clip_by_global_norm(g)
+        params, m, v_ = TO.adam_step(params, g, m, v_, step, lr=cfg["lr"])
+        if step % 200 == 0 or step == 1:
+            print("trained: step %d loss %.6f |g| %.3e  %.0f s" % (step, out["loss"].item(), gn, time.time() - t0), flush=True)
+    init = P.init_params(cfg["d"], seed=42)
+    moved = {k: float(np.abs(params[k] - init[k]).max()) for k in params}
+    print("largest movement per variable: max %.3f, LayerNorm gains now in [%.3f, %.3f]"
+          % (max(moved.values()), min(params[k].min() for k in params if k.endswith("gamma")),
+             max(params[k].max() for k in params if k.endswith("gamma"))))
+    np.savez_compressed(os.path.join(OUT, "trained_d64.npz"), **{k: v.astype(np.float32) for k, v in params.items()})
 
 
 def gen_bf16_anchors(only=None):
@@ -217,6 +287,10 @@ if __name__ == "__main__":
         gen_graph()
     if "bf16" in what:
         gen_bf16_anchors()
+    if "grads" in what:      # (not in the default list: minutes of float64 autograd at C2 size)
+        gen_grad_anchors()
+    if "trained" in what:    # (not in the default list: 2 000 oracle training steps)
+        gen_trained()
     for w in what:   # "bf16:<name>": one bf16 anchor only (the others take minutes and do not change)
         if w.startswith("bf16:"):
             gen_bf16_anchors(only=w[5:].split(","))

@@ -93,3 +93,44 @@ def test_bf16_storage_at_config5_depth(cuda_device, name):
           % (name, e_pred, f_pred, abs(float(loss) - float(z["bf16_loss"])), "  ".join(report)))
     assert e_pred < 5e-4 and abs(float(loss) - float(z["bf16_loss"])) < 2e-4
     assert f_pred < 1e-2
+
+
+@pytest.mark.parametrize("name", ["c2", "c1"])
+def test_full_size_gradients_match_float64_anchor(cuda_device, name):
+    """The training step's gradients at FULL size -- C2 (M = 99 840 edges) at T = 2, C1 at its own T = 8 -- against committed
+    float64 autograd gradients (tests/golden/anchor_grad_*.npz, oracle/gen_golden.py grads): per variable the 2-norm and 64
+    sampled entries.  Bar per variable, relative to max(its largest entry, 1e-3 of the largest gradient entry overall):
+    max(1e-5, 2 x what the op-for-op float32 autograd restatement loses on that variable) -- the bar of
+    test_gradient_parity_with_autograd_oracle, here at the size the benchmark runs."""
+    import torch
+    import tspgnn
+    from oracle.anchors import grad_anchor_inputs, grad_sample_index
+    z = np.load(os.path.join(GOLDEN, "anchor_grad_%s.npz" % name))
+    batch, params, T, finger = grad_anchor_inputs(name)
+    assert T == int(z["T"]) and np.array_equal(finger, z["fingerprint"]), "inputs differ from the anchor's"
+    EV, W, C, route_exists, n_vertices, n_edges = batch
+    model = tspgnn.build_network(64)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T, model["route_exists"]: route_exists,
+            model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    out = sess.loss_and_grads(feed)
+    torch.cuda.synchronize()
+    g = model.store.grad_dict()
+    assert abs(float(out["stats"][0].item()) - float(z["loss"])) < REL_TOL
+    gscale = float(z["grad_absmax"])
+    worst = (0.0, None)
+    for k in g:
+        # the oracle's gradients include the L2 term 1e-10 * w (model.py:163-166); the HIP backward adds it in the optimiser
+        ref = z["sample:" + k] - 1e-10 * np.asarray(params[k], dtype=np.float64).reshape(-1)[grad_sample_index(k, params[k].size)]
+        got = np.asarray(g[k], dtype=np.float64).reshape(-1)[grad_sample_index(k, params[k].size)]
+        scale = max(float(z["absmax:" + k]), 1e-3 * gscale)
+        bar = max(1e-5, 2.0 * float(z["err32:" + k]) / scale)
+        err = float(np.abs(got - ref).max()) / scale
+        nerr = abs(float(np.sqrt((np.asarray(g[k], dtype=np.float64) ** 2).sum())) - float(z["norm:" + k])) / max(float(z["norm:" + k]), 1e-3 * gscale)
+        if err / bar > worst[0]:
+            worst = (err / bar, "%s: %.2e against a bar of %.2e" % (k, err, bar))
+        assert err < bar, (k, err, bar)
+        assert nerr < max(1e-5, 2.0 * float(z["err32:" + k]) / scale), (k, "norm", nerr)
+    print("gradient anchor %s (T=%d): worst variable %s" % (name, T, worst[1]))

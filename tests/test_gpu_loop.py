@@ -16,6 +16,13 @@ pytestmark = pytest.mark.gpu
 REL_TOL = 1e-5
 
 
+@pytest.fixture(autouse=True)
+def every_batch_that_fits(monkeypatch):
+    """By default the loop only takes batches of <= 3 resident tiles per wavefront (where it is the faster path,
+    loop_plan.max_edge_tiles); the tests exercise everything the kernel holds."""
+    monkeypatch.setenv("TSPGNN_LOOP_MAX_TILES", "4")
+
+
 def forward(params, t, T, loop, d=64):
     model = tspgnn.build_network(d)
     model["gnn"].persistent_loop = loop

@@ -36,7 +36,7 @@ def decode(plan, grid):
                                         ([40] * 131, 256), ([12] * 16, 16), ([3, 3, 3, 9], 16)])
 def test_plan_covers_every_row_once_within_the_kernels_limits(sizes, grid):
     ev, (e_start, v_start) = blocks_of(sizes)
-    built = LP.build(e_start, v_start, grid=grid)
+    built = LP.build(e_start, v_start, grid=grid, max_tiles=4)
     assert built is not None
     plan, G = built
     p, edge, vert = decode(plan, grid)
@@ -82,7 +82,8 @@ def test_c2_plan_is_the_balanced_one():
     """C2 (128 x n = 40): 28 edge + 4 vertex workgroups per XCD, 784 tiles per XCD = 7 per SIMD (wavefronts w and w + 4
     share a SIMD: 4 + 3 tiles), groups of two instances = 5 full vertex tiles."""
     ev, (e_start, v_start) = blocks_of([40] * 128)
-    plan, G = LP.build(e_start, v_start, grid=256)
+    assert LP.build(e_start, v_start, grid=256) is None      # (default: only batches of <= 3 tiles per wavefront)
+    plan, G = LP.build(e_start, v_start, grid=256, max_tiles=4)
     assert G == 64 and LP.describe(plan, 256) == (224, 32, 4, 2)
     p = np.asarray(plan).reshape(256, LP.WAVES, LP.DESC)
     for b in range(256):
@@ -93,8 +94,10 @@ def test_c2_plan_is_the_balanced_one():
 
 def test_oversize_and_empty_batches_are_declined():
     _, (e_start, v_start) = blocks_of([40] * 160)       # 124 800 edge rows: more than 4 tiles per wavefront
-    assert LP.build(e_start, v_start, grid=256) is None
+    assert LP.build(e_start, v_start, grid=256, max_tiles=4) is None
     assert LP.build(np.array([0, 0]), np.array([0, 5]), grid=256) is None
+    _, (e_start, v_start) = blocks_of([40] * 96)        # 3 tiles per wavefront: taken by default
+    assert LP.describe(LP.build(e_start, v_start, grid=256)[0], 256)[2] == 3
 
 
 def test_block_structure_from_the_endpoint_list():
@@ -121,7 +124,7 @@ def test_protocol_has_no_deadlock_and_no_buffer_hazard(sizes, grid, T):
     completes the count of the step the sibling has not stored yet -- which the GPU runs had not shown.  Counters are now
     split by step parity; a producer can lead a sibling by one step, never by two.)"""
     ev, (e_start, v_start) = blocks_of(sizes)
-    plan, G = LP.build(e_start, v_start, grid=grid)
+    plan, G = LP.build(e_start, v_start, grid=grid, max_tiles=4)
     p, edge, vert = decode(plan, grid)
     M, N = ev.shape
     uv = ev.uv

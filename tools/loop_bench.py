@@ -35,11 +35,19 @@ for loop in modes:
     b = sess.prepare(feed)
     print("loop" if loop else "steps", "plan:", None if b.adj.loop_plan is None else b.adj.loop_plan[1:], flush=True)
     rp = sess.capture_forward(b)
+    if os.environ.get("SYNC_AFTER_CAPTURE"):
+        torch.cuda.synchronize()
     out = rp()
     torch.cuda.synchronize()
-    assert not sess.range_exceeded()
-    outs[loop] = {"pred": out["predictions"].clone(), "Eh": out["last_states"]["E"].h.clone(),
-                  "Vc": out["last_states"]["V"].c.clone()}
+    if not os.environ.get("NO_RANGE"):
+        assert not sess.range_exceeded()
+    if os.environ.get("NO_CLONE"):
+        outs[loop] = {"pred": out["predictions"], "Eh": out["last_states"]["E"].h, "Vc": out["last_states"]["V"].c}
+    else:
+        outs[loop] = {"pred": out["predictions"].clone(), "Eh": out["last_states"]["E"].h.clone(),
+                      "Vc": out["last_states"]["V"].c.clone()}
+    if os.environ.get("KEEP_B"):
+        replays[("b", loop)] = b
     replays[loop] = rp
 for k in (outs[True] if len(modes) == 2 else ()):
     same = torch.equal(outs[True][k], outs[False][k])

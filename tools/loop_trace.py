@@ -2,6 +2,8 @@
 phase, averaged per step.  TSPGNN_LOOP_TRACE=1 python tools/loop_trace.py [graphs=128] [n=40] [T=32]
 edge wavefronts:   0 wait for the group's message tiles   1 row-sum share (+ drain, arrive)   2 wait for projected tiles
                    3 acquire fence   4 resident tiles (cells + message MLP)   5 drain + arrive
+                   inside 4, summed over the tiles: 8 gather + f stage  9 i,j stage  10 o stage  11 split + MLP layer 1
+                   12 MLP layers 2.. (the marks 8.. make phase 4 = the time after the last mark: loop overhead)  13 stores
 vertex wavefronts: 0 wait for aggregates + operand fetch   1 K staging wait + barrier   2 cells   3 barrier + MLP staging
                    4 message MLP + projection   5 drain + arrive   6 barrier + K staging issue"""
 import os
@@ -49,7 +51,7 @@ for role, name in ((1, "edge"), (2, "vertex")):
     if len(x) == 0:
         continue
     print("%s wavefronts: %d, tiles per wavefront %s" % (name, len(x), np.bincount(p[:, :, 1][sel]).tolist()))
-    print("  phase      " + " ".join("%7d" % i for i in range(8)) + "    total")
+    print("  phase      " + " ".join("%7d" % i for i in range(x.shape[1])) + "    total")
     for label, v in (("mean", x.mean(0)), ("p10", np.percentile(x, 10, axis=0)), ("p90", np.percentile(x, 90, axis=0)),
                      ("max", x.max(0))):
         print("  %-9s  " % label + " ".join("%7.2f" % a for a in v) + "  %7.2f" % v.sum())

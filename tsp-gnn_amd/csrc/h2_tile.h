@@ -163,6 +163,37 @@ __device__ __forceinline__ void kblock_h2(f32x4 (&acc)[NT], const _Float16* wh, 
                                           const f16x8& bh, const f16x8& bl) {
     kblock_h2_sub<NT, 0, NT>(acc, wh, wl, kb, g, jl, bh, bl);
 }
+// The same for NP row tiles at once (a wavefront that holds the B operands of several tiles): one fragment fetch feeds NP
+// independent MFMA chains -- 1/NP of the LDS reads per tile and NP times the instruction-level parallelism; per output
+// tile the three MFMAs and their order are unchanged.
+template <int NT_TOTAL, int T0, int NT, int NP>
+__device__ __forceinline__ void kblock_h2_multi(f32x4 (&acc)[NP][NT], const _Float16* wh, const _Float16* wl, int kb, int g,
+                                                int jl, const f16x8 (&bh)[NP], const f16x8 (&bl)[NP]) {
+    const int off = ((kb * 4 + g) * NT_TOTAL * 16 + jl) * 8 + T0 * 128;
+    constexpr int PF = H2_PF < NT ? H2_PF : NT;
+    f16x8 ah[PF + 1], al[PF + 1];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        ah[p] = ldw(wh + off + p * 128);
+        al[p] = ldw(wl + off + p * 128);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t + PF < NT) {
+            ah[(t + PF) % (PF + 1)] = ldw(wh + off + (t + PF) * 128);
+            al[(t + PF) % (PF + 1)] = ldw(wl + off + (t + PF) * 128);
+        }
+        const f16x8 a_h = ah[t % (PF + 1)], a_l = al[t % (PF + 1)];
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            f32x4 c = acc[n][t];
+            c = MFMA_F16(a_l, bh[n], c);  // smallest terms first
+            c = MFMA_F16(a_h, bl[n], c);
+            c = MFMA_F16(a_h, bh[n], c);
+            acc[n][t] = c;
+        }
+    }
+}
 
 // bytes -> LDS, 16 bytes per lane, straight from global memory (global_load_lds_dwordx4); the LDS address of a lane is
 // the wavefront's base + lane*16.  Callers follow up with h2_stage_wait() + a barrier.

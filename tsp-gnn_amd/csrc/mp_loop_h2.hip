@@ -48,6 +48,9 @@ constexpr int kLoopWaves = TSPGNN_LOOP_WAVES;
 constexpr int kLoopDesc = TSPGNN_LOOP_DESC_INTS;
 constexpr int kLoopEdgeTiles = 4;
 constexpr int kLoopVertTiles = 2;
+#ifndef LOOP_PAIR
+#define LOOP_PAIR 4   // which stages step two resident tiles together (see pair_step)
+#endif
 constexpr int kAuxWT = 17;                 // sc0 sc1: write-through store / L1-bypassing load
 constexpr unsigned kSpinLimit = 1u << 19;  // polls (each ~1 us: a load round trip + s_sleep)
 
@@ -143,31 +146,36 @@ __device__ __forceinline__ void dense_layer_h2_loop(f32x4 (&a)[D / 16], const _F
     }
 }
 
-// Optional phase trace (args.trace != NULL): per (workgroup, wavefront) 8 sums of s_memrealtime ticks (100 MHz), see
-// tools/loop_trace.py for the phases.  A handful of scalar instructions per phase; absent pointer = two scalar branches.
+// Optional phase trace (args.trace != NULL selects the TRACE variant of the kernel): per (workgroup, wavefront) 8 sums of
+// s_memrealtime ticks (100 MHz), see tools/loop_trace.py for the phases.
+template <bool ON>
 struct LoopTrace {
     unsigned long long* dst;
     unsigned long long prev;
-    unsigned long long acc[8];
+    unsigned long long acc[ON ? 16 : 1];
     __device__ __forceinline__ void begin(unsigned long long* p) {
-        dst = p;
-        for (int i = 0; i < 8; ++i) acc[i] = 0;
-        if (dst) prev = __builtin_amdgcn_s_memrealtime();
+        if constexpr (ON) {
+            dst = p;
+            for (int i = 0; i < 16; ++i) acc[i] = 0;
+            prev = __builtin_amdgcn_s_memrealtime();
+        }
     }
     __device__ __forceinline__ void mark(int i) {
-        if (dst) {
+        if constexpr (ON) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             acc[i] += now - prev;
             prev = now;
         }
     }
     __device__ __forceinline__ void flush() {
-        if (dst && (threadIdx.x & 63) == 0)
-            for (int i = 0; i < 8; ++i) dst[i] = acc[i];
+        if constexpr (ON) {
+            if ((threadIdx.x & 63) == 0)
+                for (int i = 0; i < 16; ++i) dst[i] = acc[i];
+        }
     }
 };
 
-template <int D, bool CENTERED>
+template <int D, bool CENTERED, bool TRACE>
 __global__ __launch_bounds__(kLoopWaves * 64) void mp_loop_h2_kernel(const tspgnn_mp_loop_args a) {
     constexpr int TPG = D / 16, NT4 = D / 4, KBH = D / 32;
     constexpr int LAYER_BYTES = 2 * D * D * 2 + D * 4;   // { hi, lo, bias } of one MLP layer
@@ -195,8 +203,8 @@ __global__ __launch_bounds__(kLoopWaves * 64) void mp_loop_h2_kernel(const tspgn
     float wit = 0.f;
     unsigned vmin = 0xffffffffu;
     if (role == 0) return;
-    LoopTrace tr;
-    tr.begin(a.trace ? a.trace + ((size_t)blockIdx.x * kLoopWaves + wave) * 8 : nullptr);
+    LoopTrace<TRACE> tr;   // (a compile-time variant: its sixteen scalar registers are not free in the production kernel)
+    tr.begin(a.trace + ((size_t)blockIdx.x * kLoopWaves + wave) * 16);
 
     // LayerNorm parameters of this workgroup's cell, rows [g_i, b_i, g_j, b_j, g_f, b_f, g_o, b_o, g_s, b_s]; the gates
     // i, f, o feed sigmoids only: gamma / beta times -log2(e), forget bias folded into b_f (as lnlstm_mlp_fwd_h2_kernel)
@@ -258,6 +266,44 @@ __global__ __launch_bounds__(kLoopWaves * 64) void mp_loop_h2_kernel(const tspgn
         if (nt > 2) load_state(std::integral_constant<int, 2>{});
         if (nt > 3) load_state(std::integral_constant<int, 3>{});
 
+        // The row-sum share's edge lists never change: up to 2 passes of 4 vertices (16 lanes each) x 48 edge ids wait in
+        // LDS behind the weights (a share of more vertices, or a vertex of more than 48 edges, takes the general loop).
+        constexpr int kSharePasses = 2, kShareChunks = 3, kShareInts = kSharePasses * (kShareChunks + 1) * 64;
+        int* sh = reinterpret_cast<int*>(lds_mlp + (size_t)L * LAYER_BYTES) + wave * kShareInts;   // [pass][chunk | cnt][64]
+        bool share_fast = sv1 - sv0 <= 4 * kSharePasses;
+        int sh_mx[kSharePasses];
+#pragma unroll
+        for (int q = 0; q < kSharePasses; ++q) {
+            const int v = sv0 + 4 * q + (lane >> 4);
+            const int vv = v < sv1 ? v : (sv1 > sv0 ? sv1 - 1 : 0);
+            const int beg = sv1 > sv0 ? a.rowptr[vv] : 0;
+            const int cnt = sv1 > sv0 ? a.rowptr[vv + 1] - beg : 0;
+            int mx = cnt;
+            mx = max(mx, __shfl_xor(mx, 16));
+            mx = max(mx, __shfl_xor(mx, 32));
+            sh_mx[q] = __builtin_amdgcn_readfirstlane(mx);
+            if (sh_mx[q] > 16 * kShareChunks) share_fast = false;
+#pragma unroll
+            for (int ch = 0; ch < kShareChunks; ++ch)
+                sh[(q * (kShareChunks + 1) + ch) * 64 + lane] =
+                    (ch * 16 + (lane & 15) < cnt && ch * 16 < 16 * kShareChunks) ? a.eid[beg + ch * 16 + (lane & 15)] : 0;
+            sh[(q * (kShareChunks + 1) + kShareChunks) * 64 + lane] = cnt;
+        }
+        // The tiles' gather offsets into the projected messages (both endpoints of the lane's edge row) wait there too: the
+        // tile then starts with an LDS read instead of a dependent global round trip (uv -> address -> gather).
+        unsigned* zoff = reinterpret_cast<unsigned*>(lds_mlp + (size_t)L * LAYER_BYTES) + kLoopWaves * kShareInts +
+                         wave * (kLoopEdgeTiles * 2 * 64);
+#pragma unroll
+        for (int i = 0; i < kLoopEdgeTiles; ++i) {
+            if (i < nt) {
+                const int rl = lane & 15, g = lane >> 4;
+                const int2 ends = uv[row0[i] + (rl < nvalid[i] ? rl : 0)];
+                zoff[(i * 2 + 0) * 64 + lane] = h2_zx_row<D>((unsigned)ends.x, g);
+                zoff[(i * 2 + 1) * 64 + lane] = h2_zx_row<D>((unsigned)ends.y, g);
+            }
+        }
+        // (each wavefront reads back only what it wrote itself: LDS operations of one wavefront complete in order)
+
         for (int t = 0; t < T; ++t) {
             const int p = t & 1;
             const bool last = t == T - 1;
@@ -270,34 +316,67 @@ __global__ __launch_bounds__(kLoopWaves * 64) void mp_loop_h2_kernel(const tspgn
                 wait_ge(cnt_msg(ga, p), (unsigned)(((t + 1) >> 1) * net_a), dead, a.status);
                 tr.mark(0);
                 const int sub = lane >> 4, c = lane & 15;
-                for (int vb = sv0; vb < sv1; vb += 4) {
-                    const int v = vb + sub;
-                    const bool on = v < sv1;
-                    const int vv = on ? v : sv1 - 1;
-                    const int beg = a.rowptr[vv], cnt = a.rowptr[vv + 1] - beg;
-                    int mx = cnt;
-                    mx = max(mx, __shfl_xor(mx, 16));
-                    mx = max(mx, __shfl_xor(mx, 32));
-                    f32x4 s[4];
+                if (share_fast) {
+                    // edge ids resident (sh_e): per pass and 16-edge chunk one batch of 16 write-through loads in flight
+                    auto pass = [&](auto Q) {
+                        constexpr int q = decltype(Q)::value;
+                        const int v = sv0 + 4 * q + sub;
+                        const int cnt = sh[(q * (kShareChunks + 1) + kShareChunks) * 64 + lane];
+                        f32x4 s[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    for (int base = 0; base < mx; base += 16) {
-                        const int my_e = (base + c < cnt) ? a.eid[beg + base + c] : 0;
+                        for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int h8 = 0; h8 < 16; h8 += 8) {
-                            f32x4 x[8];
+                        for (int ch = 0; ch < kShareChunks; ++ch) {
+                            if (ch * 16 < sh_mx[q]) {   // (uniform)
 #pragma unroll
-                            for (int kk = 0; kk < 8; ++kk) {
-                                const int e = __shfl(my_e, (lane & 48) + h8 + kk);
-                                x[kk] = ld4wt(r_msg_in, ((unsigned)e * D + c * 4) * 4u);
+                                for (int h8 = 0; h8 < 16; h8 += 8) {
+                                    f32x4 x[8];
+#pragma unroll
+                                    for (int kk = 0; kk < 8; ++kk) {
+                                        const int e = sh[(q * (kShareChunks + 1) + ch) * 64 + (lane & 48) + h8 + kk];
+                                        x[kk] = ld4wt(r_msg_in, ((unsigned)e * D + c * 4) * 4u);
+                                    }
+#pragma unroll
+                                    for (int kk = 0; kk < 8; ++kk)
+                                        if (ch * 16 + h8 + kk < cnt) s[kk & 3] += x[kk];
+                                }
                             }
-#pragma unroll
-                            for (int kk = 0; kk < 8; ++kk)
-                                if (base + h8 + kk < cnt) s[kk & 3] += x[kk];   // ((h8 + kk) & 3 == kk & 3)
                         }
+                        const f32x4 tot = (s[0] + s[1]) + (s[2] + s[3]);
+                        if (v < sv1) st4wt(r_vagg, ((unsigned)v * D + c * 4) * 4u, tot);
+                    };
+                    pass(std::integral_constant<int, 0>{});
+                    if (sv0 + 4 < sv1) pass(std::integral_constant<int, 1>{});
+                } else {
+                    for (int vb = sv0; vb < sv1; vb += 4) {
+                        const int v = vb + sub;
+                        const bool on = v < sv1;
+                        const int vv = on ? v : sv1 - 1;
+                        const int beg = a.rowptr[vv], cnt = a.rowptr[vv + 1] - beg;
+                        int mx = cnt;
+                        mx = max(mx, __shfl_xor(mx, 16));
+                        mx = max(mx, __shfl_xor(mx, 32));
+                        f32x4 s[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int base = 0; base < mx; base += 16) {
+                            const int my_e = (base + c < cnt) ? a.eid[beg + base + c] : 0;
+#pragma unroll
+                            for (int h8 = 0; h8 < 16; h8 += 8) {
+                                f32x4 x[8];
+#pragma unroll
+                                for (int kk = 0; kk < 8; ++kk) {
+                                    const int e = __shfl(my_e, (lane & 48) + h8 + kk);
+                                    x[kk] = ld4wt(r_msg_in, ((unsigned)e * D + c * 4) * 4u);
+                                }
+#pragma unroll
+                                for (int kk = 0; kk < 8; ++kk)
+                                    if (base + h8 + kk < cnt) s[kk & 3] += x[kk];   // ((h8 + kk) & 3 == kk & 3)
+                            }
+                        }
+                        const f32x4 tot = (s[0] + s[1]) + (s[2] + s[3]);   // the order of csr_rowsum_kernel's lane-group butterfly
+                        if (on) st4wt(r_vagg, ((unsigned)v * D + c * 4) * 4u, tot);
                     }
-                    const f32x4 tot = (s[0] + s[1]) + (s[2] + s[3]);   // the order of csr_rowsum_kernel's lane-group butterfly
-                    if (on) st4wt(r_vagg, ((unsigned)v * D + c * 4) * 4u, tot);
                 }
                 drain_stores();
                 arrive(cnt_vagg(ga, p), (unsigned)(sv1 - sv0));
@@ -311,91 +390,200 @@ __global__ __launch_bounds__(kLoopWaves * 64) void mp_loop_h2_kernel(const tspgn
             if (t > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             tr.mark(3);
 
-            auto tile_step = [&](auto I) {
-                constexpr int i = decltype(I)::value;
+            // each stage as a function of the tiles (compile-time indices) it runs on together
+            const _Float16* Kl = lds_w + total;
+            auto coords = [&](int tile, int& rl, int& g, bool& valid, unsigned& rc, const float*& zu, const float*& zv) {
                 const int l = opaque_lane();
-                const int rl = l & 15, g = l >> 4;
-                const bool valid = rl < nvalid[i];
-                const unsigned rc = (unsigned)(row0[i] + (valid ? rl : 0));
-                const int2 ends = uv[rc];
-                const float* zu = zx + h2_zx_row<D>((unsigned)ends.x, g);
-                const float* zv = zx + h2_zx_row<D>((unsigned)ends.y, g);
-                const _Float16* Kl = lds_w + total;
-                {   // f
-                    f32x4 z[TPG];
+                rl = l & 15;
+                g = l >> 4;
+                valid = rl < nvalid[tile];
+                rc = (unsigned)(row0[tile] + (valid ? rl : 0));
+                zu = zx + zoff[(tile * 2 + 0) * 64 + l];
+                zv = zx + zoff[(tile * 2 + 1) * 64 + l];
+            };
+            // GATE: 0 = f (column tiles 2 TPG..), 1 = o (3 TPG..)
+            auto stage_fo = [&](auto GATE, auto... Is) {
+                constexpr int gate = decltype(GATE)::value;
+                constexpr int NP = sizeof...(Is);
+                constexpr int ti[NP] = {decltype(Is)::value...};
+                constexpr int T0 = gate == 0 ? 2 * TPG : 3 * TPG;
+                f32x4 z[NP][TPG];
+                int rl = 0, g = 0;
 #pragma unroll
-                    for (int q = 0; q < TPG; ++q) z[q] = ld4(zu + (2 * TPG + q) * 256);
+                for (int n = 0; n < NP; ++n) {
+                    bool valid;
+                    unsigned rc;
+                    const float *zu, *zv;
+                    coords(ti[n], rl, g, valid, rc, zu, zv);
 #pragma unroll
-                    for (int q = 0; q < TPG; ++q) z[q] += ld4(zv + (2 * TPG + q) * 256);
+                    for (int q = 0; q < TPG; ++q) z[n][q] = ld4(zu + (T0 + q) * 256);
 #pragma unroll
-                    for (int kb = 0; kb < KBH; ++kb)
-                        kblock_h2_sub<NT4, 2 * TPG, TPG>(z, lds_w, Kl, kb, g, rl, hh[i][kb], hl[i][kb]);
-                    lstm_stage_f<D, SWAP, CENTERED, true>(z, cst[i], lds_ln, g, kH2GateEps, &vmin);
+                    for (int q = 0; q < TPG; ++q) z[n][q] += ld4(zv + (T0 + q) * 256);
                 }
-                {   // i, j
-                    f32x4 z[2 * TPG];
 #pragma unroll
-                    for (int q = 0; q < 2 * TPG; ++q) z[q] = ld4(zu + q * 256);
+                for (int kb = 0; kb < KBH; ++kb) {
+                    f16x8 bh[NP], bl[NP];
 #pragma unroll
-                    for (int q = 0; q < 2 * TPG; ++q) z[q] += ld4(zv + q * 256);
-#pragma unroll
-                    for (int kb = 0; kb < KBH; ++kb)
-                        kblock_h2_sub<NT4, 0, 2 * TPG>(z, lds_w, Kl, kb, g, rl, hh[i][kb], hl[i][kb]);
-                    lstm_stage_ij<D, SWAP, CENTERED, true>(z, cst[i], lds_ln, g, kH2GateEps, &vmin);
+                    for (int n = 0; n < NP; ++n) {
+                        bh[n] = hh[ti[n]][kb];
+                        bl[n] = hl[ti[n]][kb];
+                    }
+                    kblock_h2_multi<NT4, T0, TPG, NP>(z, lds_w, Kl, kb, g, rl, bh, bl);
                 }
-                f32x4 hn[TPG];
-                {   // o
-                    f32x4 z[TPG];
 #pragma unroll
-                    for (int q = 0; q < TPG; ++q) z[q] = ld4(zu + (3 * TPG + q) * 256);
+                for (int n = 0; n < NP; ++n) {
+                    if constexpr (gate == 0) {
+                        lstm_stage_f<D, SWAP, CENTERED, true>(z[n], cst[ti[n]], lds_ln, g, kH2GateEps, &vmin);
+                    } else {
+                        // h' leaves the stage as the next GEMMs' operand pieces (resident); only the last step needs it as fp32
+                        f32x4 hn[TPG];
+                        lstm_stage_o<D, SWAP, CENTERED, true>(z[n], cst[ti[n]], lds_ln, g, hn, kH2GateEps, &vmin);
+                        if (last) {
+                            bool valid;
+                            unsigned rc;
+                            const float *zu, *zv;
+                            coords(ti[n], rl, g, valid, rc, zu, zv);
+                            if (valid) {
+                                float* hd = a.e_h + (size_t)rc * D + g * 4;
+                                float* cd = a.e_c + (size_t)rc * D + g * 4;
 #pragma unroll
-                    for (int q = 0; q < TPG; ++q) z[q] += ld4(zv + (3 * TPG + q) * 256);
+                                for (int q = 0; q < TPG; ++q) {
+                                    st4(hd + q * 16, hn[q]);
+                                    st4(cd + q * 16, cst[ti[n]][q]);
+                                }
+                            }
+                        } else {
 #pragma unroll
-                    for (int kb = 0; kb < KBH; ++kb)
-                        kblock_h2_sub<NT4, 3 * TPG, TPG>(z, lds_w, Kl, kb, g, rl, hh[i][kb], hl[i][kb]);
-                    lstm_stage_o<D, SWAP, CENTERED, true>(z, cst[i], lds_ln, g, hn, kH2GateEps, &vmin);
-                }
-                if (last) {
-                    if (valid) {
-                        float* hd = a.e_h + (size_t)rc * D + g * 4;
-                        float* cd = a.e_c + (size_t)rc * D + g * 4;
+                            for (int kb = 0; kb < KBH; ++kb) {
+                                float x[8];
 #pragma unroll
-                        for (int q = 0; q < TPG; ++q) {
-                            st4(hd + q * 16, hn[q]);
-                            st4(cd + q * 16, cst[i][q]);
+                                for (int j = 0; j < 8; ++j) x[j] = hn[2 * kb + (j >> 2)][j & 3];
+                                split2w(x, hh[ti[n]][kb], hl[ti[n]][kb], wit);
+                            }
                         }
-                    }
-                } else {
-#pragma unroll
-                    for (int kb = 0; kb < KBH; ++kb) {
-                        float x[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) x[j] = hn[2 * kb + (j >> 2)][j & 3];
-                        split2w(x, hh[i][kb], hl[i][kb], wit);
-                    }
-                    if (L > 0) {
-                        const unsigned mask = a.e_relu_mask;
-                        {
-                            const _Float16* wh = reinterpret_cast<const _Float16*>(lds_mlp);
-                            const float* bias = reinterpret_cast<const float*>(lds_mlp + 2 * D * D * 2);
-                            dense_layer_h2_pieces<D>(hh[i], hl[i], hn, wh, wh + D * D, bias, mask & 1u, g, rl);
-                        }
-                        for (int ly = 1; ly < L; ++ly) {
-                            const _Float16* wh = reinterpret_cast<const _Float16*>(lds_mlp + (size_t)ly * LAYER_BYTES);
-                            const float* bias = reinterpret_cast<const float*>(lds_mlp + (size_t)ly * LAYER_BYTES + 2 * D * D * 2);
-                            dense_layer_h2_loop<D>(hn, wh, wh + D * D, bias, (mask >> ly) & 1u, g, rl, wit);
-                        }
-                    }
-                    if (valid) {
-#pragma unroll
-                        for (int q = 0; q < TPG; ++q) st4wt(r_msg_out, (rc * D + g * 4 + q * 16) * 4u, hn[q]);
                     }
                 }
             };
-            if (nt > 0) tile_step(std::integral_constant<int, 0>{});
-            if (nt > 1) tile_step(std::integral_constant<int, 1>{});
-            if (nt > 2) tile_step(std::integral_constant<int, 2>{});
-            if (nt > 3) tile_step(std::integral_constant<int, 3>{});
+            auto stage_ij = [&](auto I) {
+                constexpr int i = decltype(I)::value;
+                int rl, g;
+                bool valid;
+                unsigned rc;
+                const float *zu, *zv;
+                coords(i, rl, g, valid, rc, zu, zv);
+                f32x4 z[2 * TPG];
+#pragma unroll
+                for (int q = 0; q < 2 * TPG; ++q) z[q] = ld4(zu + q * 256);
+#pragma unroll
+                for (int q = 0; q < 2 * TPG; ++q) z[q] += ld4(zv + q * 256);
+#pragma unroll
+                for (int kb = 0; kb < KBH; ++kb)
+                    kblock_h2_sub<NT4, 0, 2 * TPG>(z, lds_w, Kl, kb, g, rl, hh[i][kb], hl[i][kb]);
+                lstm_stage_ij<D, SWAP, CENTERED, true>(z, cst[i], lds_ln, g, kH2GateEps, &vmin);
+            };
+            // the message MLP on h' (its pieces) + the message stores
+            auto stage_out = [&](auto... Is) {
+                constexpr int NP = sizeof...(Is);
+                constexpr int ti[NP] = {decltype(Is)::value...};
+                int rl = 0, g = 0;
+                bool valid[NP];
+                unsigned rc[NP];
+#pragma unroll
+                for (int n = 0; n < NP; ++n) {
+                    const float *zu, *zv;
+                    coords(ti[n], rl, g, valid[n], rc[n], zu, zv);
+                }
+                f32x4 hn[NP][TPG];
+                const unsigned mask = a.e_relu_mask;
+                for (int ly = 0; ly < L; ++ly) {
+                    const _Float16* wh = reinterpret_cast<const _Float16*>(lds_mlp + (size_t)ly * LAYER_BYTES);
+                    const float* bias = reinterpret_cast<const float*>(lds_mlp + (size_t)ly * LAYER_BYTES + 2 * D * D * 2);
+                    f32x4 acc[NP][TPG];
+#pragma unroll
+                    for (int n = 0; n < NP; ++n) {
+#pragma unroll
+                        for (int q = 0; q < TPG; ++q) acc[n][q] = ld4(bias + q * 16 + g * 4);
+                    }
+#pragma unroll
+                    for (int kb = 0; kb < KBH; ++kb) {
+                        f16x8 bh[NP], bl[NP];
+#pragma unroll
+                        for (int n = 0; n < NP; ++n) {
+                            if (ly == 0) {   // h' arrives as the pieces just made (the next step's GEMM operand)
+                                bh[n] = hh[ti[n]][kb];
+                                bl[n] = hl[ti[n]][kb];
+                            } else {
+                                float x[8];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) x[j] = hn[n][2 * kb + (j >> 2)][j & 3];
+                                split2w(x, bh[n], bl[n], wit);
+                            }
+                        }
+                        kblock_h2_multi<TPG, 0, TPG, NP>(acc, wh, wh + D * D, kb, g, rl, bh, bl);
+                    }
+                    const bool relu = (mask >> ly) & 1u;
+                    const f32x2 inv = {kH2InvScale, kH2InvScale};
+#pragma unroll
+                    for (int n = 0; n < NP; ++n) {
+#pragma unroll
+                        for (int q = 0; q < TPG; ++q) {
+                            if (relu) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[n][q][r] = fmaxf(acc[n][q][r], 0.f);
+                            }
+                            hn[n][q].lo = acc[n][q].lo * inv;
+                            hn[n][q].hi = acc[n][q].hi * inv;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NP; ++n) {
+                    if (valid[n]) {
+#pragma unroll
+                        for (int q = 0; q < TPG; ++q) st4wt(r_msg_out, (rc[n] * D + g * 4 + q * 16) * 4u, hn[n][q]);
+                    }
+                }
+            };
+            // The resident tiles are stepped in PAIRS where the register budget allows (LOOP_PAIR: bit 0 the f stage, bit 1
+            // the o stage, bit 2 the message MLP): the stages of two tiles then share every weight fragment
+            // (kblock_h2_multi: half the LDS reads per tile, two independent MFMA chains per fragment, two LayerNorm /
+            // transcendental chains to interleave).  A wavefront is otherwise bound by the LATENCY of its own dependent
+            // chains (~10 us per tile against ~4 us of issue), which two wavefronts per SIMD only half hide.  The (i, j)
+            // stage stays one tile at a time: 32 accumulator registers per tile.
+            auto pair_step = [&](auto I0, auto I1) {
+                constexpr std::integral_constant<int, 0> F{};
+                constexpr std::integral_constant<int, 1> O{};
+                if constexpr (LOOP_PAIR & 1) stage_fo(F, I0, I1);
+                else { stage_fo(F, I0); stage_fo(F, I1); }
+                tr.mark(8);
+                stage_ij(I0);
+                stage_ij(I1);
+                tr.mark(9);
+                if constexpr (LOOP_PAIR & 2) stage_fo(O, I0, I1);
+                else { stage_fo(O, I0); stage_fo(O, I1); }
+                tr.mark(10);
+                if (!last && L > 0) {
+                    if constexpr (LOOP_PAIR & 4) stage_out(I0, I1);
+                    else { stage_out(I0); stage_out(I1); }
+                }
+                tr.mark(12);
+            };
+            auto single_step = [&](auto I0) {
+                constexpr std::integral_constant<int, 0> F{};
+                constexpr std::integral_constant<int, 1> O{};
+                stage_fo(F, I0);
+                tr.mark(8);
+                stage_ij(I0);
+                tr.mark(9);
+                stage_fo(O, I0);
+                tr.mark(10);
+                if (!last && L > 0) stage_out(I0);
+                tr.mark(12);
+            };
+            if (nt >= 2) pair_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            else single_step(std::integral_constant<int, 0>{});
+            if (nt >= 4) pair_step(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+            else if (nt == 3) single_step(std::integral_constant<int, 2>{});
             tr.mark(4);
             if (!last) {
                 drain_stores();
@@ -585,12 +773,15 @@ extern "C" int tspgnn_mp_loop_h2(const tspgnn_mp_loop_args* args, int d, void* s
     constexpr int D = 64;
     const size_t head = (10 * D + 4) * sizeof(float);
     const size_t layer = 2 * D * D * 2 + D * 4;
-    const size_t edge_bytes = (size_t)2 * D * 4 * D * 2 + a.e_mlp_layers * layer;
+    const size_t edge_bytes = (size_t)2 * D * 4 * D * 2 + a.e_mlp_layers * layer + (size_t)kLoopWaves * 2 * 4 * 64 * 4 +
+                              (size_t)kLoopWaves * kLoopEdgeTiles * 2 * 64 * 4;   // + the row-sum shares' edge lists + gather offsets
     const size_t vert_k = (size_t)2 * 2 * D * 4 * D * 2, vert_m = a.v_mlp_layers * layer + (size_t)2 * D * 4 * D * 2;
     size_t lds_bytes = edge_bytes > vert_k ? edge_bytes : vert_k;
     if (vert_m > lds_bytes) lds_bytes = vert_m;
     lds_bytes += head;
-    void (*fn)(const tspgnn_mp_loop_args) = a.z_centered ? &mp_loop_h2_kernel<D, true> : &mp_loop_h2_kernel<D, false>;
+    void (*fn)(const tspgnn_mp_loop_args) =
+        a.trace ? (a.z_centered ? &mp_loop_h2_kernel<D, true, true> : &mp_loop_h2_kernel<D, false, true>)
+                : (a.z_centered ? &mp_loop_h2_kernel<D, true, false> : &mp_loop_h2_kernel<D, false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail((int)e, "mp_loop_h2: hipFuncSetAttribute(%d B): %s", (int)lds_bytes, hipGetErrorString(e));
     fn<<<a.grid, kLoopWaves * 64, lds_bytes, as_stream(stream)>>>(a);

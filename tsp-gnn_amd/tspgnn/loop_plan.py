@@ -77,9 +77,21 @@ def _groups(e_start, v_start):
     return groups
 
 
-def build(e_start, v_start, grid=256, vertex_wgs=None):
+def max_edge_tiles():
+    """Largest number of resident tiles per edge wavefront a batch may need for the one-launch loop to be chosen.  The
+    kernel holds up to EDGE_TILES = 4, but a wavefront works through its tiles one after the other at ~10 us each (two
+    wavefronts per SIMD hide each other's stalls, not their own), so the loop's step time is set by the LONGEST wavefront:
+    measured on MI355X at n = 40 (profiles/r05_loop_vs_steps.txt), <= 3 tiles per wavefront (<= 96 instances) beats the
+    stepwise launches by 4-24 %, 4 tiles (C2's 128 instances) lose 10 %.  TSPGNN_LOOP_MAX_TILES=4 takes every batch that
+    fits (tests, A/B runs)."""
+    env = os.environ.get("TSPGNN_LOOP_MAX_TILES")
+    return max(1, min(EDGE_TILES, int(env))) if env else 3
+
+
+def build(e_start, v_start, grid=256, vertex_wgs=None, max_tiles=None):
     """-> (plan int32[grid * WAVES * DESC], n_groups) or None when the batch does not fit the resident design (more than
-    4 edge tiles per wavefront, i.e. beyond ~115 k edge rows on 256 CUs) or has no edges."""
+    ``max_tiles`` -- default max_edge_tiles() -- edge tiles per wavefront; 4 = ~115 k edge rows on 256 CUs is what the
+    kernel holds) or has no edges."""
     e_start = np.asarray(e_start, dtype=np.int64)
     v_start = np.asarray(v_start, dtype=np.int64)
     if grid < N_XCD * 2 or grid % N_XCD != 0 or e_start[-1] == 0:
@@ -87,10 +99,14 @@ def build(e_start, v_start, grid=256, vertex_wgs=None):
     if vertex_wgs is None:
         env = os.environ.get("TSPGNN_LOOP_VWG")
         vertex_wgs = int(env) if env else None
-    key = (e_start.tobytes(), v_start.tobytes(), grid, vertex_wgs)
+    if max_tiles is None:
+        max_tiles = max_edge_tiles()
+    key = (e_start.tobytes(), v_start.tobytes(), grid, vertex_wgs, max_tiles)
     if key in _cache:
         return _cache[key]
     out = _build(e_start, v_start, grid, vertex_wgs)
+    if out is not None and describe(out[0], grid)[2] > max_tiles:
+        out = None
     if len(_cache) > 64:
         _cache.clear()
     _cache[key] = out
@@ -173,12 +189,18 @@ def _build(e_start, v_start, grid, vertex_wgs):
                 d[10], d[11] = ga, gb
                 d[12], d[13] = n_a, (cnt - n_a if gb != ga else 0)
                 d[14], d[15], d[16] = vt[ga], vt[gb], et[ga]
-                first_in_group.setdefault(ga, []).append((b, w))
+                # (light = fewer tiles than the wavefront it shares a SIMD with: wavefronts w and w + 4)
+                first_in_group.setdefault(ga, []).append((b, w, cnt < base + 1 or extra == 0))
         # row-sum shares
         for gi in gs:
             owners = first_in_group.get(int(gi))
             if not owners:
                 return None
+            # the row-sum goes to the LIGHT wavefronts of the group where there are any: a SIMD holds 7 tiles as 4 + 3, and
+            # the 3-tile wavefront sums its share while its neighbour -- which then has none, and goes straight on to the
+            # next step -- works on its fourth tile
+            light = [(b, w) for b, w, is_light in owners if is_light]
+            owners = light if light else [(b, w) for b, w, _ in owners]
             v0, v1 = groups[gi][2], groups[gi][3]
             n = v1 - v0
             for k, (b, w) in enumerate(owners):
