@@ -346,7 +346,7 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTa
     };
     // z starts at 2^s * (its non-GEMM part); Zx is stored scaled by its producer (the f16x2 projection)
     auto init_acc = [&](f32x4 (&acc)[NT4], unsigned rc, bool live) {
-        if (uv != nullptr) {
+        if (uv != nullptr && live) {
             const int2 ends = uv[rc];
             const float* zu = Zx + h2_zx_row<D>((unsigned)ends.x, g);
             const float* zv = Zx + h2_zx_row<D>((unsigned)ends.y, g);
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTa
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] += ld4(zv + t * 256);
         } else if (zbias != nullptr) {
-            // (an idle wavefront of a lock-step round keeps z == 0: a variance of exactly 0 is not a row of the batch
-            // for the range guard, see ln_gate<..., TRACK>)
+            // (an idle wavefront of a lock-step round keeps z == 0 in EVERY mode -- it skips the GEMM, and a partial z is
+            // not a row of the batch: a variance of exactly 0 is ignored by the range guard, see ln_gate<..., TRACK>)
             const float sc = live ? zscale[rc] * kH2Scale : 0.f;
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] = ld4(zbias + t * 16 + g * 4) * sc;

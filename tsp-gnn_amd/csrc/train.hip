@@ -510,7 +510,10 @@ extern "C" int tspgnn_adam_clip_step_f32(float* theta, float* g, float* m, float
 }
 
 // ---------------------------------------------------------------- data-parallel bucket (Session.allreduce_grads)
-// bucket = [ grad (n floats) | tail: B_r, B_r*loss_r, B_r*acc_r, TP_r, FP_r, TN_r, FN_r, range flag_r ].  One launch each side
+// bucket = [ grad (n floats) | tail: B_r, B_r*loss_r, B_r*acc_r, TP_r, FP_r, TN_r, FN_r, guard bit 0, bit 1, bit 2 ] (the
+// bits of the rank's guard word as 0 / 1 floats, one slot each: their SUMS over the ranks keep each bit's meaning --
+// bit 0 an operand beyond fp16's range, bit 1 a gate row below the split's floor, bit 2 "this rank's variables were
+// assigned since the replicas were last made identical": Session.train_step).  One launch each side
 // of the one all-reduce of a training step: pack weights the rank's gradient and statistics by its batch
 // size, unpack divides by the reduced batch size -- on the device, so the step's two HIP graphs run back to back around
 // the collective -- and hands the (summed) range flag back to the guard word every rank's optimiser launch looks at.
@@ -519,13 +522,13 @@ __global__ __launch_bounds__(256) void bucket_pack_kernel(float* __restrict__ bu
                                                           const unsigned* __restrict__ flag) {
     if (with_grad)
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bucket[i] *= nb;
-    if (blockIdx.x == 0 && threadIdx.x < 8) {
+    if (blockIdx.x == 0 && threadIdx.x < 10) {
         const int k = threadIdx.x;
         float v = 0.f;
         if (k == 0) v = nb;
         else if (k < 3) v = stats ? nb * stats[k - 1] : 0.f;
         else if (k < 7) v = stats ? stats[k - 1] : 0.f;
-        else v = flag ? (float)flag[0] : 0.f;
+        else v = flag ? (float)((flag[0] >> (k - 7)) & 1u) : 0.f;
         bucket[n + k] = v;
     }
 }
@@ -539,7 +542,8 @@ __global__ __launch_bounds__(256) void bucket_unpack_kernel(float* __restrict__ 
         const int k = threadIdx.x;
         if (k >= 1 && k < 3 && stats) stats[k - 1] = bucket[n + k] * inv;
         if (k >= 3 && k < 7 && stats) stats[k - 1] = bucket[n + k];
-        if (k == 7 && flag) flag[0] = bucket[n + 7] != 0.f ? 1u : 0u;
+        if (k == 7 && flag)
+            flag[0] = (bucket[n + 7] != 0.f ? 1u : 0u) | (bucket[n + 8] != 0.f ? 2u : 0u) | (bucket[n + 9] != 0.f ? 4u : 0u);
     }
 }
 

@@ -191,6 +191,7 @@ class Session(object):
         self.process_group = process_group
         self._replicas_synced = False
         self._synced_assignments = -1
+        self._ever_synced = False     # data-parallel: the first train_step broadcasts unconditionally (train_step)
         self.last_range_bits = 0     # the f16x2 guard bits (1 overflow, 2 underflow) of the last flagged batch: diagnostics
 
     @property
@@ -363,6 +364,7 @@ class Session(object):
             graph.replay()
             return out
         replay.graph = graph
+        replay.batch = b    # the graph reads THIS batch's device buffers on every replay: they live as long as the closure does
         replay.range_exceeded = self.range_exceeded   # (synchronising) did a replay leave the f16x2 range? see run()
         return replay
 
@@ -477,7 +479,7 @@ class Session(object):
 
     # The data-parallel step.  The loss is a mean over the GLOBAL batch (model.py:157), so rank r's
     # gradient of its local mean counts with weight B_r / B.  Everything that must cross ranks rides in ONE bucket:
-    #   bucket = [ B_r * grad_r | B_r, B_r*loss_r, B_r*acc_r, TP_r, FP_r, TN_r, FN_r, range flag_r ]     (VariableStore.bucket)
+    #   bucket = [ B_r * grad_r | B_r, B_r*loss_r, B_r*acc_r, TP_r, FP_r, TN_r, FN_r, guard bits 0, 1, 2 ]  (VariableStore.bucket)
     # one all-reduce(sum) of it (RCCL over xGMI with the 'nccl' backend; 462 KB at d=64), then every rank divides by the
     # reduced B on the device: no host round trip, so the two HIP graphs of capture_train_step run back to back around
     # the collective.  The L2 term, the clip by the GLOBAL norm and Adam follow on the reduced gradient, identically
@@ -502,7 +504,9 @@ class Session(object):
             tail[1:3].copy_(stats[0:2])
             tail[1:3].mul_(nb)
             tail[3:7].copy_(stats[2:6])
-        tail[7:8].copy_(store.h2_guard()[0:1])   # f16x2 range flag: every rank must skip / repeat the step together
+        word = store.h2_guard()[0:1]             # guard bits, one slot each: every rank must skip / repeat the step together
+        for k in range(3):
+            tail[7 + k:8 + k].copy_((word >> k) & 1)
         return tail
 
     def _unpack_bucket(self, stats, with_grad):
@@ -519,7 +523,8 @@ class Session(object):
         if stats is not None:
             stats[0:2].copy_(tail[1:3] * inv)
             stats[2:6].copy_(tail[3:7])
-        store.h2_guard()[0:1].copy_(tail[7:8] != 0)
+        store.h2_guard()[0:1].copy_((tail[7:8] != 0).to(torch.int32) + 2 * (tail[8:9] != 0).to(torch.int32)
+                                    + 4 * (tail[9:10] != 0).to(torch.int32))
 
     def allreduce_grads(self, local_batch, stats=None):
         """One all-reduce of [gradient | batch size, statistics]; afterwards ``store.grad`` holds the gradient of
@@ -616,23 +621,46 @@ class Session(object):
     def train_step(self, feed):
         """One ``sess.run(train_step)``: forward, backward, (all-reduce), L2 + clip + Adam.
 
-        The f16x2 range flag is this call's business, whoever the caller is: it is cleared first (a flag left behind by an
+        The guard word is this call's business, whoever the caller is: it is cleared first (a flag left behind by an
         earlier, unchecked forward() must not make the optimiser kernel skip this step -- and every later one), read
         once after the optimiser launch (one blocking 4-byte read per eager step), and a flagged step -- which the
-        optimiser kernel skipped on the device -- is repeated on bf16x3 with the host mirror of the step counter put
-        back.  In a data-parallel session the flag every rank reads is the all-reduced one, so all ranks repeat
-        together."""
-        self._sync_replicas_once()
+        optimiser kernel skipped on the device -- is repeated: on bf16x3 when an f16x2 launch left its range (bits 0 / 1),
+        after a broadcast of rank 0's variables when some rank's variables were assigned since the replicas were last
+        made identical (bit 2).  In a data-parallel session the word every rank reads is the all-reduced one, so all ranks
+        repeat together -- and the "do we need to re-synchronise?" question rides in the step's ONE all-reduce instead of
+        a collective and a host round trip of its own before every step: the price is one wasted forward +
+        backward in the step after a checkpoint restore."""
         on_gpu = self.device.type == "cuda"
-        h2 = on_gpu and self.model["gnn"].active_arith() == "h2"   # (only f16x2 launches raise the flag: no read-back without)
+        dp = self.world_size > 1
+        if dp and not self._ever_synced:
+            # the session's first training step: every rank is here for the first time, the broadcast needs no agreement
+            self.broadcast_variables(0)
+            self._ever_synced = True
+        need = dp and (not self._replicas_synced or self._synced_assignments != self.store.assignments)
+        h2 = on_gpu and self.model["gnn"].active_arith() == "h2"   # (only f16x2 launches raise bits 0 / 1)
         if on_gpu:
-            self.store.h2_guard()[0:1].zero_()     # always: the optimiser kernel skips on a non-zero word whatever set it
+            self.store.h2_guard()[0:1].fill_(4 if need else 0)     # always: the optimiser kernel skips on a non-zero word
         out = self._train_step_once(feed)
-        if h2 and self.range_exceeded():
+        bits = self._guard_word() if on_gpu and (h2 or dp) else 0
+        if bits & 4:   # skipped everywhere: some replica had been assigned to.  Make them identical, then take the step.
+            self._adam["step"] -= 1
+            self.broadcast_variables(0)
+            out = self._train_step_once(feed)
+            bits = self._guard_word() if h2 else 0
+        if bits & 3:
+            self.last_range_bits = bits & 3
             self._adam["step"] -= 1     # (Adam skipped the update on the device: theta, m, v and t are untouched)
             with self.model["gnn"].forced_off_h2():
                 out = self._train_step_once(feed)
         return out
+
+    def _guard_word(self):
+        """The guard word (VariableStore.h2_guard()[0]) after a step, cleared if set: one blocking 4-byte read."""
+        guard = self.store.h2_guard()
+        w = int(guard[0].item())
+        if w:
+            guard[0:1].zero_()
+        return w
 
     def _train_step_once(self, feed):
         out = self.loss_and_grads(feed)
@@ -687,19 +715,33 @@ class Session(object):
         inflight = []                         # [(event, pinned words)] of the last LAG replays, oldest first
         count = [0]
 
+        dead = [None]    # once the guard has fired this closure is finished: graph A holds the f16x2 kernels
+
         def replay():
+            if dead[0] is not None:
+                raise RuntimeError(dead[0])
             if len(inflight) >= LAG:
                 ev, words = inflight.pop(0)
                 ev.synchronize()
-                if (int(words[0]) & 3) or int(words[1]) >= store.H2_WEIGHT_LIMIT_BITS:
+                act, weight = int(words[0]) & 3, int(words[1]) >= store.H2_WEIGHT_LIMIT_BITS
+                if act or weight:
                     torch.cuda.synchronize()
-                    self.last_range_bits = int(words[0]) & 3
+                    self.last_range_bits = act
                     gnn._h2_off_at = store.assignments
                     store.h2_guard().zero_()
                     del inflight[:]
                     self._adam["step"] = int(self._adam["t"].item())   # the device counter did not count the skipped steps
-                    raise RuntimeError("f16x2 range exceeded during replayed training steps (the affected steps were "
-                                       "not applied): capture_train_step() again -- it will run on bf16x3")
+                    if act:
+                        why = ("an activation left the fp16 range of the f16x2 split (guard bits %d): that step and the "
+                               "replays after it were skipped by the optimiser kernel, the variables are those of the "
+                               "last clean step" % act)
+                    else:
+                        why = ("a weight passed half the fp16 range of the f16x2 packing: the steps so far WERE applied, "
+                               "the next ones would not be safe")
+                    dead[0] = ("f16x2 range exceeded during replayed training steps: %s.  This replay closure is finished "
+                               "(its graph holds the f16x2 kernels): call capture_train_step() again -- it will run on "
+                               "bf16x3" % why)
+                    raise RuntimeError(dead[0])
             ga.replay()
             self.allreduce_grads(b.B, out["stats"])   # device-side only: no host sync between the two graphs
             gb.replay()

@@ -108,7 +108,8 @@ class BatchPrefetcher(object):
                 else:
                     b, ev = self.sess.prepare(self._feed(t), remember_adjacency=False), None
                 with self._lock:
-                    self._ready[seq] = (b, ev)
+                    if self._exhausted_at is None or seq < self._exhausted_at:   # (not after close())
+                        self._ready[seq] = (b, ev)
                     self._lock.notify_all()
         except BaseException as exc:   # handed to the consumer: a dead worker must not look like an empty dataset
             with self._lock:
@@ -118,6 +119,28 @@ class BatchPrefetcher(object):
                 if self._error is None or at < self._error[0]:
                     self._error = (at, exc)
                 self._lock.notify_all()
+
+    def close(self):
+        """Stop early: the workers end after the batch they are packing, batches already uploaded are dropped (their GPU
+        memory returns to the allocator).  Called by ``__del__`` and on leaving a ``with`` block; a consumer that abandons
+        the iterator without it would leave the workers blocked on a full queue for the life of the process."""
+        with self._lock:
+            if self._exhausted_at is None or self._exhausted_at > self._next_out:
+                self._exhausted_at = self._next_out
+            self._ready.clear()
+            self._lock.notify_all()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __iter__(self):
         return self
@@ -133,6 +156,7 @@ class BatchPrefetcher(object):
                 if self._error is not None and self._error[0] <= self._next_out:
                     err, self._error = self._error[1], None
                     self._exhausted_at = self._next_out      # (the remaining workers stop)
+                    self._ready.clear()                      # batches packed behind the failed one: their GPU memory goes back
                     self._lock.notify_all()
                     raise RuntimeError("BatchPrefetcher worker failed") from err
                 if self._exhausted_at is not None and self._next_out >= self._exhausted_at:

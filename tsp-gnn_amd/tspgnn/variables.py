@@ -168,7 +168,7 @@ class VariableStore(object):
     # -- gradients (same flat layout as theta: one buffer to all-reduce, clip and apply) ----
     # ``bucket`` = [grad (theta's layout) | BUCKET_TAIL floats]: the data-parallel step appends the local batch size
     # and the batch statistics to the gradient so that ONE all-reduce carries everything (Session.allreduce_grads).
-    BUCKET_TAIL = 8
+    BUCKET_TAIL = 10   # B_r, B_r*loss, B_r*acc, TP, FP, TN, FN, guard bits 0 / 1 / 2 (csrc/train.hip, bucket_pack_kernel)
 
     def zero_grad(self):
         if self.grad is None:
