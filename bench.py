@@ -153,6 +153,10 @@ def main():
     ap.add_argument("--serve-workers", type=int, default=1,
                     help="packer threads of the serve leg's BatchPrefetcher (measured: one keeps up at C2 / C4 and a second one's "
                          "uploads disturb the forward -- 1.51-1.55 vs 1.56-1.89 ms per C2 batch, 11.3-11.6 vs 16.5-18.2 ms at C4)")
+    ap.add_argument("--plumbing", action="store_true",
+                    help="no GPU: the launcher / rendezvous / collective / JSON-contract path only (Session(device='cpu'), gloo; "
+                         "the timed step is the data-parallel bucket's pack -> all-reduce -> unpack).  What the CPU test suite "
+                         "runs at --gpus 8; never a performance number.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (bounded sample)")
     args = ap.parse_args()
@@ -177,6 +181,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if args.plumbing:
+        return plumbing_main(args, rank, world)
     # one rank per GPU; (ranks wrap around the visible devices only so that the N>1 path can be exercised with the
     # gloo backend on a single-GPU box: TSPGNN_DIST_BACKEND=gloo, see tests/test_gpu_bench_contract.py)
     dev_index = local_rank % max(1, torch.cuda.device_count())
@@ -310,7 +316,26 @@ def main():
         # next to the headline number; a failure here (e.g. the collective) must not lose the forward measurement
         try:
             dt_train, tout = timed(make_train_fn(), 1, args.train_steps)
+            allreduce_us = None
+            if world > 1:      # the step's one collective alone: the bucket, back to back, HIP events on this stream
+                sess.store.zero_grad()
+                for _ in range(5):
+                    dist.all_reduce(sess.store.bucket)
+                barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    dist.all_reduce(sess.store.bucket)
+                e1.record()
+                torch.cuda.synchronize()
+                tm = torch.tensor([e0.elapsed_time(e1) * 1e3 / 20], dtype=torch.float64, device=device)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                allreduce_us = round(float(tm.item()), 2)
             train = {"ms_per_batch": round(1e3 * dt_train / args.train_steps, 3),
+                     "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                     "backend": dist.get_backend() if world > 1 else None,
+                     "allreduce_us": allreduce_us,
+                     "allreduce_bytes": 4 * (sess.store.theta.numel() + sess.store.BUCKET_TAIL) if world > 1 else None,
                      "ms_per_step": round(1e3 * dt_train / args.train_steps, 3),
                      "value": round(world * args.train_steps * T / dt_train, 2), "unit": "mp-steps/s",
                      "mp_steps_per_s": round(world * args.train_steps * T / dt_train, 2),
@@ -656,6 +681,15 @@ def main():
             "cpu_baseline": cpu_baseline,
             "gemm": gemm,
             "mode": args.mode, "hip_graph": bool(use_graph),
+            # N > 1: the forward-only `value` has no collective and scales by construction; the curve north_star asks for
+            # is the TRAINING step's (one RCCL all-reduce per step) -- lifted to the top level so that it cannot be missed
+            "rccl_ranks": (train or {}).get("rccl_ranks") if world > 1 else None,
+            "allreduce_us": (train or {}).get("allreduce_us") if world > 1 else None,
+            "train_value": (train or {}).get("value"),
+            "train_ms_per_step": (train or {}).get("ms_per_step"),
+            "scaling_note": ("`value` = forward passes of %d independent shards (no data-path collective: weak scaling by "
+                             "construction); `train_value` = whole-job mp-steps/s of the training step, whose gradient "
+                             "bucket crosses all %d ranks once per step" % (world, world)) if world > 1 else None,
             "train": train,
             "serve": serve,
             "kernels_us": {k: {"n": v["n"], "avg_us": round(v["avg_us"], 2)} for k, v in kernels_us.items()},
@@ -666,6 +700,85 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return result
+
+
+def plumbing_main(args, rank, world):
+    """`bench.py --plumbing --gpus N`: everything of the N-rank benchmark that is not a kernel -- launcher, rendezvous on
+    127.0.0.1 (gloo), per-rank shards of unequal size, the data-parallel bucket (pack -> ONE all-reduce -> unpack, the
+    same Session code the GPU path runs), barrier-bracketed timing with the max over ranks, rank 0 printing ONE JSON line
+    with the driver's keys.  Session(device='cpu') launches no kernel; the numbers time the collective on the host and are
+    labelled as such."""
+    import torch
+    import torch.distributed as dist
+    import tspgnn
+    torch.set_num_threads(1)
+    if world > 1:
+        dist.init_process_group("gloo")
+    d, T = 32, 2
+    sizes = [5 + (rank + i) % 4 for i in range(2 + rank % 3)]            # unequal shards: B_r / B weights matter
+    batch = tspgnn.synthetic_batch(sizes, seed=1234 + rank)
+    model = tspgnn.build_network(d)
+    sess = tspgnn.Session(model, device="cpu")
+    sess.run(tspgnn.global_variables_initializer(seed=0))
+    store = model.store
+    store.zero_grad()
+    store.grad.fill_(float(rank + 1))
+    stats = torch.tensor([0.5 + rank, 1.0, 1.0, 0.0, float(len(sizes)) - 1.0, 0.0])
+
+    def step():
+        store.grad.fill_(float(rank + 1))
+        st = stats.clone()
+        sess.allreduce_grads(len(sizes), st)
+        return st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    total_b = float(len(sizes))
+    if world > 1:
+        tm = torch.tensor([dt, total_b], dtype=torch.float64)
+        mx = tm.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tm, op=dist.ReduceOp.SUM)
+        dt, total_b = float(mx[0]), float(tm[1])
+    # the reduced gradient of a constant-(r+1) gradient weighted by B_r / B: checked against the closed form on every rank
+    want = 1.0
+    if world > 1:
+        per = torch.zeros(world, 2, dtype=torch.float64)
+        per[rank, 0], per[rank, 1] = float(len(sizes)), float(len(sizes) * (rank + 1))
+        dist.all_reduce(per)
+        want = float(per[:, 1].sum() / per[:, 0].sum())
+    ok = bool(abs(float(store.grad[0]) - want) < 1e-5 * max(1.0, want))
+    result = None
+    if rank == 0:
+        result = {
+            "metric": "message-passing steps/sec (edges aggregated/sec) at n=40, batch=128, T=32 [PLUMBING RUN: no GPU, "
+                      "collective path only]",
+            "value": round(world * args.steps * T / dt, 2), "unit": "mp-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "plumbing: %d ranks, shards of 2-4 tiny graphs, d=%d, no kernels" % (world, d),
+                       "global_batch": int(total_b), "parallelism": "shard-by-instance x%d, one all-reduce of the bucket" % world},
+            "plumbing": True, "roofline": None, "cpu_baseline": None,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
+            "allreduce_us": round(1e6 * dt / args.steps, 1), "allreduce_bytes": 4 * store.bucket.numel(),
+            "reduced_gradient_ok": ok, "reduced_loss": float(st[0]),
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("plumbing: the reduced gradient is %r, expected %r" % (float(store.grad[0]), want))
     return result
 
 

@@ -14,6 +14,7 @@ from oracle import torch_oracle as TO
 pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-5
+MOVE_TOL_BY_CLASS = {}   # (filled from the round-5 measurement below)
 MOVE_TOL = 0.05    # three Adam steps: error of a variable's movement relative to its largest movement (see the test;
                    # measured 3.9e-2 in round 4 -- entries whose gradient sits at fp32 noise level, normalised by sqrt(v))
 
@@ -326,6 +327,7 @@ def test_train_steps_follow_the_oracle(cuda_device):
         assert abs(float(sess._adam["gnorm"].item()) - gn) < 2e-5 * gn
     now = model.store.state_dict()
     worst = 0.0
+    by_class = {}
     for k in p:
         # three Adam steps move every weight by ~6e-5; compare the MOVEMENT, not just the value
         moved_ref = p[k] - params[k]
@@ -334,8 +336,11 @@ def test_train_steps_follow_the_oracle(cuda_device):
         # noise-dependent fraction of the step, hence a budget relative to the largest movement)
         ratio = np.abs(moved - moved_ref).max() / np.abs(moved_ref).max()
         worst = max(worst, ratio)
-        assert np.abs(moved - moved_ref).max() < 2e-7 + MOVE_TOL * np.abs(moved_ref).max(), (k, ratio)
-    print("\n[train steps] worst movement error relative to the largest movement of its variable: %.2e" % worst)
+        klass = k.rsplit("/", 1)[-1] if "/" in k else k
+        by_class[klass] = max(by_class.get(klass, 0.0), ratio)
+        assert np.abs(moved - moved_ref).max() < 2e-7 + MOVE_TOL_BY_CLASS.get(klass, MOVE_TOL) * np.abs(moved_ref).max(), (k, ratio)
+    print("\n[train steps] worst movement error relative to the largest movement of its variable: %.2e; by class: %s"
+          % (worst, "  ".join("%s %.2e" % kv for kv in sorted(by_class.items()))))
 
 
 def test_captured_graph_replay_matches_eager(cuda_device):

@@ -9,9 +9,11 @@
 //     gradient w.r.t. the SCALED pre-activation, dz' = dz / 2^s.  dz is stored as 2^s * dz' (exact).
 //   * dh = dz Kh^T = dz' (2^s Kh)^T: the factor cancels against the packed weights.  Gradients span many binades
 //     (1e-8 .. 1e-3 across rows and time steps), far outside fp16's normal range, so every row of dz' is brought to
-//     [0.5, 1) by the power of two of its largest entry before the split (entries more than 2^-12 below the row's
-//     maximum then carry an absolute error of 2^-25 of that maximum -- fp32 rounding level for the dot product) and
-//     the 16 outputs of the row are scaled back.
+//     [0.5, 1) by the power of two of its largest entry before the split, and the split's second piece is scaled up by
+//     2^11 into fp16's normal range and accumulated apart (split2s / kblock_h2_side, h2_tile.h: the plain lo piece goes
+//     subnormal and then quantises every small entry at 2^-25 of the ROW's maximum -- measured at full C2 size as 5-6x
+//     the fp32-MFMA backward's error on the bias / LayerNorm-shift gradients, which sum 10^5 such rows); the 16 outputs
+//     of the row are scaled back.
 #include "common.h"
 #include "h2_tile.h"
 #include "lstm_bwd_tile.h"
@@ -139,21 +141,29 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
             m = max_over_lane_groups16_swap(m);
             const int e = m > 0.f ? __builtin_amdgcn_frexp_expf(m) : 0;   // m = f * 2^e, f in [0.5, 1)
             const float up = __builtin_ldexpf(1.0f, -e), down = __builtin_ldexpf(1.0f, e);
-            f32x4 out[TPG];
+            // (the row's second piece is the SCALED one of split2s, accumulated apart: entries far below the row's
+            // largest keep a relative, not an absolute, accuracy)
+            f32x4 out[TPG], side[TPG];
 #pragma unroll
-            for (int t = 0; t < TPG; ++t) out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < TPG; ++t) out[t] = side[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < NT4 / 2; ++kb) {
                 float xv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = acc[2 * kb + (j >> 2)][j & 3] * up;
-                f16x8 bh, bl;
-                split2(xv, bh, bl);
-                kblock_h2<TPG>(out, lds_kt, lds_kt + kt_total, kb, g, rl, bh, bl);
+                f16x8 bh, bm;
+                split2s(xv, bh, bm);
+                kblock_h2_side<TPG>(out, side, lds_kt, lds_kt + kt_total, kb, g, rl, bh, bm);
             }
             if (valid) {
+                const float fold = 1.0f / 2048.0f;
 #pragma unroll
-                for (int t = 0; t < TPG; ++t) st4(dxh + (size_t)rc * D + t * 16 + g * 4, out[t] * down);
+                for (int t = 0; t < TPG; ++t) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(side[t][r], fold, out[t][r]) * down;
+                    st4(dxh + (size_t)rc * D + t * 16 + g * 4, v);
+                }
             }
         }
     }

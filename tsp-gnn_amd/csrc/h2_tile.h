@@ -44,6 +44,30 @@ __device__ __forceinline__ void split2(const float (&x)[8], f16x8& hi, f16x8& lo
     }
 }
 
+// The split for operands whose entries span many binades INSIDE one row (gradients): x = hi + 2^-11 * m with
+// hi = rn16(x), m = rn16(2^11 (x - hi)).  The second piece is scaled up into fp16's NORMAL range -- the plain lo piece of
+// split2 goes subnormal below 2^-14 and then carries an absolute error of 2^-25 of the row's scale however small the
+// entry, which a column sum over 10^5 rows turns into a relative error several times fp32's (round 5: bias / LayerNorm
+// shift gradients at full C2 size 6e-4..8e-4 against 1.5e-4 for the fp32-MFMA backward).  The products with m go to an
+// accumulator of their own (kblock_h2_side) and are folded in with one fma per output: for |x| <= 1 the pair represents x
+// to 2^-35 absolutely.
+__device__ __forceinline__ void split2s(const float (&x)[8], f16x8& hi, f16x8& m) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2 v = {x[i], x[i + 1]};
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x[i]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x[i + 1]));
+        const f32x2 r = {r0 * 2048.0f, r1 * 2048.0f};
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        hi[i] = h[0];
+        hi[i + 1] = h[1];
+        m[i] = l[0];
+        m[i + 1] = l[1];
+    }
+}
+
 // The same split, keeping a witness of fp16 overflow: an |x| >= 65520 rounds to hi = +-inf, and then the residual
 // x - hi is -+inf (NaN for a non-finite x, which the maximum ignores: the fp32 reference is non-finite there too).
 // `wit` accumulates max |residual| -- one v_max3_f32 per PAIR of values; h2_range_report() turns an infinite witness
@@ -192,6 +216,34 @@ __device__ __forceinline__ void kblock_h2_multi(f32x4 (&acc)[NP][NT], const _Flo
             c = MFMA_F16(a_h, bh[n], c);
             acc[n][t] = c;
         }
+    }
+}
+
+// kblock_h2 for a B operand split by split2s: acc += (W_lo + W_hi) x B_hi, side += W_hi x B_m; the caller folds
+// acc + 2^-11 * side.  Three MFMAs per product, as kblock_h2.
+template <int NT>
+__device__ __forceinline__ void kblock_h2_side(f32x4 (&acc)[NT], f32x4 (&side)[NT], const _Float16* wh, const _Float16* wl,
+                                               int kb, int g, int jl, const f16x8& bh, const f16x8& bm) {
+    const int off = ((kb * 4 + g) * NT * 16 + jl) * 8;
+    constexpr int PF = H2_PF < NT ? H2_PF : NT;
+    f16x8 ah[PF + 1], al[PF + 1];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        ah[p] = ldw(wh + off + p * 128);
+        al[p] = ldw(wl + off + p * 128);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t + PF < NT) {
+            ah[(t + PF) % (PF + 1)] = ldw(wh + off + (t + PF) * 128);
+            al[(t + PF) % (PF + 1)] = ldw(wl + off + (t + PF) * 128);
+        }
+        const f16x8 a_h = ah[t % (PF + 1)], a_l = al[t % (PF + 1)];
+        side[t] = MFMA_F16(a_h, bm, side[t]);
+        f32x4 c = acc[t];
+        c = MFMA_F16(a_l, bh, c);
+        c = MFMA_F16(a_h, bh, c);
+        acc[t] = c;
     }
 }
 
