@@ -556,6 +556,14 @@ long long tspgnn_host_pack_batch(const void* const* Ma, const int* ma_kind, cons
  * Returns 0, or <0: -1 bad arguments, -2 cannot open, -3 no/invalid DIMENSION, -4 missing section, -5 edge out of
  * range, -6 malformed weight matrix.
  */
+/* One device batch's worth of arrays packed by one call into one caller-owned (pinned) buffer: off[7] = byte offsets of
+ * uv int32[M][2], eid int32[2M], rowptr int32[N+1], wc float[M][2], labels float[B], seg int32[B+1], n_edges int32[B]
+ * (instance_loader.py:29-80 + the conversions of the feed, train.py:25-33).  Returns M; -1 malformed, -2 a route leaves
+ * its graph, -3 M / N differ from M_expected / N_expected.  Thread-safe (thread-local scratch). */
+long long tspgnn_host_stage_batch(const void* const* Ma, const int* ma_kind, const double* const* Mw, const int* n,
+                                  const int64_t* const* route, const int* route_len, int B, double dev, int use_target,
+                                  double target_cost, long long M_expected, int N_expected, unsigned char* stage,
+                                  const long long* off);
 int tspgnn_host_read_graph(const char* path, int* n_out, int* route_len_out, int64_t* Ma, double* Mw, int64_t* route);
 
 /*

@@ -13,7 +13,7 @@ ANCHORS = {
     # name: (sizes, T)  -- BASELINE.json configs[0], [1], [3]
     "c1": (lambda: [20] * 32, 8),
     "c2": (lambda: [40] * 128, 32),
-    "c4": (lambda: [int(x) for x in np.random.RandomState(0).randint(20, 81, size=512)], 2),
+    "c4": (lambda: [int(x) for x in np.random.RandomState(0).randint(20, 81, size=512)], 8),   # (T = 2 until round 5)
 }
 ANCHOR_ROWS = 512
 

@@ -122,13 +122,15 @@ from oracle.anchors import (ANCHORS, BF16_ANCHORS, GRAD_ANCHORS, TRAINED, anchor
                             bf16_anchor_inputs, grad_anchor_inputs, grad_sample_index)
 
 
-def gen_anchors():
+def gen_anchors(only=None):
     import time
     import torch
     from oracle import torch_oracle as TO
 
     torch.set_num_threads(os.cpu_count() or 1)
     for name in ANCHORS:
+        if only is not None and name not in only:
+            continue
         batch, params, T, finger = anchor_inputs(name)
         EV, W, C, route_exists, n_vertices, n_edges = batch
         ob = {"ev_uv": EV.uv, "W": W, "C": C, "route_exists": route_exists, "n_vertices": n_vertices, "n_edges": n_edges}
@@ -291,6 +293,8 @@ if __name__ == "__main__":
         gen_grad_anchors()
     if "trained" in what:    # (not in the default list: 2 000 oracle training steps)
         gen_trained()
-    for w in what:   # "bf16:<name>": one bf16 anchor only (the others take minutes and do not change)
+    for w in what:   # "bf16:<name>" / "anchors:<name>": one anchor only (the others take minutes and do not change)
         if w.startswith("bf16:"):
             gen_bf16_anchors(only=w[5:].split(","))
+        if w.startswith("anchors:"):
+            gen_anchors(only=w[8:].split(","))

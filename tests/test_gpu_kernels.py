@@ -291,15 +291,16 @@ def test_bucket_pack_unpack(cuda_device, n, with_grad):
     rng = np.random.RandomState(n + 3)
     g = [rng.randn(n).astype(np.float32) for _ in range(2)]
     stats = [np.array([0.7, 0.5, 3, 1, 2, 0], np.float32), np.array([0.4, 0.75, 1, 0, 5, 2], np.float32)]
-    nb, flags = [6.0, 10.0], [0, 2]
+    nb, flags = [6.0, 10.0], [4, 2]      # guard words: rank 0 "my variables were assigned" (bit 2), rank 1 "variance floor" (bit 1)
     buckets = []
     for r in range(2):
-        b = dev(np.concatenate([g[r], np.full(8, 123.0, np.float32)]), cuda_device)
+        b = dev(np.concatenate([g[r], np.full(10, 123.0, np.float32)]), cuda_device)
         fl = dev(np.array([flags[r]], np.uint32), cuda_device, dtype=np.uint32)
         _lib.call("tspgnn_bucket_pack_f32", _lib.ptr(b), n, int(with_grad), nb[r], _lib.ptr(dev(stats[r], cuda_device)),
                   _lib.ptr(fl), None)
         got = b.cpu().numpy()
-        want_tail = np.array([nb[r], nb[r] * stats[r][0], nb[r] * stats[r][1], *stats[r][2:6], flags[r]], np.float32)
+        want_tail = np.array([nb[r], nb[r] * stats[r][0], nb[r] * stats[r][1], *stats[r][2:6],
+                              flags[r] & 1, (flags[r] >> 1) & 1, (flags[r] >> 2) & 1], np.float32)   # one slot per guard bit
         assert np.array_equal(got[n:], want_tail)
         assert np.array_equal(got[:n], g[r] * np.float32(nb[r]) if with_grad else g[r])
         buckets.append(b)
@@ -315,7 +316,7 @@ def test_bucket_pack_unpack(cuda_device, n, with_grad):
     assert np.array_equal(got[:n], before[:n] * inv if with_grad else before[:n])
     want_stats = np.concatenate([before[n + 1:n + 3] * inv, before[n + 3:n + 7]])
     assert np.array_equal(st_out.cpu().numpy(), want_stats)
-    assert int(fl_out.item()) == 1
+    assert int(fl_out.item()) == 6      # the bits keep their meaning through the sum (they used to collapse to 1)
     # no statistics, no flag: nothing is dereferenced
     _lib.call("tspgnn_bucket_pack_f32", _lib.ptr(total), n, 0, 4.0, None, None, None)
     _lib.call("tspgnn_bucket_unpack_f32", _lib.ptr(total), n, 0, None, None, None)

@@ -1164,3 +1164,41 @@ def test_replayed_training_raises_at_a_fixed_lag(cuda_device):
     step()
     torch.cuda.synchronize()
     assert int(sess._adam["t"].item()) == 4 and sess._adam["step"] == 4 and not torch.equal(model.store.theta, theta3)
+
+
+def test_batch_stager_serves_fresh_batches_through_one_captured_graph(cuda_device):
+    """parallel.BatchStager: fresh instances -> one native staging call into a pinned slot -> one upload -> one device copy
+    into the buffer the captured graph reads.  Every batch's replayed predictions equal the plain prepare + forward of the
+    same instances (bit for bit: same device arrays, same kernels), in the iterator's order; a batch of another shape is
+    refused; the device batch the graph is bound to equals Session.prepare's arrays."""
+    rng = np.random.RandomState(11)
+    sizes = [12, 9, 12, 9, 20, 20, 7, 7]
+    pool = [[tspgnn.random_instance(n, rng) for n in sizes] for _ in range(6)]
+    d, T = 64, 3
+    params = P.init_params(d, seed=6, perturb=True)
+    model = tspgnn.build_network(d)
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+
+    def feed_of(inst):
+        EV, W, C, r, nv, ne = tspgnn.InstanceLoader.create_batch(inst, dev=0.02)
+        return {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T, model["route_exists"]: r,
+                model["n_vertices"]: nv, model["n_edges"]: ne}
+    want = [sess.forward_device(sess.prepare(feed_of(inst)))["predictions"].clone() for inst in pool]
+    stager = tspgnn.BatchStager(sess, pool[0], T)
+    ref = sess.prepare(feed_of(pool[0]))
+    for a, b in zip(stager.batch.tensors(), ref.tensors()):
+        assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)
+    replay = sess.capture_forward(stager.batch)
+    got = []
+    for _ in stager.feed(pool * 3):
+        got.append(replay()["predictions"].clone())
+    torch.cuda.synchronize()
+    assert len(got) == 18
+    for i, p in enumerate(got):
+        assert torch.equal(p, want[i % 6]), i
+    with pytest.raises(RuntimeError):
+        for _ in stager.feed([pool[0][:-1]]):
+            pass
+    assert not sess.range_exceeded()

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <string>
+#include <vector>
 
 #include "tspgnn.h"
 
@@ -135,6 +136,58 @@ extern "C" int tspgnn_host_csr_by_vertex(const int32_t* uv, long long M, int N, 
     for (int v = N; v > 0; --v) rowptr[v] = rowptr[v - 1];  // undo the cursor advance
     rowptr[0] = 0;
     return 0;
+}
+
+// ---------------------------------------------------------------------------------- one staged batch
+// Everything a device batch is made of (Session.prepare), packed by ONE call into ONE caller-owned buffer -- meant to be
+// pinned host memory, so that a batch reaches the GPU as one asynchronous copy (parallel.BatchStager): the worker thread
+// spends its time here, outside the interpreter lock, instead of in eight numpy conversions and eight pageable uploads
+// (round 4: the fresh-batch path ran 9-17 % behind the resident one, and its one packer thread was nearly as slow as the
+// forward pass itself).  off[7] = byte offsets of
+//   uv int32[M][2] | eid int32[2M] | rowptr int32[N+1] | wc float[M][2] (edge weight, target cost) | labels float[B]
+//   (i mod 2, instance_loader.py:50) | seg int32[B+1] (prefix sums of the edge counts) | n_edges int32[B]
+// Returns M, or -1 malformed input, -2 a route names a vertex outside its graph, -3 M / N differ from what the caller
+// sized the buffer for.
+extern "C" long long tspgnn_host_stage_batch(const void* const* Ma, const int* ma_kind, const double* const* Mw,
+                                             const int* n, const int64_t* const* route, const int* route_len, int B,
+                                             double dev, int use_target, double target_cost, long long M_expected,
+                                             int N_expected, unsigned char* stage, const long long* off) {
+    if (B < 0 || !stage || !off || (B > 0 && (!Ma || !ma_kind || !Mw || !n))) return -1;
+    static thread_local std::vector<int64_t> counts;
+    static thread_local std::vector<double> W, C;
+    counts.assign((size_t)(B > 0 ? B : 1), 0);
+    if (tspgnn_host_count_edges(Ma, ma_kind, n, B, counts.data()) != 0) return -1;
+    long long M = 0, N = 0;
+    for (int b = 0; b < B; ++b) {
+        M += counts[b];
+        N += n[b];
+    }
+    if (M != M_expected || N != N_expected) return -3;
+    int32_t* uv = reinterpret_cast<int32_t*>(stage + off[0]);
+    int32_t* eid = reinterpret_cast<int32_t*>(stage + off[1]);
+    int32_t* rowptr = reinterpret_cast<int32_t*>(stage + off[2]);
+    float* wc = reinterpret_cast<float*>(stage + off[3]);
+    float* labels = reinterpret_cast<float*>(stage + off[4]);
+    int32_t* seg = reinterpret_cast<int32_t*>(stage + off[5]);
+    int32_t* ne = reinterpret_cast<int32_t*>(stage + off[6]);
+    W.resize((size_t)(M > 0 ? M : 1));
+    C.resize((size_t)(M > 0 ? M : 1));
+    const long long got = tspgnn_host_pack_batch(Ma, ma_kind, Mw, n, route, route_len, B, dev, use_target, target_cost, uv,
+                                                 W.data(), C.data());
+    if (got < 0) return got;
+    if (got != M) return -1;
+    for (long long e = 0; e < M; ++e) {   // the float32 the device reads (Session.prepare: np.stack([W, C], 1) as float32)
+        wc[2 * e] = (float)W[e];
+        wc[2 * e + 1] = (float)C[e];
+    }
+    seg[0] = 0;
+    for (int b = 0; b < B; ++b) {
+        labels[b] = (float)(b % 2);
+        ne[b] = (int32_t)counts[b];
+        seg[b + 1] = seg[b] + (int32_t)counts[b];
+    }
+    const int rc = tspgnn_host_csr_by_vertex(uv, M, (int)N, rowptr, eid);
+    return rc == 0 ? M : -1;
 }
 
 // ---------------------------------------------------------------------------------- .graph files

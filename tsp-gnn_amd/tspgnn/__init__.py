@@ -10,7 +10,7 @@ from .graphnn import GraphNN, LSTMStateTuple, DeviceAdjacency, LayerNormBasicLST
 from .instance_loader import InstanceLoader, SparseEV, read_graph, write_graph, synthetic_batch, random_instance
 from .binary_search import get_cost
 from .mlp import Mlp
-from .parallel import BatchPrefetcher, shard_instances
+from .parallel import BatchPrefetcher, BatchStager, shard_instances
 from .model import build_network, Session, global_variables_initializer
 from .variables import VariableStore, get_default_store, reset_default_store
 from . import tf_checkpoint
@@ -21,6 +21,6 @@ from . import experiments
 __all__ = [
     "TspgnnError", "GraphNN", "LSTMStateTuple", "DeviceAdjacency", "LayerNormBasicLSTMCell", "InstanceLoader",
     "SparseEV", "read_graph", "write_graph", "synthetic_batch", "random_instance", "Mlp", "build_network",
-    "Session", "global_variables_initializer", "get_cost", "BatchPrefetcher", "shard_instances", "VariableStore", "get_default_store", "reset_default_store",
+    "Session", "global_variables_initializer", "get_cost", "BatchPrefetcher", "BatchStager", "shard_instances", "VariableStore", "get_default_store", "reset_default_store",
     "load_weights", "save_weights", "run_batch", "summarize_epoch",
 ]

@@ -82,7 +82,7 @@ SIGNATURES = {
 }
 
 HOST_FUNCTIONS = ("tspgnn_host_pack_instance", "tspgnn_host_route_cost", "tspgnn_host_csr_by_vertex",
-                  "tspgnn_host_read_graph", "tspgnn_host_count_edges", "tspgnn_host_pack_batch")
+                  "tspgnn_host_read_graph", "tspgnn_host_count_edges", "tspgnn_host_pack_batch", "tspgnn_host_stage_batch")
 
 # size queries: name -> argtypes; these return long long (floats of workspace)
 SIZE_QUERIES = {
@@ -201,6 +201,9 @@ def _load():
     lib.tspgnn_host_pack_batch.restype = c_longlong
     lib.tspgnn_host_pack_batch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                            ctypes.c_double, c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p]
+    lib.tspgnn_host_stage_batch.restype = c_longlong
+    lib.tspgnn_host_stage_batch.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                            ctypes.c_double, c_int, ctypes.c_double, c_longlong, c_int, c_void_p, c_void_p]
     lib.tspgnn_host_read_graph.restype = c_int
     lib.tspgnn_host_read_graph.argtypes = [c_char_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     return lib

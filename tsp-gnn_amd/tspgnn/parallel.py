@@ -170,3 +170,195 @@ class BatchPrefetcher(object):
             for t in b.tensors():
                 t.record_stream(cur)
         return b
+
+
+def stage_layout(M, N, B, plan_ints):
+    """Byte offsets (256-byte aligned) of the arrays of one staged batch and the total size: uv, eid, rowptr, wc, labels,
+    seg, n_edges (tspgnn_host_stage_batch's order), then the one-launch loop's work plan."""
+    sizes = [8 * M, 8 * M, 4 * (N + 1), 8 * M, 4 * B, 4 * (B + 1), 4 * B, 4 * plan_ints]
+    off, pos = [], 0
+    for nbytes in sizes:
+        off.append(pos)
+        pos += (nbytes + 255) // 256 * 256
+    return off, sizes, max(pos, 256)
+
+
+def stage_instances(instances, dev, target_cost, M, N, stage_ptr, offsets):
+    """tspgnn_host_stage_batch over a list of (Ma, Mw, route): everything Session.prepare would upload, written into the
+    buffer at ``stage_ptr`` (the GIL is released inside the call).  Raises like create_batch on malformed instances."""
+    import ctypes
+    from . import _lib
+    from .instance_loader import _KIND
+    B = len(instances)
+    f64, i64 = np.dtype(np.float64), np.dtype(np.int64)
+    mas, mws, routes = [], [], []
+    pa, pw, pr, kinds, ns, rls = ([0] * B for _ in range(6))
+    for k, (Ma, Mw, route) in enumerate(instances):
+        # (the usual case -- C-contiguous int / float64 arrays, the route a list or an int64 vector -- costs a few attribute
+        # reads per instance: this loop runs under the interpreter lock, next to the consumer's launches)
+        if not (type(Ma) is np.ndarray and Ma.flags.c_contiguous and Ma.dtype in _KIND):
+            Ma = np.ascontiguousarray(Ma)
+            if Ma.dtype not in _KIND:
+                Ma = Ma.astype(np.int64)
+        if not (type(Mw) is np.ndarray and Mw.flags.c_contiguous and Mw.dtype == f64):
+            Mw = np.ascontiguousarray(Mw, dtype=np.float64)
+        if not (type(route) is np.ndarray and route.ndim == 1 and route.flags.c_contiguous and route.dtype == i64):
+            route = np.ascontiguousarray(route, dtype=np.int64).reshape(-1)
+        if Ma.ndim != 2 or Ma.shape[0] != Ma.shape[1] or Mw.shape != Ma.shape:
+            raise ValueError("stage_instances: instance %d: adjacency %s / weight matrix %s" % (k, Ma.shape, Mw.shape))
+        mas.append(Ma)
+        mws.append(Mw)
+        routes.append(route)
+        pa[k], pw[k], pr[k] = (Ma.__array_interface__["data"][0], Mw.__array_interface__["data"][0],
+                               route.__array_interface__["data"][0])   # (.ctypes builds an object per access)
+        kinds[k], ns[k], rls[k] = _KIND[Ma.dtype], Ma.shape[0], route.shape[0]
+    ptrs = lambda vals: (ctypes.c_void_p * B)(*vals)
+    ints = lambda vals: (ctypes.c_int * B)(*vals)
+    off = (ctypes.c_longlong * 7)(*offsets[:7])
+    keep = (mas, mws, routes)   # (alive across the call)
+    got = _lib.lib.tspgnn_host_stage_batch(ptrs(pa), ints(kinds), ptrs(pw), ints(ns),
+                                           ptrs(pr), ints(rls), B, float(dev),
+                                           0 if target_cost is None else 1, 0.0 if target_cost is None else float(target_cost),
+                                           int(M), int(N), stage_ptr, off)
+    del keep
+    if got == -2:
+        raise IndexError("stage_instances: a route names a vertex outside its graph")
+    if got == -3:
+        raise ValueError("stage_instances: the batch does not have the %d edges / %d vertices the stager was built for" % (M, N))
+    if got != M:
+        raise ValueError("stage_instances: malformed instances (status %d)" % got)
+
+
+class BatchStager(object):
+    """Serving path for batches of ONE shape (the same instance sizes in the same order, e.g. BASELINE's 128 x n = 40):
+
+        stager = BatchStager(sess, template_instances, time_steps)
+        replay = sess.capture_forward(stager.batch)          # the graph reads the stager's device buffer
+        for _ in stager.feed(iterable_of_instance_lists):    # each turn: the next batch is in place
+            out = replay()
+
+    Per batch the worker thread makes one native call (tspgnn_host_stage_batch: endpoints, CSR, float32 (weight, cost)
+    pairs, labels, segment offsets straight into a PINNED slot, outside the interpreter lock) and enqueues ONE
+    asynchronous host-to-device copy on its side stream; the consumer enqueues ONE device-to-device copy into the buffer
+    the captured graph is bound to.  BatchPrefetcher + DeviceBatch.copy_from do the same job for arbitrary shapes with eight
+    numpy conversions, eight pageable uploads and eight device copies per batch under the interpreter lock -- measured
+    (round 4) at 9-17 % behind the resident-batch rate at C2, the one packer thread nearly as slow as the forward itself."""
+
+    def __init__(self, sess, template_instances, time_steps, dev=0.02, target_cost=None, slots=3):
+        from . import loop_plan
+        from .graphnn import DeviceAdjacency, loop_enabled
+        from .model import DeviceBatch
+        if sess.device.type != "cuda":
+            raise RuntimeError("BatchStager needs a GPU session (pinned staging, asynchronous copies)")
+        self.sess, self.T, self.dev, self.target_cost = sess, int(time_steps), dev, target_cost
+        self.sizes = [int(np.asarray(Ma).shape[0]) for Ma, _, _ in template_instances]
+        n_edges = [int(np.count_nonzero(Ma)) for Ma, _, _ in template_instances]
+        self.n_edges = np.asarray(n_edges, dtype=np.int32)
+        B, M, N = len(self.sizes), int(sum(n_edges)), int(sum(self.sizes))
+        plan, self.plan_meta = None, None
+        if loop_enabled() and M > 0:
+            grid = torch.cuda.get_device_properties(sess.device).multi_processor_count
+            grid -= grid % 8
+            built = loop_plan.build(np.concatenate([[0], np.cumsum(n_edges)]), np.concatenate([[0], np.cumsum(self.sizes)]), grid=grid)
+            if built is not None:
+                plan, self.plan_meta = built[0], (built[1], grid)
+        self.offsets, self.nbytes, total = stage_layout(M, N, B, 0 if plan is None else plan.size)
+        self.M, self.N, self.B = M, N, B
+        self.slots = max(2, int(slots))
+        self.pinned = [torch.empty(total, dtype=torch.uint8).pin_memory() for _ in range(self.slots)]
+        if plan is not None:   # the plan follows the block structure, which is the stager's contract: written once per slot
+            for p in self.pinned:
+                p[self.offsets[7]:self.offsets[7] + 4 * plan.size].view(torch.int32).copy_(torch.from_numpy(plan))
+        self.dev_stage = [torch.empty(total, dtype=torch.uint8, device=sess.device) for _ in range(self.slots)]
+        self.dev_buf = torch.empty(total, dtype=torch.uint8, device=sess.device)
+
+        def view(k, dtype, shape):
+            o, nb = self.offsets[k], self.nbytes[k]
+            return self.dev_buf[o:o + nb].view(dtype).view(*shape)
+        uv = view(0, torch.int32, (M, 2))
+        csr = (torch.arange(0, 2 * M + 1, 2, dtype=torch.int32, device=sess.device), uv.view(-1), None)
+        csr_t = (view(2, torch.int32, (N + 1,)), view(1, torch.int32, (2 * M,)), None)
+        adj = DeviceAdjacency((M, N), sess.device, csr, csr_t, uv=uv)
+        if plan is not None:
+            adj.loop_plan = (view(7, torch.int32, (plan.size,)), self.plan_meta[0], self.plan_meta[1])
+        b = DeviceBatch()
+        b.adj, b.M, b.N, b.B, b.T = adj, M, N, B, self.T
+        b.WC, b.labels, b.seg = view(3, torch.float32, (M, 2)), view(4, torch.float32, (B,)), view(5, torch.int32, (B + 1,))
+        self.batch = b
+        self.load(template_instances)       # the buffer holds a valid batch from the start (capture_forward runs it)
+
+    def load(self, instances):
+        """Synchronously place one batch in the device buffer (set-up, tests)."""
+        self._stage(instances, 0)
+        self.dev_buf.copy_(self.pinned[0], non_blocking=False)
+        torch.cuda.synchronize()
+        return self.batch
+
+    def _stage(self, instances, slot):
+        if len(instances) != self.B or any(len(inst[0]) != n for inst, n in zip(instances, self.sizes)):
+            raise ValueError("BatchStager: the batch's instance sizes differ from the template's")
+        p = self.pinned[slot]
+        stage_instances(instances, self.dev, self.target_cost, self.M, self.N, p.data_ptr(), self.offsets)
+        o = self.offsets[6]
+        if not np.array_equal(p[o:o + 4 * self.B].view(torch.int32).numpy(), self.n_edges):
+            raise ValueError("BatchStager: the batch's edge counts differ from the template's (the work plan and the "
+                             "segment layout are fixed per stager)")
+
+    def feed(self, batches):
+        """Iterate: every ``next`` leaves the following batch of ``batches`` (lists of (Ma, Mw, route)) in ``self.batch``.
+        The worker stages and uploads up to ``slots - 1`` batches ahead."""
+        import queue
+        q = queue.Queue(maxsize=self.slots - 1)
+        free = [None] * self.slots          # per slot: event after which its device stage may be overwritten
+        released = [threading.Event() for _ in range(self.slots)]   # ... set once the consumer has recorded that event
+        for r in released:
+            r.set()
+        stop = threading.Event()
+        side = torch.cuda.Stream(device=self.sess.device)
+
+        def work():
+            try:
+                for i, inst in enumerate(batches):
+                    if stop.is_set():
+                        return
+                    slot = i % self.slots
+                    while not released[slot].wait(timeout=0.05):   # the consumer has enqueued its copy out of this slot ...
+                        if stop.is_set():
+                            return
+                    released[slot].clear()
+                    if free[slot] is not None:
+                        free[slot].synchronize()                   # ... and that copy has run
+                    self._stage(inst, slot)
+                    with torch.cuda.stream(side):
+                        self.dev_stage[slot].copy_(self.pinned[slot], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                    q.put((slot, ev, None))
+                q.put((None, None, None))
+            except BaseException as exc:   # noqa: BLE001 -- handed to the consumer
+                q.put((None, None, exc))
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        try:
+            while True:
+                slot, ev, exc = q.get()
+                if exc is not None:
+                    raise RuntimeError("BatchStager worker failed") from exc
+                if slot is None:
+                    return
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev)
+                self.dev_buf.copy_(self.dev_stage[slot], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(cur)
+                free[slot] = done
+                released[slot].set()
+                yield self.batch
+        finally:
+            stop.set()
+            while t.is_alive():            # unblock a worker waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                t.join(timeout=0.05)
