@@ -253,9 +253,11 @@ int tspgnn_lnlstm_mlp_fwd_multi_h2(const tspgnn_cell_mlp_task* tasks, int n_task
  *   - the V<-E row-sum of a group is shared by the wavefronts that produced its messages; the vertex cells run on a few
  *     workgroups of their own, one LDS residency for the cell kernel and one for the message MLP + projection per step.
  * All buffers are caller-owned device memory; `plan` (int32, built by the host from the batch's instance sizes, see
- * tspgnn/loop_plan.py) tells every wavefront its tiles: TSPGNN_LOOP_DESC_INTS ints per (workgroup, wavefront), then
- * 4 ints per group {edge tiles, vertex tiles, vertex rows, 0}.  `counters` = 3 * 32 * n_groups unsigned words + 32, ZEROED
- * by the caller before every launch (stream-ordered).  status (optional device word): |= 1 when a wait timed out (the
+ * tspgnn/loop_plan.py) tells every wavefront its role, its tiles, its groups and the counts it waits for:
+ * TSPGNN_LOOP_DESC_INTS ints per (workgroup, wavefront), grid * TSPGNN_LOOP_WAVES descriptors in all -- the layout is
+ * documented where it is written (loop_plan._build) and read (mp_loop_h2.hip).  `counters` = 3 * 32 * n_groups unsigned
+ * words + 32 (three counters per group, each split by step parity), ZEROED by the caller before every launch
+ * (stream-ordered).  status (optional device word): |= 1 when a wait timed out (the
  * launch's outputs are then garbage; cannot happen unless fewer than `grid` workgroups are resident).
  * msg[0] / zx[0] hold the messages / projected messages of step 0 on entry (tspgnn_mlp_fwd_multi_h2).  T >= 1.
  */

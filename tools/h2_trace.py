@@ -1,6 +1,9 @@
 #!/usr/bin/env python
-"""Development aid: per-phase cycle sums of one workgroup of the fused cell launch's edge task, from a -DH2_TRACE=1 build
-(tools/build_variant.sh NAME -DH2_TRACE=1 [...]; run with TSPGNN_LIB=tools/variants/NAME.so)."""
+"""Development aid: per-phase cycle sums of one workgroup of the fused cell launch's edge task, from an instrumented build.
+The instrumentation lives OUTSIDE the shipped kernel source, as tools/h2_trace.patch:
+    patch -o /tmp/dense_h2_traced.hip tsp-gnn_amd/csrc/dense_h2.hip tools/h2_trace.patch
+    SRC=/tmp/dense_h2_traced.hip tools/build_variant.sh trace -DH2_TRACE=1
+    TSPGNN_LIB=tools/variants/trace.so python tools/h2_trace.py"""
 import ctypes
 import os
 import sys

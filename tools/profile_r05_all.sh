@@ -1,0 +1,66 @@
+#!/bin/bash
+# Round-5 profile set (run on the GPU box through gpurun; outputs in gpurun_out/r05/; the summaries are copied to
+# profiles/r05_* by `python tools/collect_r05.py`).  Every rocprofv3 kernel summary starts with `# csrc_sha16: <hash>` = the
+# fingerprint of the kernel sources it was taken from (bench.csrc_fingerprint): bench.py refuses to lead with a summary
+# whose fingerprint is not the tree's.
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r05
+mkdir -p $O
+SHA=$(cd $R && python -c "import bench; print(bench.csrc_fingerprint())")
+cd /tmp; export TMPDIR=/tmp
+stats() {  # db, title, out
+  { echo "# csrc_sha16: $SHA"; python $R/profiles/summarize_rocpd.py "$1" "$2"; } > "$3"
+}
+for w in ${WORKLOADS:-c2 c4 c5 c1}; do
+  steps=20; [ $w != c2 ] && [ $w != c1 ] && steps=6
+  python $R/bench.py --workload $w --steps $steps --warmup 3 --train-steps $([ $w = c5 ] && echo 0 || echo 2) > $O/${w}_bench.json 2> $O/${w}_bench.err
+  rm -rf $O/kt_$w
+  rocprofv3 --kernel-trace --stats -d $O/kt_$w -o k -- python $R/tools/forward_graph.py $w 20 > $O/kt_$w.log 2>&1
+  f=$(find $O/kt_$w -name "*.db" | head -1)
+  stats $f "round 5: python tools/forward_graph.py $w 20 (HIP-graph replays of the forward pass, nothing else)" $O/${w}_forward_kernel_stats.txt
+  python $R/tools/timeline_rocpd.py $f > $O/${w}_forward_timeline.txt 2>&1
+  if [ $w != c1 ]; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $O/pmc_${w}_$c
+    rocprofv3 --kernel-trace --pmc $c -d $O/pmc_${w}_$c -o p -- python $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --train-steps 0 --no-graph > $O/pmc_${w}_$c.log 2>&1
+    f=$(find $O/pmc_${w}_$c -name "*.db" | head -1)
+    python $R/profiles/summarize_pmc.py $f > $O/${w}_pmc_$c.txt
+    rm -rf $O/pmcf_${w}_$c
+    rocprofv3 --kernel-trace --pmc $c -d $O/pmcf_${w}_$c -o p -- python $R/tools/forward_only.py $w 3 > $O/pmcf_${w}_$c.log 2>&1
+    f=$(find $O/pmcf_${w}_$c -name "*.db" | head -1)
+    python $R/profiles/summarize_pmc.py $f > $O/${w}_forward_pmc_$c.txt
+  done
+  fi
+  find $O -name "*.db" -delete
+done
+# the persistent loop where the selector takes it (C1) and where it does not (C2, forced): kernel stats of the replayed forward
+for spec in "c1 0" "c2 4"; do
+  set -- $spec
+  rm -rf $O/kt_loop_$1
+  TSPGNN_LOOP_MAX_TILES=$([ $2 = 0 ] && echo 3 || echo $2) rocprofv3 --kernel-trace --stats -d $O/kt_loop_$1 -o k -- python $R/tools/forward_graph.py $1 20 > $O/kt_loop_$1.log 2>&1
+  f=$(find $O/kt_loop_$1 -name "*.db" | head -1)
+  stats $f "round 5: TSPGNN_LOOP_MAX_TILES=$2 (0 = default 3) python tools/forward_graph.py $1 20 (the persistent message-passing kernel)" $O/${1}_loop_kernel_stats.txt
+  find $O -name "*.db" -delete
+done
+# training steps
+python $R/bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline > $O/c2_train_bench.json 2> $O/c2_train_bench.err
+rm -rf $O/kt_c2t
+rocprofv3 --kernel-trace --stats -d $O/kt_c2t -o k -- python $R/bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline > $O/kt_c2t.log 2>&1
+f=$(find $O/kt_c2t -name "*.db" | head -1)
+stats $f "round 5: python bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline (C2 training step, HIP-graph replay)" $O/c2_train_kernel_stats.txt
+python $R/bench.py --workload c5 --mode train --steps 3 --warmup 2 --no-cpu-baseline --no-graph > $O/c5_train_bench.json 2> $O/c5_train_bench.err
+find $O -name "*.db" -delete
+# loop vs step-by-step over batch sizes (what loop_plan.max_edge_tiles was set from), the loop's phase trace, the staged
+# serving path, the full-size gradient anchors, the edge-once bound of the row-sum
+{
+  for spec in "32 20 8" "32 40 32" "64 40 32" "96 40 32" "128 40 32"; do
+    echo "## B n T = $spec"; TSPGNN_LOOP_MAX_TILES=4 timeout 300 python $R/tools/loop_bench.py $spec 2 2>&1 | grep -v amdgpu | tail -6
+  done
+} > $O/loop_vs_steps.txt
+TSPGNN_LOOP_MAX_TILES=4 timeout 300 python $R/tools/loop_trace.py > $O/loop_trace.txt 2>&1
+timeout 300 python $R/tools/stager_breakdown.py 2>&1 | grep -v amdgpu > $O/stager_breakdown.txt
+TOP=6 timeout 600 python $R/tools/grad_anchor_report.py 2>&1 | grep -v amdgpu > $O/grad_anchor_report.txt
+timeout 400 python $R/tools/rowsum_once_bound.py 2>&1 | grep -v amdgpu > $O/rowsum_once_bound.txt
+# counters of the cell launch (C2 forward)
+TAG=r05cell WORKLOAD=c2 SKIP_TRAFFIC=1 $R/tools/profile_r04.sh > $O/profile_cell.log 2>&1
+ls $O | head -80

@@ -30,10 +30,6 @@
 #include "h2_tile.h"
 #include "mfma_tile.h"
 
-#ifndef H2_TRACE
-#define H2_TRACE 0   // development builds: per-phase cycle sums of the edge task's tile loop (tools/h2_trace.py)
-#endif
-
 namespace tspgnn {
 
 // The cell launch's output rows (the states h', c' and the next step's messages) go through st4o<WT> (h2_tile.h).  WT --
@@ -41,28 +37,6 @@ namespace tspgnn {
 // five alternating runs on one box) and costs when they do not (C4: 10.31-10.43 -> 10.43-10.82 ms), so the launcher chooses by
 // footprint (launch_cell_h2); profiles/r04_store_flavour_ab.txt.
 
-#if H2_TRACE
-__device__ unsigned long long h2_trace_buf[16 * 8];   // [wavefront][phase] of workgroup H2_TRACE_BLOCK, summed over its tiles
-#ifndef H2_TRACE_BLOCK
-#define H2_TRACE_BLOCK 8
-#endif
-#define TR_DECL unsigned long long tr_prev = __builtin_readcyclecounter(), tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define TR(i)                                                        \
-    do {                                                             \
-        const unsigned long long tr_now = __builtin_readcyclecounter(); \
-        tr_acc[i] += tr_now - tr_prev;                               \
-        tr_prev = tr_now;                                            \
-    } while (0)
-#define TR_FLUSH                                                                                  \
-    do {                                                                                          \
-        if (blockIdx.x == H2_TRACE_BLOCK && lane == 0)                                            \
-            for (int i = 0; i < 8; ++i) h2_trace_buf[wave * 8 + i] += tr_acc[i];                   \
-    } while (0)
-#else
-#define TR_DECL
-#define TR(i)
-#define TR_FLUSH
-#endif
 
 // Packed weights of a [krows, ncols] matrix: P[piece][kb][g][t][jl][8] (fp16), piece 0 = hi, 1 = lo of 2^s * W,
 //   value = piece(2^s * W[16*(2kb + (j>>2)) + 4g + (j&3)][t*16 + jl]),   KB = krows/32, NT = ncols/16.
@@ -405,13 +379,11 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTa
         h2_stage_wait();
         __syncthreads();
         {
-        TR_DECL;
         for (;;) {
             int tile = 0;
             if (lane == 0) tile = atomicAdd(ticket, 1);
             tile = __builtin_amdgcn_readfirstlane(tile);
             if (tile >= t_end) break;
-            TR(0);
             {   // the lane's coordinates in the tile, recomputed (two VALU instructions) instead of kept: as loop invariants
                 // they and what is derived from them were SPILLED to scratch, a reload on every tile's critical path
                 const int l = opaque_lane();
@@ -425,26 +397,11 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTa
             {
                 f32x4 acc[NT4], cf[TPG];
                 init_acc(acc, rc, true);
-#if H2_TRACE
-#pragma unroll
-                for (int t = 0; t < NT4; ++t) asm volatile("" : "+v"(acc[t]));
-                TR(1);
-#endif
 #pragma unroll
                 for (int t = 0; t < TPG; ++t)
                     cf[t] = c != nullptr ? ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
                 kloop(acc, rc, 0, 0, KBT);
-#if H2_TRACE
-#pragma unroll
-                for (int t = 0; t < NT4; ++t) asm volatile("" : "+v"(acc[t]));
-                TR(2);
-#endif
                 cell(acc, cf, rc, valid, hn);
-#if H2_TRACE
-#pragma unroll
-                for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(hn[t]));
-                TR(3);
-#endif
             }
             if (n_layers > 0) {
                 for (int l = 0; l < n_layers; ++l) {
@@ -462,14 +419,7 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTa
                     for (int t = 0; t < TPG; ++t) st4o<WT>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
             }
-#if H2_TRACE
-#pragma unroll
-            for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(hn[t]));
-            TR(4);
-            tr_acc[7] += 1;
-#endif
         }
-        TR_FLUSH;
         }
     } else {
         // lock-step rounds: one tile per wavefront; K (whole or chunk by chunk), then the MLP + the projection
@@ -479,7 +429,6 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTa
         // are bound by the matrix pipes of the few CUs it runs on)
         const int lw = tt.lock_tiles[k];
         const int rounds = (tiles_total + lw - 1) / lw;
-        TR_DECL;
         for (int r = my_blk; r < rounds; r += my_grid) {
             {
                 const int l = opaque_lane();
@@ -512,14 +461,12 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTa
                         }
                     }
                 }
-                TR(0);
                 for (int kb0 = 0; kb0 < KBT; kb0 += kbc) {
                     const int kb1 = min(KBT, kb0 + kbc);
                     __syncthreads();
                     stage(kb0, kb1);
                     h2_stage_wait();
                     __syncthreads();
-                    TR(1);
                     if (live && pre) {
 #pragma unroll
                         for (int kb = 0; kb < KBP; ++kb) {
@@ -535,11 +482,6 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTa
                         kloop(acc, rc, kb0, kb0, kb1);
                     }
                 }
-#if H2_TRACE
-#pragma unroll
-                for (int t = 0; t < NT4; ++t) asm volatile("" : "+v"(acc[t]));
-#endif
-                TR(2);
                 if (n_layers > 0) {  // every wavefront is done with K: the next residency loads behind the gates
                     __syncthreads();
                     h2_copy_to_lds(lds_wb, mlp_wb, n_layers * LAYER_BYTES, tid, blockDim.x);
@@ -551,16 +493,10 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTa
                 for (int t = 0; t < TPG; ++t)
                     cf[t] = c != nullptr ? ld4(c + h2_state_row<D>(rc, g, in_blk) + t * in_ts) : f32x4{0.f, 0.f, 0.f, 0.f};
                 cell(acc, cf, rc, valid, hn);
-#if H2_TRACE
-#pragma unroll
-                for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(hn[t]));
-#endif
-                TR(3);
             }
             if (n_layers > 0) {
                 h2_stage_wait();
                 __syncthreads();
-                TR(4);
                 for (int l = 0; l < n_layers; ++l) {
                     const _Float16* wh = reinterpret_cast<const _Float16*>(lds_wb + (size_t)l * LAYER_BYTES);
                     const float* bias = reinterpret_cast<const float*>(lds_wb + (size_t)l * LAYER_BYTES + 2 * D * D * 2);
@@ -575,11 +511,6 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTa
 #pragma unroll
                     for (int t = 0; t < TPG; ++t) st4o<WT>(mlp_out + (rc * D + g * 4 + t * 16), hn[t]);
                 }
-#if H2_TRACE
-#pragma unroll
-                for (int t = 0; t < TPG; ++t) asm volatile("" : "+v"(hn[t]));
-#endif
-                TR(5);
                 if (proj_w != nullptr) {  // proj_out = 2^s mlp(h') P, P packed [D, 4D]
                     if (!together) {
                         __syncthreads();
@@ -606,13 +537,7 @@ __global__ __launch_bounds__(768) void lnlstm_mlp_fwd_h2_kernel(const CellTaskTa
                     }
                 }
             }
-#if H2_TRACE
-            __builtin_amdgcn_s_waitcnt(0);
-            TR(6);
-            tr_acc[7] += 1;
-#endif
         }
-        TR_FLUSH;
     }
     h2_range_report(tk.range_flag, wit, vmin);
 }
@@ -795,12 +720,6 @@ using namespace tspgnn;
 
 extern "C" float tspgnn_h2_weight_scale(void) { return kH2Scale; }
 
-#if H2_TRACE
-extern "C" int tspgnn_debug_h2_trace(unsigned long long* host_dst) {
-    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(tspgnn::h2_trace_buf), sizeof(unsigned long long) * 16 * 8, 0,
-                                    hipMemcpyDeviceToHost);
-}
-#endif
 
 extern "C" int tspgnn_pack_weights_h2(const float* W, void* P, int krows, int ncols, unsigned* absmax_bits, void* stream) {
     TSPGNN_REQUIRE(krows >= 0 && krows % 32 == 0, "pack_weights_h2: krows=%d must be a multiple of 32", krows);
