@@ -146,7 +146,7 @@ def main():
                                                                "under 'train' when --mode forward")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
                                                             "the captured HIP graph of the forward pass")
-    ap.add_argument("--serve-batches", type=int, default=24,
+    ap.add_argument("--serve-batches", type=int, default=64,
                     help="fresh-batch ('serve') leg: this many batches of NEW instances go host instances -> native packer "
                          "-> BatchPrefetcher (worker thread, side-stream upload) -> DeviceBatch.copy_from -> replayed graph; "
                          "0 skips it.  Reported under 'serve', never in 'value'.")

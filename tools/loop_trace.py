@@ -45,6 +45,7 @@ print("eager forward with trace: %.3f ms" % e0.elapsed_time(e1))
 tr = model["gnn"].loop_trace.cpu().numpy().astype(np.float64) * 0.01 / T     # us per step
 plan, G, grid = b.adj.loop_plan
 p = plan.cpu().numpy().reshape(grid, LP.WAVES, LP.DESC)
+print("\n".join(__doc__.split("\n")[2:]))
 for role, name in ((1, "edge"), (2, "vertex")):
     sel = (p[:, :, 0] == role) & (p[:, :, 1] > 0)
     x = tr[sel]
@@ -59,4 +60,5 @@ for role, name in ((1, "edge"), (2, "vertex")):
         for k in (3, 4):
             xs = tr[sel & (p[:, :, 1] == k)]
             if len(xs):
-                print("  %d-tile wavefronts: tiles phase mean %.2f us per step = %.2f per tile" % (k, xs[:, 4].mean(), xs[:, 4].mean() / k))
+                tiles_us = xs[:, [4, 8, 9, 10, 11, 12, 13]].sum(1).mean()
+                print("  %d-tile wavefronts: resident tiles %.2f us per step = %.2f per tile" % (k, tiles_us, tiles_us / k))
