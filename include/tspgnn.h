@@ -471,6 +471,37 @@ int tspgnn_lnlstm_bwd_multi_h2(const tspgnn_lstm_bwd_task* tasks, int n_tasks, i
 int tspgnn_lnlstm_bwd_finish_f32(const float* workspace, float* ln_grad, int d, void* stream);
 int tspgnn_mlp_bwd_multi_f32(const tspgnn_mlp_bwd_task* tasks, int n_tasks, int d, void* stream);
 
+/*
+ * Backward of a message MLP's square layers that RECOMPUTES the hidden activations instead of reading a forward tape
+ * (csrc/mlp_bwd_rc.hip) -- the data gradient of graphnn.py:150-155's `msg(h)` under model.py:160-167 from nothing but the
+ * chain's input, its output and the incoming gradient; both GEMM chains on the fp16 matrix cores (f16x2):
+ *   a_0 = X,  a_{l+1} = act_l(a_l W_l + b_l)  (recomputed as the f16x2 forward forms them; a_L = Yout is read),
+ *   dpre_l = G_{l+1} * [a_{l+1} > 0]  (G_L = dY, or dY[uv[r][0]] + dY[uv[r][1]]),   G_l = dpre_l W_l^T,   dX (+)= G_0.
+ * The operands of the weight gradients leave through `acts` (a_1 .. a_{L-1}: layer l+1 at acts + l * acts_stride) and
+ * `dpre` (dpre_l at dpre + l * dpre_stride), buffers of the backward pass (either may be NULL).  d = 64, 1 <= n_layers <= 3.
+ */
+typedef struct tspgnn_mlp_bwd_rc_task {
+    const float* X;          /* [rows, d]: the chain's input rows */
+    const void* wb;          /* the f16x2 forward's blocks {tspgnn_pack_weights_h2(W_l), 2^s b_l} (tspgnn_mlp_task.wb) */
+    const void* wt;          /* n_layers blocks tspgnn_pack_weights_h2(W_l^T), 2 d d fp16 each */
+    const float* Yout;       /* [rows, d]: the chain's output as the forward wrote it (needed if the last layer has relu) */
+    const float* dY;         /* gradient w.r.t. the output: [rows, d], or [n_src, d] with uv */
+    const int32_t* uv;       /* optional, [rows, 2]: gather-init mode as in tspgnn_mlp_bwd_task */
+    float* dX; int accumulate_dx;
+    int rows; int n_layers; unsigned relu_mask;
+    float* acts; long long acts_stride;
+    float* dpre; long long dpre_stride;
+    float* partial;          /* != NULL (then acts == dpre == NULL): the weight gradients are formed in the launch --
+                                partial[workgroup] += { a_l^T dpre_l , colsum(dpre_l) }_l, per workgroup [W_0, b_0, W_1, ...];
+                                tspgnn_mlp_bwd_rc_partial_floats(d, n_layers) floats, zeroed by the caller before the first
+                                launch of a backward pass, ACCUMULATED by every launch, folded in a fixed order by
+                                tspgnn_mlp_bwd_rc_finish_f32 into the flat [W,b,W,b,...] gradient slice.  Deterministic:
+                                rows, LDS slots and the order of the sums are assigned statically */
+} tspgnn_mlp_bwd_rc_task;
+int tspgnn_mlp_bwd_rc_h2(const tspgnn_mlp_bwd_rc_task* task, int d, void* stream);
+long long tspgnn_mlp_bwd_rc_partial_floats(int d, int n_layers);
+int tspgnn_mlp_bwd_rc_finish_f32(const float* partial, float* grad_wb, int d, int n_layers, void* stream);
+
 /* Workspace (floats) tspgnn_wgrad_f32 needs. */
 long long tspgnn_wgrad_workspace_floats(long long rows, int kin, int nout);
 

@@ -44,7 +44,7 @@ def test_abi_version_and_struct_layouts_agree(tmp_path):
     assert hv == _lib.ABI_VERSION == _lib.lib.tspgnn_version()
     pairs = {"tspgnn_mlp_task": _lib.MlpTask, "tspgnn_lstm_task": _lib.LstmTask, "tspgnn_cell_mlp_task": _lib.CellMlpTask,
              "tspgnn_mlp_task_bf16": _lib.MlpTaskB, "tspgnn_lstm_task_bf16": _lib.LstmTaskB,
-             "tspgnn_lstm_bwd_task": _lib.LstmBwdTask, "tspgnn_mlp_bwd_task": _lib.MlpBwdTask,
+             "tspgnn_lstm_bwd_task": _lib.LstmBwdTask, "tspgnn_mlp_bwd_task": _lib.MlpBwdTask, "tspgnn_mlp_bwd_rc_task": _lib.MlpBwdRcTask,
              "tspgnn_mp_loop_args": _lib.MpLoopArgs}
     src = ["#include <stdio.h>", "#include <stddef.h>", '#include "tspgnn.h"', "int main(void) {"]
     for cname, cls in pairs.items():

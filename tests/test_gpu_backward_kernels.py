@@ -1,4 +1,6 @@
 """Backward HIP kernels vs torch-autograd (float64, CPU) on the oracle's restatement of each op."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -473,3 +475,101 @@ def test_adam_skip_flag_leaves_the_variables_alone(cuda_device):
     assert np.array_equal(res[1][0], theta) and np.array_equal(res[1][1], m) and np.array_equal(res[1][2], v) and res[1][3] == 4
     assert res[0][3] == 5 and not np.array_equal(res[0][0], theta)
     assert res[1][4] == res[0][4] > 0
+
+
+def _h2_blocks(Ws, bs, device, transposed=False):
+    """The f16x2 kernels' weight blocks: forward {pack_h2(W), 2^s b} per layer, or pack_h2(W^T) back to back."""
+    d = Ws[0].shape[0]
+    scale = _lib.lib.tspgnn_h2_weight_scale()
+    per = 4 * d * d + (0 if transposed else 4 * d)
+    out = torch.empty(len(Ws) * per, dtype=torch.uint8, device=device)
+    for j, (w, b) in enumerate(zip(Ws, bs)):
+        src = dev(w.T if transposed else w, device)
+        _lib.call("tspgnn_pack_weights_h2", _lib.ptr(src), _lib.ptr(out[j * per:j * per + 4 * d * d]), d, d, None, None)
+        if not transposed:
+            out[j * per + 4 * d * d:(j + 1) * per].copy_(dev(scale * b, device).view(torch.uint8))
+    _KEEP.append(out)
+    return out
+
+
+@pytest.mark.parametrize("L,mask", [(3, 0b111), (2, 0b11), (1, 0b1), (3, 0b011), (1, 0)])
+@pytest.mark.parametrize("rows,n_src", [(1, 0), (33, 7), (700, 41), (1000, 0), (40000, 333)])
+def test_mlp_backward_recompute(cuda_device, L, mask, rows, n_src):
+    """tspgnn_mlp_bwd_rc_h2 (hidden activations recomputed, data gradient on the fp16 matrix cores) against float64
+    arithmetic on the chain with the forward's own relu masks: dX (accumulated) and the pre-activation gradients it hands
+    to the weight-gradient reduction; the recomputed activations are bit-identical to the f16x2 forward's."""
+    d = 64
+    rng = np.random.RandomState(100 * L + rows + mask)
+    X = rng.randn(rows, d).astype(np.float32)
+    Ws = [(rng.randn(d, d) / np.sqrt(d)).astype(np.float32) for _ in range(L)]
+    bs = [(0.1 * rng.randn(d)).astype(np.float32) for _ in range(L)]
+    if n_src:
+        uv = np.stack([rng.randint(0, n_src, rows), rng.randint(0, n_src, rows)], 1).astype(np.int32)
+        # gradients of very different magnitude from row to row, as in a real backward pass
+        src = (rng.randn(n_src, d) * 10.0 ** rng.uniform(-7, -2, (n_src, 1))).astype(np.float32)
+        dY = src[uv[:, 0]] + src[uv[:, 1]]
+    else:
+        uv, src = None, None
+        dY = (rng.randn(rows, d) * 10.0 ** rng.uniform(-7, -2, (rows, 1))).astype(np.float32)
+    dX0 = (0.5 * rng.randn(rows, d) * np.abs(dY).max(1, keepdims=True)).astype(np.float32)   # (of each row's own scale)
+    # the f16x2 forward: messages and hidden activations
+    wb = _h2_blocks(Ws, bs, cuda_device)
+    wt = _h2_blocks(Ws, bs, cuda_device, transposed=True)
+    Xd = dev(X, cuda_device)
+    Y = empty((rows, d), cuda_device)
+    acts = empty((max(L - 1, 1), rows, d), cuda_device)
+    task = _lib.MlpTask(_lib.ptr(Xd), _lib.ptr(wb), _lib.ptr(Y), _lib.ptr(acts) if L > 1 else None, rows * d, rows, L, mask, None,
+                        None, None)
+    _lib.call_multi("tspgnn_mlp_fwd_multi_h2", [task], d)
+    torch.cuda.synchronize()
+    A = [X.astype(np.float64)] + [acts[l].cpu().numpy().astype(np.float64) for l in range(L - 1)] + [Y.cpu().numpy().astype(np.float64)]
+    G = dY.astype(np.float64)
+    want_dpre = [None] * L
+    for l in range(L - 1, -1, -1):
+        if (mask >> l) & 1:
+            G = G * (A[l + 1] > 0)
+        want_dpre[l] = G
+        G = G @ Ws[l].astype(np.float64).T
+    # HIP
+    dX = dev(dX0, cuda_device)
+    dYd = dev(src if n_src else dY, cuda_device)
+    uvd = dev(uv, cuda_device, np.int32) if n_src else None
+    acts2 = empty((max(L - 1, 1), rows, d), cuda_device, 7.0)
+    dpre = empty((L, rows, d), cuda_device, 7.0)
+    t = _lib.MlpBwdRcTask(_lib.ptr(Xd), _lib.ptr(wb), _lib.ptr(wt), _lib.ptr(Y), _lib.ptr(dYd), _lib.ptr(uvd), _lib.ptr(dX), 1,
+                          rows, L, mask, _lib.ptr(acts2), rows * d, _lib.ptr(dpre), rows * d, None)
+    _lib.call("tspgnn_mlp_bwd_rc_h2", ctypes.cast(ctypes.pointer(t), ctypes.c_void_p), d, None)
+    torch.cuda.synchronize()
+    if L > 1:
+        assert torch.equal(acts2, acts)
+    got = dX.cpu().numpy().astype(np.float64) - dX0
+    # per row: the rows' scales differ by five decades, and each must come out to fp32-class accuracy
+    scale = np.maximum(np.abs(G).max(1, keepdims=True), 1e-30)
+    assert (np.abs(got - G) / scale).max() < 4 * TOL
+    for l in range(L):
+        ref = want_dpre[l]
+        scale = np.maximum(np.abs(ref).max(1, keepdims=True), 1e-30)
+        assert (np.abs(dpre[l].cpu().numpy() - ref) / scale).max() < TOL, ("dpre", l)
+    # the same chain with the weight gradients formed in the launch: two launches into one partial buffer, then the fold
+    # into a gradient slice that already holds values; dX bit-identical to the two-kernel form
+    n_part = int(_lib.lib.tspgnn_mlp_bwd_rc_partial_floats(d, L))
+    part = empty((n_part,), cuda_device, 0.0)
+    outs = []
+    for rep in range(2):
+        dX2 = dev(dX0, cuda_device)
+        t = _lib.MlpBwdRcTask(_lib.ptr(Xd), _lib.ptr(wb), _lib.ptr(wt), _lib.ptr(Y), _lib.ptr(dYd), _lib.ptr(uvd), _lib.ptr(dX2), 1,
+                              rows, L, mask, None, 0, None, 0, _lib.ptr(part))
+        _lib.call("tspgnn_mlp_bwd_rc_h2", ctypes.cast(ctypes.pointer(t), ctypes.c_void_p), d, None)
+        torch.cuda.synchronize()
+        assert torch.equal(dX2, dX)
+        outs.append(part.clone())
+    assert torch.equal(outs[1], 2 * outs[0])      # (deterministic: the second launch adds exactly what the first one did)
+    g0 = (1e-3 * rng.randn(L * (d * d + d))).astype(np.float32) * np.float32(np.abs(want_dpre[0]).max())
+    grad = dev(g0, cuda_device)
+    _lib.call("tspgnn_mlp_bwd_rc_finish_f32", _lib.ptr(part), _lib.ptr(grad), d, L, None)
+    torch.cuda.synchronize()
+    got = grad.cpu().numpy().astype(np.float64) - g0
+    for l in range(L):
+        o = l * (d * d + d)
+        assert rel_err(got[o:o + d * d].reshape(d, d), 2 * (A[l].T @ want_dpre[l])) < TOL, ("dW", l)
+        assert rel_err(got[o + d * d:o + d * d + d], 2 * want_dpre[l].sum(0)) < TOL, ("db", l)

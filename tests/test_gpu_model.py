@@ -804,6 +804,43 @@ def test_pushed_training_gradients_equal_the_plain_form(cuda_device, name, d, T)
         assert np.abs(gp[k] - gu[k]).max() / scale < 1e-4, k
 
 
+@pytest.mark.parametrize("fused_dw", [True, False])
+@pytest.mark.parametrize("name,d,T", [("ragged_B6", 64, 4), ("n20_B32", 64, 5), ("n5_B2", 64, 1)])
+def test_recomputed_training_gradients_equal_the_taped_form(cuda_device, name, d, T, fused_dw):
+    """Training with the pushed message MLP's backward recomputing its hidden activations (tspgnn_mlp_bwd_rc_h2, opt-in;
+    the forward then tapes only the messages and runs the MLP inside the cell launch; ``fused_dw``: the MLP's weight
+    gradients formed in the same launch) against the taped form: same loss, bit-identical states, gradients equal up to
+    the arithmetic of the data gradient (fp16 matrix cores on scaled splits instead of the fp32 matrix instruction)."""
+    t = pack_tuple(name, 1)
+    params = P.init_params(d, seed=8, perturb=True)
+    grads = []
+    for rc in (True, False):
+        model = tspgnn.build_network(d)
+        sess = tspgnn.Session(model)
+        sess.run(tspgnn.global_variables_initializer())
+        model.store.load(params)
+        model["gnn"].recompute_messages = rc
+        model["gnn"].recompute_weight_gradients = fused_dw
+        EV, W, C, route_exists, n_vertices, n_edges = t
+        feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+                model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+        out = sess.loss_and_grads(feed, keep_tape=True)
+        torch.cuda.synchronize()
+        tape = out["tape"]
+        assert tape.pushed["V"] and bool(tape.rc.get(("V", 0))) == rc and tape.fused == rc
+        assert tape.acts[("V", 0)].shape[0] == (1 if rc else 3)
+        grads.append((float(out["stats"][0].item()), model.store.grad_dict(), tape))
+    (loss_r, gr, tr), (loss_t, gt, tt) = grads
+    assert loss_r == loss_t
+    for v in ("V", "E"):
+        assert torch.equal(tr.H[v], tt.H[v]) and torch.equal(tr.C[v], tt.C[v])
+    assert torch.equal(tr.acts[("V", 0)][0], tt.acts[("V", 0)][2])     # the messages = the last hidden activation
+    gscale = max(np.abs(gt[k]).max() for k in gt)
+    for k in gt:
+        scale = max(np.abs(gt[k]).max(), 1e-3 * gscale)
+        assert np.abs(gr[k] - gt[k]).max() / scale < 1e-4, k
+
+
 def test_weight_gradient_chunks_agree(cuda_device):
     """GraphNN.backward reduces the weight gradients per chunk of time steps (all T when they fit the budget): one,
     two and five chunks give the same gradients up to the order of the fp32 sums."""

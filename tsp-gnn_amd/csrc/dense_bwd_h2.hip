@@ -21,15 +21,6 @@
 
 namespace tspgnn {
 
-// max over the four 16-lane groups of a wavefront (lanes l, l^16, l^32, l^48), full EXEC mask required
-__device__ __forceinline__ float max_over_lane_groups16_swap(float v) {
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    float s = fmaxf(a, b), t = s;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(s), "+v"(t));
-    return fmaxf(s, t);
-}
-
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTaskTable tt) {
     int k = 0;

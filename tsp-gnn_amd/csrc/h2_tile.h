@@ -247,6 +247,47 @@ __device__ __forceinline__ void kblock_h2_side(f32x4 (&acc)[NT], f32x4 (&side)[N
     }
 }
 
+// max over the four 16-lane groups of a wavefront (lanes l, l^16, l^32, l^48), full EXEC mask required
+__device__ __forceinline__ float max_over_lane_groups16_swap(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    float s = fmaxf(a, b), t = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(s), "+v"(t));
+    return fmaxf(s, t);
+}
+
+// kblock_h2_side for NP row tiles at once (one fragment fetch feeds NP independent chains; per output tile the MFMAs and
+// their order are those of kblock_h2_side).
+template <int NT, int NP>
+__device__ __forceinline__ void kblock_h2_side_multi(f32x4 (&acc)[NP][NT], f32x4 (&side)[NP][NT], const _Float16* wh,
+                                                     const _Float16* wl, int kb, int g, int jl, const f16x8 (&bh)[NP],
+                                                     const f16x8 (&bm)[NP]) {
+    const int off = ((kb * 4 + g) * NT * 16 + jl) * 8;
+    constexpr int PF = H2_PF < NT ? H2_PF : NT;
+    f16x8 ah[PF + 1], al[PF + 1];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        ah[p] = ldw(wh + off + p * 128);
+        al[p] = ldw(wl + off + p * 128);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t + PF < NT) {
+            ah[(t + PF) % (PF + 1)] = ldw(wh + off + (t + PF) * 128);
+            al[(t + PF) % (PF + 1)] = ldw(wl + off + (t + PF) * 128);
+        }
+        const f16x8 a_h = ah[t % (PF + 1)], a_l = al[t % (PF + 1)];
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            side[n][t] = MFMA_F16(a_h, bm[n], side[n][t]);
+            f32x4 c = acc[n][t];
+            c = MFMA_F16(a_l, bh[n], c);
+            c = MFMA_F16(a_h, bh[n], c);
+            acc[n][t] = c;
+        }
+    }
+}
+
 // bytes -> LDS, 16 bytes per lane, straight from global memory (global_load_lds_dwordx4); the LDS address of a lane is
 // the wavefront's base + lane*16.  Callers follow up with h2_stage_wait() + a barrier.
 __device__ __forceinline__ void h2_copy_to_lds(void* dst, const void* __restrict__ src, int nbytes, int tid, int nthreads) {

@@ -50,6 +50,8 @@ SIGNATURES = {
     "tspgnn_wgrad_bf16x_f32": [c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "tspgnn_lnlstm_bwd_finish_f32": [c_void_p, c_void_p, c_int, c_void_p],
     "tspgnn_mlp_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_mlp_bwd_rc_h2": [c_void_p, c_int, c_void_p],
+    "tspgnn_mlp_bwd_rc_finish_f32": [c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_gather_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_gather_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -88,6 +90,7 @@ HOST_FUNCTIONS = ("tspgnn_host_pack_instance", "tspgnn_host_route_cost", "tspgnn
 SIZE_QUERIES = {
     "tspgnn_lnlstm_bwd_workspace_floats": [c_int],
     "tspgnn_wgrad_workspace_floats": [c_longlong, c_int, c_int],
+    "tspgnn_mlp_bwd_rc_partial_floats": [c_int, c_int],
     "tspgnn_wcolsum_workspace_floats": [c_longlong, c_int],
     "tspgnn_einit_bwd_workspace_floats": [c_int, c_int],
     "tspgnn_adam_workspace_floats": [],
@@ -157,6 +160,14 @@ class MlpBwdTask(ctypes.Structure):
     _fields_ = [("dY", c_void_p), ("wt", c_void_p), ("acts", c_void_p), ("acts_stride", c_longlong), ("Yout", c_void_p),
                 ("dpre", c_void_p), ("dpre_stride", c_longlong), ("dX", c_void_p), ("accumulate_dx", c_int),
                 ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint), ("uv", c_void_p), ("acts_bf16", c_int)]
+
+
+class MlpBwdRcTask(ctypes.Structure):
+    """tspgnn_mlp_bwd_rc_task (include/tspgnn.h)."""
+    _fields_ = [("X", c_void_p), ("wb", c_void_p), ("wt", c_void_p), ("Yout", c_void_p), ("dY", c_void_p), ("uv", c_void_p),
+                ("dX", c_void_p), ("accumulate_dx", c_int), ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint),
+                ("acts", c_void_p), ("acts_stride", c_longlong), ("dpre", c_void_p), ("dpre_stride", c_longlong),
+                ("partial", c_void_p)]
 
 
 class TspgnnError(RuntimeError):

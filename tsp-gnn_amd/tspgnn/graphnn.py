@@ -731,6 +731,14 @@ class GraphNN(object):
         # default: the tape makes the training forward HBM-write-bound, and there the two plain launches at full occupancy
         # measured 0.2 ms per step FASTER than the fused one (C2: 11.75 vs 11.95 ms)
         self.fuse_training_messages = os.environ.get("TSPGNN_FUSE_TRAINING", "0") == "1"
+        # training (f16x2, pushed message MLPs of width 64), OPT-IN (TSPGNN_RECOMPUTE=1): the backward recomputes the MLP's
+        # hidden activations (tspgnn_mlp_bwd_rc_h2) so that the forward tapes only the messages and runs the message MLP
+        # inside the cell launch as the inference plan does; with recompute_weight_gradients (TSPGNN_RECOMPUTE_DW, default on
+        # within the mode) the MLP's weight gradients are formed in that launch too.  Both forms are parity-green and
+        # deterministic; off by default because they do not pay at C2 (round 5, one box: taped 10.98-11.19 ms per training
+        # step, recomputed 11.23-11.33 ms, with the fused weight gradients 11.3 ms at best and unstable -- DESIGN_HISTORY)
+        self.recompute_messages = os.environ.get("TSPGNN_RECOMPUTE", "0") == "1"
+        self.recompute_weight_gradients = os.environ.get("TSPGNN_RECOMPUTE_DW", "1") != "0"
         # GEMM arithmetic of the inference forward, all fp32-class in accuracy: "f16x2" = fp16 matrix cores on
         # two-piece splits of the fp32 operands (csrc/dense_h2.hip, the default); "bf16x3" = bf16 matrix cores on
         # exact three-piece splits (csrc/dense_x3.hip); "f32" = fp32 MFMA.  TSPGNN_GEMM in the environment selects
@@ -1564,11 +1572,20 @@ class GraphNN(object):
                 if "msg" in u:
                     mlp = self._msg_MLPs[u["msg"]]
                     src = u["var"]
-                    tape.acts[(v, i)] = torch.empty((max(mlp.n_square - 1, 1), T, n[src], self.var[src]), **stored)
+                    tape.acts[(v, i)] = None     # allocated below, once the arithmetic (hence the tape's form) is known
         tape.fused = False
+        tape.rc = {}
+
+        def alloc_acts():
+            for (v, i) in tape.acts:
+                u = self.loop[v][i]
+                mlp, src = self._msg_MLPs[u["msg"]], u["var"]
+                layers = 1 if tape.rc.get((v, i)) else max(mlp.n_square - 1, 1)   # (recomputed: the messages only)
+                tape.acts[(v, i)] = torch.empty((layers, T, n[src], self.var[src]), **stored)
         if bf16:
             tape.arith = "bf16"
             tape.pushed = {v: False for v in self.var}
+            alloc_acts()
             self._forward_train_bf16(tape, n, T)
             return {v: LSTMStateTuple(c=tape.C[v][T], h=tape.H[v][T]) for v in self.var}, tape
         # forward GEMMs in the split-operand arithmetic selected by self.gemm (fp32-class accuracy).  With f16x2 the
@@ -1601,6 +1618,12 @@ class GraphNN(object):
         # runs with K' = [W Kx ; Kh], z starting at degree * (b Kx) (LayerNormBasicLSTMCell.pushed_kernel)
         tape.pushed = {v: bool(arith == "h2" and self.push_training and not self.fuse_training_messages
                                and self._pushable(v, mats, tape.folded)) for v in self.var}
+        # recomputed message MLPs (tspgnn_mlp_bwd_rc_h2): the pushed entries whose prefix the kernel covers
+        for v in self.var:
+            if tape.pushed[v] and self.recompute_messages:
+                mlp = self._msg_MLPs[self.loop[v][0]["msg"]]
+                tape.rc[(v, 0)] = mlp.recompute_ok(mlp.n_square - 1)
+        alloc_acts()
 
         def message_dest(v, i, t):
             """(out, projection) of loop entry (v, i)'s message MLP at step t: outputs straight into the tape."""
@@ -1625,9 +1648,13 @@ class GraphNN(object):
                         acts = tape.acts[(v, i)]
                         if tape.pushed[v]:      # all but the last layer; its output is the last saved activation
                             k = mlp.n_square - 1
-                            out = acts[k - 1, t]
-                            mlp_tasks.setdefault(mlp.sizes[-1], []).append(
-                                mlp.prefix_task(y, out, k, arith=arith, acts=acts[:, t], acts_stride=acts.stride(0)))
+                            if tape.rc.get((v, i)):
+                                out = acts[0, t]
+                                task = mlp.prefix_task(y, out, k, arith=arith)
+                            else:
+                                out = acts[k - 1, t]
+                                task = mlp.prefix_task(y, out, k, arith=arith, acts=acts[:, t], acts_stride=acts.stride(0))
+                            mlp_tasks.setdefault(mlp.sizes[-1], []).append(task)
                             msg_out[(v, i)] = out
                             continue
                         out, proj = message_dest(v, i, t)
@@ -1686,7 +1713,8 @@ class GraphNN(object):
         # f16x2, opt-in (fuse_training_messages): the message MLPs of step t+1 ride in the cell launch of step t, on the
         # rows of h' it still holds in registers (tspgnn_lnlstm_mlp_fwd_multi_h2 as in the inference plan, here writing
         # the tape: states, hidden activations, messages and projected messages of every step)
-        consumers = self._single_consumers() if arith == "h2" and self.fuse_training_messages else None
+        consumers = self._single_consumers() if arith == "h2" and (self.fuse_training_messages or any(tape.rc.values())) \
+            else None
         tape.fused = consumers is not None
         if consumers is not None:
             msg_out = messages(0) if T > 0 else {}
@@ -1699,12 +1727,19 @@ class GraphNN(object):
                         cv, ci = consumers[v]
                         mlp = self._msg_MLPs[self.loop[cv][ci]["msg"]]
                         acts = tape.acts[(cv, ci)]
-                        out, proj = message_dest(cv, ci, t + 1)
-                        pw, po = proj if proj is not None else (None, None)
-                        k = mlp.n_square
+                        if tape.pushed[cv]:     # all but the last layer; the message is the last hidden activation
+                            k = mlp.n_square - 1
+                            rc = tape.rc.get((cv, ci))
+                            out, (pw, po) = acts[0 if rc else k - 1, t + 1], (None, None)
+                            saved = None if (rc or k == 1) else acts[:, t + 1]
+                        else:
+                            out, proj = message_dest(cv, ci, t + 1)
+                            pw, po = proj if proj is not None else (None, None)
+                            k = mlp.n_square
+                            saved = acts[:, t + 1] if k > 1 else None
                         ct = _lib.CellMlpTask(task, _lib.ptr(mlp.wb_packed_split(arith, 0, k - 1, d)), k, mlp.relu_mask(0, k),
                                               _lib.ptr(out), _lib.ptr(pw), _lib.ptr(po), 0, 0,
-                                              _lib.ptr(acts[:, t + 1]) if k > 1 else None, acts.stride(0))
+                                              _lib.ptr(saved), acts.stride(0))
                         nxt[(cv, ci)] = out
                     else:
                         ct = _lib.CellMlpTask(task, None, 0, 0, None, None, None, 0, 0, None, 0)
@@ -1826,9 +1861,12 @@ class GraphNN(object):
         # the pre-activations of the chunk (4d + the MLP layers' d floats per row and step) fit the budget -- the C2
         # case, ~6 GB -- else the largest chunk that does (a C5 shard: 84 GB for all 64 steps)
         pushed = getattr(tape, "pushed", None) or {v: False for v in self.var}
+        rc = getattr(tape, "rc", None) or {}      # entries whose backward recomputes the hidden activations
+        rc_dw = self.recompute_weight_gradients   # ... and forms the weight gradients in the same launch (no chunk buffers)
         per_step = sum(n[v] * 4 * d * 4 for v, d in self.var.items())
         per_step += sum(self._msg_MLPs[self.loop[v][i]["msg"]].n_square * n[self.loop[v][i]["var"]]
-                        * self.var[self.loop[v][i]["var"]] * 4 for (v, i) in tape.acts)
+                        * self.var[self.loop[v][i]["var"]] * 4 * ((0 if rc_dw else 2) if rc.get((v, i)) else 1)
+                        for (v, i) in tape.acts)
         per_step += sum(tape.X[v].shape[1] * 4 * self.var[v] * 4 for v in self.var if folded[v] is not None)   # DZX
         per_step += sum(n[v] * 4 for v in self.var if (getattr(tape, "pushed", None) or {}).get(v))          # degrees
         if getattr(tape, "arith", None) == "bf16" and not native:
@@ -1843,11 +1881,16 @@ class GraphNN(object):
             budget = min(budget, avail // 2)
         CH = max(1, min(T, int(budget // max(per_step, 1)))) if T > 0 else 1
         DZ = {v: torch.empty((CH, n[v], 4 * d), **f32) for v, d in self.var.items()}
-        DPRE = {}
+        DPRE, RCA, RCP = {}, {}, {}
         for (v, i), acts in tape.acts.items():
             u = self.loop[v][i]
             mlp = self._msg_MLPs[u["msg"]]
+            if rc.get((v, i)) and rc_dw:
+                RCP[(v, i)] = mlp.backward_rc_partial(mlp.n_square - 1)   # workgroup partials of {dW, db}, all T steps
+                continue
             DPRE[(v, i)] = torch.empty((mlp.n_square - (1 if pushed[v] else 0), CH, n[u["var"]], self.var[u["var"]]), **f32)
+            if rc.get((v, i)):   # the recomputed hidden activations a_1 .. a_{L-1} of the chunk's steps
+                RCA[(v, i)] = torch.empty((max(mlp.n_square - 2, 1), CH, n[u["var"]], self.var[u["var"]]), **f32)
         # LayerNorm-gradient partials of all T steps accumulate here (zeroed); one fold per cell after the loop
         ws = {v: _lib.workspace("tspgnn_lnlstm_bwd_workspace_floats", d, device=device).zero_() for v, d in self.var.items()}
         DZX = {v: torch.empty((CH, tape.X[v].shape[1], 4 * self.var[v]), **f32) for v in self.var if folded[v] is not None}
@@ -1881,7 +1924,10 @@ class GraphNN(object):
                 mlp = self._msg_MLPs[u["msg"]]
                 src, dsrc = u["var"], self.var[u["var"]]
                 layers = dpre.shape[0]      # (a pushed entry's last layer has its gradient formed on the receiving side)
-                inputs = [tape.h_steps(src, t0, t1)] + [tape.acts_steps((v, i), l, t0, t1) for l in range(layers - 1)]
+                if rc.get((v, i)):
+                    inputs = [tape.h_steps(src, t0, t1)] + [RCA[(v, i)][l, :steps].reshape(-1, dsrc) for l in range(layers - 1)]
+                else:
+                    inputs = [tape.h_steps(src, t0, t1)] + [tape.acts_steps((v, i), l, t0, t1) for l in range(layers - 1)]
                 mlp.backward_weights(inputs, [dpre[l, :steps].reshape(-1, dsrc) for l in range(layers)], steps * n[src],
                                      n_layers=layers)
 
@@ -1937,7 +1983,7 @@ class GraphNN(object):
                 else:
                     cell.backward_data(DZ[v][k], dX[v], ndH[v])
             # ---- 3: adjoint adjacency products, then every message MLP's data gradient in one launch
-            mlp_tasks, targets = [], []
+            mlp_tasks, rc_tasks, targets = [], [], []
             for v in self.var:
                 off = 0
                 for i, u in enumerate(self.loop[v]):
@@ -1953,6 +1999,23 @@ class GraphNN(object):
                             gather_uv = adj.uv     # the adjoint of the row-sum is a two-row gather: the MLP launch forms it
                         else:
                             dy = adj.matmul(dy, transpose=not u.get("transpose?", False))
+                    if "msg" in u and rc.get((v, i)):
+                        # the chain is recomputed from its input rows; data and weight gradients in one launch
+                        mlp = self._msg_MLPs[u["msg"]]
+                        if src in targets:
+                            raise NotImplementedError("recomputed message MLP: a second writer of the source's gradient")
+                        h_src = tape.h(src, t)
+                        keep.append(h_src)
+                        if rc_dw:
+                            task = mlp.backward_rc_task(mlp.n_square - 1, h_src, tape.acts[(v, i)][0, t], dy, ndH[src], True,
+                                                        gather_uv=gather_uv, partial=RCP[(v, i)])
+                        else:
+                            dpre, rca = DPRE[(v, i)], RCA[(v, i)]
+                            task = mlp.backward_rc_task(mlp.n_square - 1, h_src, tape.acts[(v, i)][0, t], dy, ndH[src], True,
+                                                        rca[:, k], rca.stride(0), dpre[:, k], dpre.stride(0), gather_uv=gather_uv)
+                        rc_tasks.append((mlp, task, dy))
+                        targets.append(src)
+                        continue
                     if "msg" in u:
                         mlp = self._msg_MLPs[u["msg"]]
                         (acts_t, acts_stride), dpre = tape.acts_at((v, i), t), DPRE[(v, i)]
@@ -1981,9 +2044,15 @@ class GraphNN(object):
             for d, ts in by_d.items():
                 for j in range(0, len(ts), 4):
                     _lib.call_multi("tspgnn_mlp_bwd_multi_f32", ts[j:j + 4], d)
+            for mlp, task, _ in rc_tasks:
+                _lib.call("tspgnn_mlp_bwd_rc_h2", ctypes.cast(ctypes.pointer(task), ctypes.c_void_p), mlp.sizes[-1],
+                          _lib.current_stream())
             dH, dC = ndH, ndC
             if k == 0:      # the chunk [t, t + CH) is complete
                 weight_gradients(t, min(t + CH, T))
+        for (v, i), part in RCP.items():
+            mlp = self._msg_MLPs[self.loop[v][i]["msg"]]
+            mlp.backward_rc_finish(mlp.n_square - 1, part)
         for v in self.var:
             self._RNN_cells[v].backward_finish(ws[v])      # LayerNorm parameters: the deferred per-step partials
             if pushed[v]:

@@ -192,6 +192,51 @@ class Mlp(object):
             return out
         return self.store.packed(("mlpT", self.name, first, last), build)
 
+    def wt_packed_h2(self, first, last, d):
+        """tspgnn_pack_weights_h2(W_l^T) (two fp16 pieces of 2^s W_l^T, 4 d d bytes) for square layers first..last back
+        to back: the data-gradient operand of tspgnn_mlp_bwd_rc_h2."""
+        def build(out):
+            if out is None:
+                out = torch.empty((last - first + 1) * 4 * d * d, dtype=torch.uint8, device=self.store.theta.device)
+            st = _lib.current_stream()
+            for j in range(last - first + 1):
+                Wt = self.store.view(self.layer_names[first + j] + "/kernel").t().contiguous()
+                _lib.call("tspgnn_pack_weights_h2", _lib.ptr(Wt), _lib.ptr(out[j * 4 * d * d:(j + 1) * 4 * d * d]), d, d,
+                          None, st)
+            return out
+        return self.store.packed(("mlpT.h2", self.name, first, last), build)
+
+    def recompute_ok(self, n_layers):
+        """tspgnn_mlp_bwd_rc_h2 covers the first ``n_layers`` square layers of this Mlp (d = 64, one to three layers)."""
+        kind, d, n_sq, head = self._plan
+        return kind == "square" and d == 64 and 1 <= n_layers <= min(3, n_sq) and len(self._chunks()) == 1
+
+    def backward_rc_task(self, n_layers, x, y_out, dY, dX, accumulate, acts=None, acts_stride=0, dpre=None, dpre_stride=0,
+                         gather_uv=None, partial=None):
+        """An _lib.MlpBwdRcTask for the first ``n_layers`` square layers: the data gradient from the chain's input ``x``,
+        its output ``y_out`` and the incoming gradient -- the hidden activations are recomputed (csrc/mlp_bwd_rc.hip).
+        ``partial`` (backward_rc_partial()): the weight gradients are formed in the same launch and accumulate there over
+        the launches of a backward pass (folded by backward_rc_finish()); else the recomputed activations and the
+        pre-activation gradients leave through ``acts`` / ``dpre`` for backward_weights()."""
+        kind, d, n_sq, head = self._plan
+        return _lib.MlpBwdRcTask(_lib.ptr(x), _lib.ptr(self.wb_packed_split("h2", 0, n_layers - 1, d)),
+                                 _lib.ptr(self.wt_packed_h2(0, n_layers - 1, d)), _lib.ptr(y_out), _lib.ptr(dY),
+                                 _lib.ptr(gather_uv), _lib.ptr(dX), 1 if accumulate else 0,
+                                 dY.shape[0] if gather_uv is None else gather_uv.shape[0], n_layers,
+                                 self.relu_mask(0, n_layers), _lib.ptr(acts), acts_stride, _lib.ptr(dpre), dpre_stride,
+                                 _lib.ptr(partial))
+
+    def backward_rc_partial(self, n_layers):
+        kind, d, n_sq, head = self._plan
+        n = int(_lib.lib.tspgnn_mlp_bwd_rc_partial_floats(d, n_layers))
+        return torch.zeros(n, dtype=torch.float32, device=self.store.theta.device)
+
+    def backward_rc_finish(self, n_layers, partial):
+        """grad[W_0, b_0, .., W_{n-1}, b_{n-1}] += fixed-order sum of the workgroup partials."""
+        kind, d, n_sq, head = self._plan
+        g = self.store.grad_span(self.layer_names[0] + "/kernel", self.layer_names[n_layers - 1] + "/bias")
+        _lib.call("tspgnn_mlp_bwd_rc_finish_f32", _lib.ptr(partial), _lib.ptr(g), d, n_layers, _lib.current_stream())
+
     @property
     def n_square(self):
         return self._plan[2] if self._plan[0] == "square" else 0
