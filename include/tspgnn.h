@@ -470,6 +470,10 @@ int tspgnn_lnlstm_bwd_multi_h2(const tspgnn_lstm_bwd_task* tasks, int n_tasks, i
 /* ln_grad[10d] += fixed-order sum of the deferred partials in `workspace` (tspgnn_lnlstm_bwd_workspace_floats(d)). */
 int tspgnn_lnlstm_bwd_finish_f32(const float* workspace, float* ln_grad, int d, void* stream);
 int tspgnn_mlp_bwd_multi_f32(const tspgnn_mlp_bwd_task* tasks, int n_tasks, int d, void* stream);
+/* tspgnn_mlp_bwd_multi_f32 with the data gradient on the fp16 matrix cores (f16x2: every row of dpre_l normalised by a
+ * power of two, second piece scaled into fp16's normal range and accumulated apart -- csrc/mlp_bwd_rc.hip): the same task
+ * structure with wt = n_layers blocks tspgnn_pack_weights_h2(W_l^T) (4 d d bytes each); d = 64, fp32 tapes, <= 4 tasks. */
+int tspgnn_mlp_bwd_multi_h2(const tspgnn_mlp_bwd_task* tasks, int n_tasks, int d, void* stream);
 
 /*
  * Backward of a message MLP's square layers that RECOMPUTES the hidden activations instead of reading a forward tape

@@ -573,3 +573,49 @@ def test_mlp_backward_recompute(cuda_device, L, mask, rows, n_src):
         o = l * (d * d + d)
         assert rel_err(got[o:o + d * d].reshape(d, d), 2 * (A[l].T @ want_dpre[l])) < TOL, ("dW", l)
         assert rel_err(got[o + d * d:o + d * d + d], 2 * want_dpre[l].sum(0)) < TOL, ("db", l)
+
+
+def test_mlp_backward_taped_h2(cuda_device):
+    """tspgnn_mlp_bwd_multi_h2: the taped backward with its data gradient on the fp16 matrix cores -- two MLPs of different
+    depth in one launch (one of them in gather-init mode), against float64 arithmetic with the tape's own masks; the
+    pre-activation gradients it hands on and dX, row by row (the rows' scales differ by five decades)."""
+    d = 64
+    rng = np.random.RandomState(77)
+    specs = [dict(L=3, mask=0b111, rows=5000, n_src=120, acc=1), dict(L=4, mask=0b0111, rows=333, n_src=0, acc=0)]
+    tasks, checks = [], []
+    for sp in specs:
+        L, mask, rows, n_src = sp["L"], sp["mask"], sp["rows"], sp["n_src"]
+        Ws = [(rng.randn(d, d) / np.sqrt(d)).astype(np.float32) for _ in range(L)]
+        acts = rng.randn(max(L - 1, 1), rows, d).astype(np.float32)
+        Y = rng.randn(rows, d).astype(np.float32)
+        if n_src:
+            uv = np.stack([rng.randint(0, n_src, rows), rng.randint(0, n_src, rows)], 1).astype(np.int32)
+            src = (rng.randn(n_src, d) * 10.0 ** rng.uniform(-7, -2, (n_src, 1))).astype(np.float32)
+            dY = src[uv[:, 0]] + src[uv[:, 1]]
+        else:
+            uv, src = None, None
+            dY = (rng.randn(rows, d) * 10.0 ** rng.uniform(-7, -2, (rows, 1))).astype(np.float32)
+        dX0 = (0.5 * rng.randn(rows, d) * np.abs(dY).max(1, keepdims=True)).astype(np.float32)
+        G = dY.astype(np.float64)
+        want = [None] * L
+        for l in range(L - 1, -1, -1):
+            if (mask >> l) & 1:
+                G = G * ((Y if l == L - 1 else acts[l]) > 0)
+            want[l] = G
+            G = G @ Ws[l].astype(np.float64).T
+        wt = _h2_blocks(Ws, [None] * L, cuda_device, transposed=True)
+        dpre = empty((L, rows, d), cuda_device, 7.0)
+        dX = dev(dX0, cuda_device)
+        tasks.append(_lib.MlpBwdTask(_lib.ptr(dev(src if n_src else dY, cuda_device)), _lib.ptr(wt), _lib.ptr(dev(acts, cuda_device)),
+                                     rows * d, _lib.ptr(dev(Y, cuda_device)), _lib.ptr(dpre), rows * d, _lib.ptr(dX), sp["acc"], rows,
+                                     L, mask, _lib.ptr(dev(uv, cuda_device, np.int32)) if n_src else None, 0))
+        checks.append((dX, dX0 * sp["acc"], G, dpre, want))
+    _lib.call_multi("tspgnn_mlp_bwd_multi_h2", tasks, d)
+    torch.cuda.synchronize()
+    for dX, base, G, dpre, want in checks:
+        got = dX.cpu().numpy().astype(np.float64) - base
+        scale = np.maximum(np.abs(G).max(1, keepdims=True), 1e-30)
+        assert (np.abs(got - G) / scale).max() < 4 * TOL
+        for l, ref in enumerate(want):
+            scale = np.maximum(np.abs(ref).max(1, keepdims=True), 1e-30)
+            assert (np.abs(dpre[l].cpu().numpy() - ref) / scale).max() < TOL, ("dpre", l)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "tspgnn_wgrad_bf16x_f32": [c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "tspgnn_lnlstm_bwd_finish_f32": [c_void_p, c_void_p, c_int, c_void_p],
     "tspgnn_mlp_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
+    "tspgnn_mlp_bwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_mlp_bwd_rc_h2": [c_void_p, c_int, c_void_p],
     "tspgnn_mlp_bwd_rc_finish_f32": [c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_gather_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -736,7 +736,10 @@ class GraphNN(object):
         # inside the cell launch as the inference plan does; with recompute_weight_gradients (TSPGNN_RECOMPUTE_DW, default on
         # within the mode) the MLP's weight gradients are formed in that launch too.  Both forms are parity-green and
         # deterministic; off by default because they do not pay at C2 (round 5, one box: taped 10.98-11.19 ms per training
-        # step, recomputed 11.23-11.33 ms, with the fused weight gradients 11.3 ms at best and unstable -- DESIGN_HISTORY)
+        # step, recomputed 11.23-11.33 ms, with the weight gradients in the launch 11.7 vs 11.3 ms -- DESIGN_HISTORY)
+        # training (f16x2, width 64): the message MLPs' data gradient on the fp16 matrix cores (tspgnn_mlp_bwd_multi_h2)
+        # instead of the fp32 matrix instruction (TSPGNN_MLP_BWD_H2=0: A/B)
+        self.mlp_backward_h2 = os.environ.get("TSPGNN_MLP_BWD_H2", "1") != "0"
         self.recompute_messages = os.environ.get("TSPGNN_RECOMPUTE", "0") == "1"
         self.recompute_weight_gradients = os.environ.get("TSPGNN_RECOMPUTE_DW", "1") != "0"
         # GEMM arithmetic of the inference forward, all fp32-class in accuracy: "f16x2" = fp16 matrix cores on
@@ -2020,30 +2023,31 @@ class GraphNN(object):
                         mlp = self._msg_MLPs[u["msg"]]
                         (acts_t, acts_stride), dpre = tape.acts_at((v, i), t), DPRE[(v, i)]
                         keep.append(acts_t)
+                        h2 = bool(bwd_arith == "h2" and self.mlp_backward_h2 and mlp.backward_h2_ok(acts_t))
                         if pushed[v]:   # the chain ends at the last hidden activation (a relu layer: masked by its output)
                             task = mlp.backward_prefix_task(dpre.shape[0], dy, acts_t, acts_stride, acts_t[dpre.shape[0] - 1],
-                                                            dpre[:, k], dpre.stride(0), ndH[src], True, gather_uv=gather_uv)
+                                                            dpre[:, k], dpre.stride(0), ndH[src], True, gather_uv=gather_uv, h2=h2)
                             if task is None or src in targets:
                                 raise NotImplementedError("pushed training needs the message MLP's backward in one launch")
-                            mlp_tasks.append((self.var[src], task, dy))
+                            mlp_tasks.append(((self.var[src], h2), task, dy))
                             targets.append(src)
                             continue
                         task = mlp.backward_task(dy, acts_t, acts_stride, None, dpre[:, k], dpre.stride(0),
-                                                 ndH[src], True, gather_uv=gather_uv)
+                                                 ndH[src], True, gather_uv=gather_uv, h2=h2)
                         if task is None or src in targets:   # several kernels, or a second writer of ndH[src]
                             mlp.backward_data(dy, acts_t, acts_stride, None, dpre[:, k], dpre.stride(0), ndH[src],
                                               accumulate=True)
                         else:
-                            mlp_tasks.append((self.var[src], task, dy))
+                            mlp_tasks.append(((self.var[src], h2), task, dy))
                             targets.append(src)
                     else:
                         ndH[src].add_(dy)
             by_d = {}
-            for d, task, _ in mlp_tasks:
-                by_d.setdefault(d, []).append(task)
-            for d, ts in by_d.items():
+            for key, task, _ in mlp_tasks:
+                by_d.setdefault(key, []).append(task)
+            for (d, h2), ts in by_d.items():
                 for j in range(0, len(ts), 4):
-                    _lib.call_multi("tspgnn_mlp_bwd_multi_f32", ts[j:j + 4], d)
+                    _lib.call_multi("tspgnn_mlp_bwd_multi_" + ("h2" if h2 else "f32"), ts[j:j + 4], d)
             for mlp, task, _ in rc_tasks:
                 _lib.call("tspgnn_mlp_bwd_rc_h2", ctypes.cast(ctypes.pointer(task), ctypes.c_void_p), mlp.sizes[-1],
                           _lib.current_stream())

@@ -312,24 +312,33 @@ class Mlp(object):
             _lib.call_multi("tspgnn_mlp_bwd_multi_f32", [task], d)
             g = dst
 
-    def backward_task(self, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, gather_uv=None):
+    def backward_h2_ok(self, acts):
+        """tspgnn_mlp_bwd_multi_h2 (data gradient on the fp16 matrix cores) covers this Mlp's single-kernel chain."""
+        kind, d, n_sq, head = self._plan
+        return kind == "square" and d == 64 and len(self._chunks()) == 1 and not _bf16_flag(acts)
+
+    def backward_task(self, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, gather_uv=None, h2=False):
         """An _lib.MlpBwdTask for a single-kernel chain (None if several kernels are needed).
-        ``gather_uv`` (int32 [rows,2]): dY holds SOURCE rows and the chain starts from dY[u] + dY[v] per row."""
+        ``gather_uv`` (int32 [rows,2]): dY holds SOURCE rows and the chain starts from dY[u] + dY[v] per row.
+        ``h2``: the task is for tspgnn_mlp_bwd_multi_h2 (weights in the f16x2 packing of W^T)."""
         kind, d, n_sq, head = self._plan
         if len(self._chunks()) != 1:
             return None
-        return _lib.MlpBwdTask(_lib.ptr(dY), _lib.ptr(self.wt_packed(0, n_sq - 1, d)), _lib.ptr(acts), acts_stride,
+        wt = self.wt_packed_h2(0, n_sq - 1, d) if h2 else self.wt_packed(0, n_sq - 1, d)
+        return _lib.MlpBwdTask(_lib.ptr(dY), _lib.ptr(wt), _lib.ptr(acts), acts_stride,
                                _lib.ptr(y_out), _lib.ptr(dpre), dpre_stride, _lib.ptr(dX), 1 if accumulate else 0,
                                dY.shape[0] if gather_uv is None else gather_uv.shape[0], n_sq, self.relu_mask(0, n_sq),
                                _lib.ptr(gather_uv), _bf16_flag(acts))
 
-    def backward_prefix_task(self, n_layers, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, gather_uv=None):
+    def backward_prefix_task(self, n_layers, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, gather_uv=None,
+                             h2=False):
         """backward_task for the first ``n_layers`` square layers only (the rest was pushed elsewhere); ``y_out`` = the
         prefix's output (read when its last layer has relu)."""
         kind, d, n_sq, head = self._plan
         if len(self._chunks()) != 1 or not (1 <= n_layers <= n_sq):
             return None
-        return _lib.MlpBwdTask(_lib.ptr(dY), _lib.ptr(self.wt_packed(0, n_layers - 1, d)), _lib.ptr(acts), acts_stride,
+        wt = self.wt_packed_h2(0, n_layers - 1, d) if h2 else self.wt_packed(0, n_layers - 1, d)
+        return _lib.MlpBwdTask(_lib.ptr(dY), _lib.ptr(wt), _lib.ptr(acts), acts_stride,
                                _lib.ptr(y_out), _lib.ptr(dpre), dpre_stride, _lib.ptr(dX), 1 if accumulate else 0,
                                dY.shape[0] if gather_uv is None else gather_uv.shape[0], n_layers,
                                self.relu_mask(0, n_layers), _lib.ptr(gather_uv), _bf16_flag(acts))
