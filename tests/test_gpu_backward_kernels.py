@@ -575,19 +575,32 @@ def test_mlp_backward_recompute(cuda_device, L, mask, rows, n_src):
         assert rel_err(got[o + d * d:o + d * d + d], 2 * want_dpre[l].sum(0)) < TOL, ("db", l)
 
 
-def test_mlp_backward_taped_h2(cuda_device):
+@pytest.mark.parametrize("d,bf16", [(64, False), (128, True), (128, False), (64, True)])
+def test_mlp_backward_taped_h2(cuda_device, d, bf16):
     """tspgnn_mlp_bwd_multi_h2: the taped backward with its data gradient on the fp16 matrix cores -- two MLPs of different
-    depth in one launch (one of them in gather-init mode), against float64 arithmetic with the tape's own masks; the
-    pre-activation gradients it hands on and dX, row by row (the rows' scales differ by five decades)."""
-    d = 64
-    rng = np.random.RandomState(77)
-    specs = [dict(L=3, mask=0b111, rows=5000, n_src=120, acc=1), dict(L=4, mask=0b0111, rows=333, n_src=0, acc=0)]
+    depth in one launch (one of them in gather-init mode), fp32 and bf16 tapes, widths 64 and 128, against float64
+    arithmetic with the tape's own masks; the pre-activation gradients it hands on and dX, row by row (the rows' scales
+    differ by five decades)."""
+    rng = np.random.RandomState(77 + d)
+    if d == 64:
+        specs = [dict(L=3, mask=0b111, rows=5000, n_src=120, acc=1), dict(L=4, mask=0b0111, rows=333, n_src=0, acc=0)]
+    else:
+        specs = [dict(L=2, mask=0b11, rows=3000, n_src=90, acc=1), dict(L=2, mask=0b01, rows=77, n_src=0, acc=0)]
     tasks, checks = [], []
     for sp in specs:
         L, mask, rows, n_src = sp["L"], sp["mask"], sp["rows"], sp["n_src"]
         Ws = [(rng.randn(d, d) / np.sqrt(d)).astype(np.float32) for _ in range(L)]
         acts = rng.randn(max(L - 1, 1), rows, d).astype(np.float32)
         Y = rng.randn(rows, d).astype(np.float32)
+        if bf16:
+            acts = torch.from_numpy(acts).to(torch.bfloat16)
+            Y = torch.from_numpy(Y).to(torch.bfloat16)
+            acts_np, Y_np = acts.to(torch.float32).numpy(), Y.to(torch.float32).numpy()
+            acts_d, Y_d = acts.to(cuda_device), Y.to(cuda_device)
+            _KEEP.extend([acts_d, Y_d])
+        else:
+            acts_np, Y_np = acts, Y
+            acts_d, Y_d = dev(acts, cuda_device), dev(Y, cuda_device)
         if n_src:
             uv = np.stack([rng.randint(0, n_src, rows), rng.randint(0, n_src, rows)], 1).astype(np.int32)
             src = (rng.randn(n_src, d) * 10.0 ** rng.uniform(-7, -2, (n_src, 1))).astype(np.float32)
@@ -600,15 +613,15 @@ def test_mlp_backward_taped_h2(cuda_device):
         want = [None] * L
         for l in range(L - 1, -1, -1):
             if (mask >> l) & 1:
-                G = G * ((Y if l == L - 1 else acts[l]) > 0)
+                G = G * ((Y_np if l == L - 1 else acts_np[l]) > 0)
             want[l] = G
             G = G @ Ws[l].astype(np.float64).T
         wt = _h2_blocks(Ws, [None] * L, cuda_device, transposed=True)
         dpre = empty((L, rows, d), cuda_device, 7.0)
         dX = dev(dX0, cuda_device)
-        tasks.append(_lib.MlpBwdTask(_lib.ptr(dev(src if n_src else dY, cuda_device)), _lib.ptr(wt), _lib.ptr(dev(acts, cuda_device)),
-                                     rows * d, _lib.ptr(dev(Y, cuda_device)), _lib.ptr(dpre), rows * d, _lib.ptr(dX), sp["acc"], rows,
-                                     L, mask, _lib.ptr(dev(uv, cuda_device, np.int32)) if n_src else None, 0))
+        tasks.append(_lib.MlpBwdTask(_lib.ptr(dev(src if n_src else dY, cuda_device)), _lib.ptr(wt), _lib.ptr(acts_d),
+                                     rows * d, _lib.ptr(Y_d), _lib.ptr(dpre), rows * d, _lib.ptr(dX), sp["acc"], rows,
+                                     L, mask, _lib.ptr(dev(uv, cuda_device, np.int32)) if n_src else None, 1 if bf16 else 0))
         checks.append((dX, dX0 * sp["acc"], G, dpre, want))
     _lib.call_multi("tspgnn_mlp_bwd_multi_h2", tasks, d)
     torch.cuda.synchronize()

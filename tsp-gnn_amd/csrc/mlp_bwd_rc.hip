@@ -17,6 +17,7 @@
 // Both forms are parity-green; neither pays at C2 (DESIGN_HISTORY, round 5), so the training step keeps the taped form
 // by default and these are opt-in (GraphNN.recompute_messages).
 #include "common.h"
+#include "bf16_tile.h"
 #include "h2_tile.h"
 #include "mfma_tile.h"
 
@@ -198,9 +199,10 @@ static int launch_mlp_bwd_rc(const tspgnn_mlp_bwd_rc_task& tk, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // The TAPED backward (dense_bwd.hip's mlp_bwd_kernel: masks from the saved activations, dpre written for the weight-gradient
-// reduction) with its data gradient on the fp16 matrix cores instead of 256 v_mfma_f32_16x16x4_f32 per layer and tile:
-// tspgnn_mlp_bwd_multi_h2.  Same task structure (several MLPs per launch, gather-init mode); wt = n_layers blocks
-// tspgnn_pack_weights_h2(W_l^T).  d = 64, up to four layers (64 KB of LDS).
+// reduction) with its data gradient on the fp16 matrix cores instead of 256 (d = 64; 1024 at d = 128) v_mfma_f32_16x16x4_f32
+// per layer and tile: tspgnn_mlp_bwd_multi_h2.  Same task structure (several MLPs per launch, gather-init mode, bf16
+// tapes); wt = n_layers blocks tspgnn_pack_weights_h2(W_l^T).  d = 64 with up to four layers (64 KB of LDS), d = 128 with
+// up to two (128 KB) -- the chunking of tspgnn_mlp_bwd_multi_f32.
 constexpr int kMaxTasksBwdH2 = 4;
 struct MlpBwdTaskTableH2 {
     tspgnn_mlp_bwd_task task[kMaxTasksBwdH2];
@@ -208,12 +210,13 @@ struct MlpBwdTaskTableH2 {
     int n;
 };
 
-template <int MAXL>
+// ABF16: the saved activations (and Yout) are the bf16 arrays of a bf16-storage tape -- they only decide the relu masks.
+template <int D, int MAXL, bool ABF16>
 __global__ __launch_bounds__(1024) void mlp_bwd_h2_kernel(const MlpBwdTaskTableH2 tt) {
-    constexpr int D = 64;
+    constexpr int NT = D / 16, KB = D / 32;
     constexpr int WT_BYTES = 2 * D * D * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[MAXL * WT_BYTES + 16];
-    int* ticket = reinterpret_cast<int*>(lds + MAXL * WT_BYTES);
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsw[];
+    int* ticket = reinterpret_cast<int*>(ldsw + MAXL * WT_BYTES);
     int k = 0;
     while (k + 1 < tt.n && (int)blockIdx.x >= tt.blk_end[k]) ++k;
     const int blk0 = k ? tt.blk_end[k - 1] : 0;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(1024) void mlp_bwd_h2_kernel(const MlpBwdTaskTableH
     const int2* __restrict__ uv = reinterpret_cast<const int2*>(tt.task[k].uv);
     const int tiles_total = (rows + 15) / 16;
     const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4;
-    h2_copy_to_lds(lds, tt.task[k].wt, n_layers * WT_BYTES, tid, blockDim.x);
+    h2_copy_to_lds(ldsw, tt.task[k].wt, n_layers * WT_BYTES, tid, blockDim.x);
     const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
     const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
     if (tid == 0) *ticket = t_beg;
@@ -246,70 +249,81 @@ __global__ __launch_bounds__(1024) void mlp_bwd_h2_kernel(const MlpBwdTaskTableH
         const bool valid = row < rows;
         const unsigned rc = (unsigned)(valid ? row : rows - 1);
         const size_t rbase = (size_t)rc * D + g * 4;
-        f32x4 gr[1][4];
+        f32x4 gr[1][NT];
         if (uv != nullptr) {
             const int2 ends = uv[rc];
             const float* pu = dY + (size_t)ends.x * D + g * 4;
             const float* pv = dY + (size_t)ends.y * D + g * 4;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) gr[0][t] = ld4(pu + t * 16) + ld4(pv + t * 16);
+            for (int t = 0; t < NT; ++t) gr[0][t] = ld4(pu + t * 16) + ld4(pv + t * 16);
         } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) gr[0][t] = ld4(dY + rbase + t * 16);
+            for (int t = 0; t < NT; ++t) gr[0][t] = ld4(dY + rbase + t * 16);
         }
         for (int l = n_layers - 1; l >= 0; --l) {
             if ((relu_mask >> l) & 1u) {
-                const float* A = (l == n_layers - 1) ? Yout : acts + (size_t)l * acts_stride;
+                if constexpr (ABF16) {
+                    const __bf16* A = (l == n_layers - 1) ? reinterpret_cast<const __bf16*>(Yout)
+                                                          : reinterpret_cast<const __bf16*>(acts) + (size_t)l * acts_stride;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f32x4 av = ld4(A + rbase + t * 16);
+                    for (int t = 0; t < NT; ++t) {
+                        const f32x4 av = widen(ldw4(A + rbase + t * 16));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) gr[0][t][q] = av[q] > 0.f ? gr[0][t][q] : 0.f;
+                        for (int q = 0; q < 4; ++q) gr[0][t][q] = av[q] > 0.f ? gr[0][t][q] : 0.f;
+                    }
+                } else {
+                    const float* A = (l == n_layers - 1) ? Yout : acts + (size_t)l * acts_stride;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const f32x4 av = ld4(A + rbase + t * 16);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gr[0][t][q] = av[q] > 0.f ? gr[0][t][q] : 0.f;
+                    }
                 }
             }
             if (dpre != nullptr && valid) {
                 float* dst = dpre + (size_t)l * dpre_stride + rbase;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) st4(dst + t * 16, gr[0][t]);
+                for (int t = 0; t < NT; ++t) st4(dst + t * 16, gr[0][t]);
             }
             // G = dpre_l W_l^T (packed 2^s W_l^T): the row normalised to [0.5, 1), scaled second piece apart
-            const _Float16* wt = reinterpret_cast<const _Float16*>(lds + l * WT_BYTES);
-            f32x4 out[1][4], side[1][4];
+            const _Float16* wt = reinterpret_cast<const _Float16*>(ldsw + l * WT_BYTES);
+            f32x4 out[1][NT], side[1][NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) out[0][t] = side[0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) out[0][t] = side[0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
             float m = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) m = fmaxf(m, __builtin_fabsf(gr[0][t][q]));
             m = max_over_lane_groups16_swap(m);
             const int e = m > 0.f ? __builtin_amdgcn_frexp_expf(m) : 0;
             const float up = __builtin_ldexpf(1.0f, -e), down = __builtin_ldexpf(kH2InvScale, e);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < KB; ++kb) {
                 f16x8 bh[1], bm[1];
                 float xv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = gr[0][2 * kb + (j >> 2)][j & 3] * up;
                 split2s(xv, bh[0], bm[0]);
-                kblock_h2_side_multi<4, 1>(out, side, wt, wt + D * D, kb, g, rl, bh, bm);
+                kblock_h2_side_multi<NT, 1>(out, side, wt, wt + D * D, kb, g, rl, bh, bm);
             }
             const float fold = 1.0f / 2048.0f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) gr[0][t][q] = fmaf(side[0][t][q], fold, out[0][t][q]) * down;
         }
         if (dX != nullptr && valid) {
             float* p = dX + rbase;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) st4(p + t * 16, acc_dx ? ld4(p + t * 16) + gr[0][t] : gr[0][t]);
+            for (int t = 0; t < NT; ++t) st4(p + t * 16, acc_dx ? ld4(p + t * 16) + gr[0][t] : gr[0][t]);
         }
     }
 }
 
+template <int D, int MAXL>
 static int launch_mlp_bwd_h2(const tspgnn_mlp_bwd_task* tasks, int n, hipStream_t st) {
-    constexpr int D = 64;
     MlpBwdTaskTableH2 tt;
     long long cost[kMaxTasksBwdH2], total = 0, tiles_all = 0;
     for (int k = 0; k < n; ++k) {
@@ -322,8 +336,9 @@ static int launch_mlp_bwd_h2(const tspgnn_mlp_bwd_task* tasks, int n, hipStream_
         tiles_all += tiles;
     }
     tt.n = n;
+    constexpr int threads = 1024;
     int grid = n_cus();
-    const long long max_grid = (tiles_all + 15) / 16;
+    const long long max_grid = (tiles_all + threads / 64 - 1) / (threads / 64);
     if (grid > max_grid) grid = (int)max_grid;
     if (grid < n) grid = n;
     int used = 0;
@@ -333,7 +348,14 @@ static int launch_mlp_bwd_h2(const tspgnn_mlp_bwd_task* tasks, int n, hipStream_
         used += bk;
         tt.blk_end[k] = used;
     }
-    mlp_bwd_h2_kernel<4><<<used, 1024, 0, st>>>(tt);
+    const int lds_bytes = MAXL * 2 * D * D * 2 + 16;
+    const bool abf = tasks[0].acts_bf16 != 0;
+    const void* fn = abf ? reinterpret_cast<const void*>(&mlp_bwd_h2_kernel<D, MAXL, true>)
+                         : reinterpret_cast<const void*>(&mlp_bwd_h2_kernel<D, MAXL, false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return fail((int)e, "mlp_bwd_h2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (abf) mlp_bwd_h2_kernel<D, MAXL, true><<<used, threads, lds_bytes, st>>>(tt);
+    else mlp_bwd_h2_kernel<D, MAXL, false><<<used, threads, lds_bytes, st>>>(tt);
     return launched("tspgnn_mlp_bwd_multi_h2");
 }
 
@@ -604,21 +626,23 @@ extern "C" int tspgnn_mlp_bwd_rc_finish_f32(const float* partial, float* grad_wb
 
 extern "C" int tspgnn_mlp_bwd_multi_h2(const tspgnn_mlp_bwd_task* tasks, int n_tasks, int d, void* stream) {
     TSPGNN_REQUIRE(tasks && n_tasks >= 1 && n_tasks <= kMaxTasksBwdH2, "mlp_bwd_multi_h2: 1..%d tasks", kMaxTasksBwdH2);
-    TSPGNN_REQUIRE(d == 64, "mlp_bwd_h2: d=%d must be 64", d);
+    TSPGNN_REQUIRE(d == 64 || d == 128, "mlp_bwd_h2: d=%d must be 64 or 128", d);
     tspgnn_mlp_bwd_task live[kMaxTasksBwdH2];
     int n = 0;
     for (int k = 0; k < n_tasks; ++k) {
         const tspgnn_mlp_bwd_task& t = tasks[k];
         TSPGNN_REQUIRE(t.rows >= 0 && (long long)t.rows * d < (1ll << 31), "mlp_bwd_h2: rows=%d", t.rows);
         TSPGNN_REQUIRE(t.n_layers >= 1 && t.n_layers <= 4, "mlp_bwd_h2: n_layers=%d must be in 1..4", t.n_layers);
-        TSPGNN_REQUIRE(!t.acts_bf16, "mlp_bwd_h2: fp32 tapes only");
+        if (d == 128 && t.n_layers > 2)
+            return fail(TSPGNN_EUNSUPPORTED, "mlp_bwd_h2: d=128 holds at most 2 layers in LDS (got %d)", t.n_layers);
         if (t.rows == 0) continue;
         TSPGNN_REQUIRE(t.dY && t.wt, "mlp_bwd_h2: null pointer");
         const unsigned inner = t.relu_mask & ((1u << (t.n_layers - 1)) - 1u);
         TSPGNN_REQUIRE(!inner || t.acts, "mlp_bwd_h2: relu layers need the saved activations");
         TSPGNN_REQUIRE(!((t.relu_mask >> (t.n_layers - 1)) & 1u) || t.Yout, "mlp_bwd_h2: relu on the last layer needs Yout");
+        TSPGNN_REQUIRE(n == 0 || (t.acts_bf16 != 0) == (live[0].acts_bf16 != 0), "mlp_bwd_h2: the tasks of a launch share acts_bf16");
         live[n++] = t;
     }
     if (n == 0) return TSPGNN_OK;
-    return launch_mlp_bwd_h2(live, n, as_stream(stream));
+    return d == 64 ? launch_mlp_bwd_h2<64, 4>(live, n, as_stream(stream)) : launch_mlp_bwd_h2<128, 2>(live, n, as_stream(stream));
 }

@@ -2023,7 +2023,7 @@ class GraphNN(object):
                         mlp = self._msg_MLPs[u["msg"]]
                         (acts_t, acts_stride), dpre = tape.acts_at((v, i), t), DPRE[(v, i)]
                         keep.append(acts_t)
-                        h2 = bool(bwd_arith == "h2" and self.mlp_backward_h2 and mlp.backward_h2_ok(acts_t))
+                        h2 = bool((bwd_arith == "h2" or native) and self.mlp_backward_h2 and mlp.backward_h2_ok(acts_t))
                         if pushed[v]:   # the chain ends at the last hidden activation (a relu layer: masked by its output)
                             task = mlp.backward_prefix_task(dpre.shape[0], dy, acts_t, acts_stride, acts_t[dpre.shape[0] - 1],
                                                             dpre[:, k], dpre.stride(0), ndH[src], True, gather_uv=gather_uv, h2=h2)
@@ -2036,7 +2036,7 @@ class GraphNN(object):
                                                  ndH[src], True, gather_uv=gather_uv, h2=h2)
                         if task is None or src in targets:   # several kernels, or a second writer of ndH[src]
                             mlp.backward_data(dy, acts_t, acts_stride, None, dpre[:, k], dpre.stride(0), ndH[src],
-                                              accumulate=True)
+                                              accumulate=True, h2=h2)
                         else:
                             mlp_tasks.append(((self.var[src], h2), task, dy))
                             targets.append(src)

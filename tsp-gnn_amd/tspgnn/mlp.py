@@ -295,8 +295,9 @@ class Mlp(object):
                       _lib.ptr(acts[l0]) if n > 1 else None, acts_stride, rows, d, n, self.relu_mask(l0, n), st)
         return out
 
-    def backward_data(self, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate):
-        """Data gradient of the square chain (tspgnn_mlp_bwd_f32), chunk by chunk in reverse."""
+    def backward_data(self, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, h2=False):
+        """Data gradient of the square chain (tspgnn_mlp_bwd_f32; ``h2``: tspgnn_mlp_bwd_multi_h2), chunk by chunk in
+        reverse."""
         kind, d, n_sq, head = self._plan
         st, rows = _lib.current_stream(), dY.shape[0]
         g = dY
@@ -305,17 +306,19 @@ class Mlp(object):
             first = l0 == 0
             yo = y_out if last else acts[l0 + n - 1]
             dst = dX if first else torch.empty_like(dY)
-            task = _lib.MlpBwdTask(_lib.ptr(g), _lib.ptr(self.wt_packed(l0, l0 + n - 1, d)),
+            wt = self.wt_packed_h2(l0, l0 + n - 1, d) if h2 else self.wt_packed(l0, l0 + n - 1, d)
+            task = _lib.MlpBwdTask(_lib.ptr(g), _lib.ptr(wt),
                                    _lib.ptr(acts[l0]) if n > 1 else None, acts_stride, _lib.ptr(yo), _lib.ptr(dpre[l0]),
                                    dpre_stride, _lib.ptr(dst), 1 if (accumulate and first) else 0, rows, n,
                                    self.relu_mask(l0, n), None, _bf16_flag(acts))
-            _lib.call_multi("tspgnn_mlp_bwd_multi_f32", [task], d)
+            _lib.call_multi("tspgnn_mlp_bwd_multi_" + ("h2" if h2 else "f32"), [task], d)
             g = dst
 
     def backward_h2_ok(self, acts):
-        """tspgnn_mlp_bwd_multi_h2 (data gradient on the fp16 matrix cores) covers this Mlp's single-kernel chain."""
+        """tspgnn_mlp_bwd_multi_h2 (data gradient on the fp16 matrix cores) covers this Mlp's square chain (width 64:
+        one kernel; width 128: the two-layer chunks of backward_data); fp32 and bf16 tapes."""
         kind, d, n_sq, head = self._plan
-        return kind == "square" and d == 64 and len(self._chunks()) == 1 and not _bf16_flag(acts)
+        return kind == "square" and d in (64, 128)
 
     def backward_task(self, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, gather_uv=None, h2=False):
         """An _lib.MlpBwdTask for a single-kernel chain (None if several kernels are needed).
