@@ -450,8 +450,9 @@ int tspgnn_lnlstm_bwd_multi_f32(const tspgnn_lstm_bwd_task* tasks, int n_tasks, 
  *     d in {32, 64, 128}; at d = 128 Kh[128,512] is resident in LDS (128 KB).
  *   tspgnn_linear_bf16w_f32: tspgnn_linear_f32 with Wp = the bf16 packing of a bf16-exact W[kin, n1+n2] (e.g. K^T for
  *     [dx | dh] = dz K^T); X fp32, split into two bf16 pieces (16 significand bits), two MFMAs per product.
- *   tspgnn_wgrad_bf16x_f32: tspgnn_wgrad_f32 with X a bf16 array (h, messages, hidden activations of the tape): three
- *     bf16 MFMA terms per product (X exact, dY in three pieces); kin and nout multiples of 64 (else TSPGNN_EUNSUPPORTED).
+ *   tspgnn_wgrad_bf16x_f32: tspgnn_wgrad_f32 with X a bf16 array (h, messages, hidden activations of the tape): two
+ *     bf16 MFMA terms per product (X exact, dY in two pieces = 16 significand bits, like the fp32 operand of
+ *     tspgnn_linear_bf16w_f32); kin and nout multiples of 64 (else TSPGNN_EUNSUPPORTED).
  */
 int tspgnn_lnlstm_bwd_multi_bf16(const tspgnn_lstm_bwd_task* tasks, int n_tasks, int d, void* stream);
 int tspgnn_linear_bf16w_f32(const float* X, int kin, const void* Wp, float* Y1, int n1, float* Y2, int n2,

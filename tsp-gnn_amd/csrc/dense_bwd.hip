@@ -578,7 +578,8 @@ __device__ __forceinline__ void split3_w(const float (&x)[8], bf16x8_w& hi, bf16
 }
 
 // XB: X is a bf16 array (a bf16-storage tape: h, messages, hidden activations) -- bf16-exact, so its split is the value
-// itself and a product needs three MFMA terms instead of six, and half the bytes of X are read.
+// itself, and dY is taken to 16 significand bits (two pieces): two MFMA terms per product instead of six, half the bytes
+// of X, and a third less splitting arithmetic, which is what bounds this launch at the wide shapes.
 template <bool XB>
 __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                        long long rows, int kin, int nout, float* __restrict__ P,
@@ -641,9 +642,11 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
                 if constexpr (!XB) {
                     d = MFMA_BF16_W(al[m], bh, d);  // smallest terms first
                     d = MFMA_BF16_W(am[m], bm, d);
+                    d = MFMA_BF16_W(ah[m], bl, d);
+                    d = MFMA_BF16_W(am[m], bh, d);
                 }
-                d = MFMA_BF16_W(ah[m], bl, d);
-                if constexpr (!XB) d = MFMA_BF16_W(am[m], bh, d);
+                // (XB: dY enters with two pieces = 16 significand bits, as the fp32 operand of tspgnn_linear_bf16w_f32 does:
+                // next to activations stored to 8 bits, a third piece buys nothing and costs a third of the launch)
                 d = MFMA_BF16_W(ah[m], bm, d);
                 d = MFMA_BF16_W(ah[m], bh, d);
                 acc[m][n] = d;
