@@ -580,13 +580,16 @@ __device__ __forceinline__ void split3_w(const float (&x)[8], bf16x8_w& hi, bf16
 // XB: X is a bf16 array (a bf16-storage tape: h, messages, hidden activations) -- bf16-exact, so its split is the value
 // itself, and dY is taken to 16 significand bits (two pieces): two MFMA terms per product instead of six, half the bytes
 // of X, and a third less splitting arithmetic, which is what bounds this launch at the wide shapes.
-template <bool XB>
+// NBI: 64-feature blocks of X per wavefront (output block 64 NBI x 64).  NBI = 2 (kin = 128 on a bf16 tape) splits every dY
+// value once for two output blocks instead of once per block -- the splitting arithmetic, not the matrix pipe, bounds the
+// launch -- at 128 accumulator registers (two wavefronts per SIMD instead of five).
+template <bool XB, int NBI>
 __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                        long long rows, int kin, int nout, float* __restrict__ P,
                                                        float* __restrict__ Pb, int n_chunks, long long chunk_rows,
                                                        int xcd_map) {
     const int lane = threadIdx.x & 63, fl = lane & 15, g = lane >> 4;
-    const int nbi = kin / 64, nbj = nout / 64, nob = nbi * nbj;
+    const int nbi = kin / (64 * NBI), nbj = nout / 64, nob = nbi * nbj;
     // the wavefronts of one chunk read the same rows (X nbj times, dY nbi times): past four of them (one workgroup) they
     // are kept on ONE XCD, whose L2 then serves the repeats (xcd_map; d = 128 cell, 128 x 512: 4.03 -> 3.79 ms per 5.1 M rows)
     const int blk = xcd_map ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
@@ -594,38 +597,55 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
     if (w >= (long long)n_chunks * nob) return;  // wave-uniform
     const int c = (int)(w / nob), ob = (int)(w % nob), ib = ob / nbj, jb = ob % nbj;
     const long long r_beg = c * chunk_rows, r_end = min(rows, r_beg + chunk_rows);
-    const float* xp = X + (size_t)ib * 64 + fl * 4;
-    const __bf16* xpb = reinterpret_cast<const __bf16*>(X) + (size_t)ib * 64 + fl * 4;
+    const float* xp = X + (size_t)ib * NBI * 64 + fl * 4;
+    const __bf16* xpb = reinterpret_cast<const __bf16*>(X) + (size_t)ib * NBI * 64 + fl * 4;
     const float* yp = dY + (size_t)jb * 64 + fl * 4;
-    f32x4 acc[4][4];
+    f32x4 acc[NBI][4][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int q = 0; q < NBI; ++q)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[q][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
     for (long long r0 = r_beg; r0 < r_end; r0 += 32) {
-        f32x4 a[8], b[8];
+        f32x4 a[NBI][8], b[8];
+        bf16x4 ab[NBI][8];     // XB: the bf16 rows as they are (their own hi piece: no widening, no split)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const long long r = r0 + 8 * g + j;
             const bool ok = r < r_end;
             const long long rr = ok ? r : r_beg;
-            if constexpr (XB) a[j] = widen(ldw4(xpb + rr * kin));
-            else a[j] = ld4(xp + rr * kin);
+#pragma unroll
+            for (int q = 0; q < NBI; ++q) {
+                if constexpr (XB) ab[q][j] = ldw4(xpb + rr * kin + q * 64);
+                else a[q][j] = ld4(xp + rr * kin + q * 64);
+            }
             b[j] = ld4(yp + rr * nout);
             if (!ok) {
-                a[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < NBI; ++q) {
+                    if constexpr (XB) ab[q][j] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                    else a[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
                 b[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        bf16x8_w ah[4], am[4], al[4];
+        bf16x8_w ah[NBI][4], am[NBI][4], al[NBI][4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            float v[8];
+        for (int q = 0; q < NBI; ++q)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = a[j][m];
-            split3_w(v, ah[m], am[m], al[m]);
-        }
+            for (int m = 0; m < 4; ++m) {
+                if constexpr (XB) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ah[q][m][j] = ab[q][j][m];
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = a[q][j][m];
+                    split3_w(v, ah[q][m], am[q][m], al[q][m]);
+                }
+            }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             float v[8];
@@ -637,33 +657,37 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
             bf16x8_w bh, bm, bl;
             split3_w(v, bh, bm, bl);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                f32x4 d = acc[m][n];
-                if constexpr (!XB) {
-                    d = MFMA_BF16_W(al[m], bh, d);  // smallest terms first
-                    d = MFMA_BF16_W(am[m], bm, d);
-                    d = MFMA_BF16_W(ah[m], bl, d);
-                    d = MFMA_BF16_W(am[m], bh, d);
+            for (int q = 0; q < NBI; ++q)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x4 d = acc[q][m][n];
+                    if constexpr (!XB) {
+                        d = MFMA_BF16_W(al[q][m], bh, d);  // smallest terms first
+                        d = MFMA_BF16_W(am[q][m], bm, d);
+                        d = MFMA_BF16_W(ah[q][m], bl, d);
+                        d = MFMA_BF16_W(am[q][m], bh, d);
+                    }
+                    // (XB: dY enters with two pieces = 16 significand bits, as the fp32 operand of tspgnn_linear_bf16w_f32
+                    // does: next to activations stored to 8 bits, a third piece buys nothing and costs a third of the launch)
+                    d = MFMA_BF16_W(ah[q][m], bm, d);
+                    d = MFMA_BF16_W(ah[q][m], bh, d);
+                    acc[q][m][n] = d;
                 }
-                // (XB: dY enters with two pieces = 16 significand bits, as the fp32 operand of tspgnn_linear_bf16w_f32 does:
-                // next to activations stored to 8 bits, a third piece buys nothing and costs a third of the launch)
-                d = MFMA_BF16_W(ah[m], bm, d);
-                d = MFMA_BF16_W(ah[m], bh, d);
-                acc[m][n] = d;
-            }
         }
     }
     float* Pc = P + (size_t)c * kin * nout;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int q = 0; q < NBI; ++q)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int xf = ib * 64 + (4 * g + r) * 4 + m;
-                const int yf = jb * 64 + fl * 4 + n;
-                Pc[(size_t)xf * nout + yf] = acc[m][n][r];
-            }
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int xf = (ib * NBI + q) * 64 + (4 * g + r) * 4 + m;
+                    const int yf = jb * 64 + fl * 4 + n;
+                    Pc[(size_t)xf * nout + yf] = acc[q][m][n][r];
+                }
     if (Pb != nullptr && ib == 0) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -963,10 +987,17 @@ extern "C" int tspgnn_wgrad_bf16x_f32(const void* X, const float* dY, long long 
     float* P = workspace;
     float* Pb = db ? workspace + (size_t)nc * kin * nout : nullptr;
     hipStream_t st = as_stream(stream);
-    const int nob = (kin / 64) * (nout / 64);
-    const unsigned grid = (unsigned)(((long long)nc * nob + 3) / 4);
-    wgrad_x3_kernel<true><<<grid, 256, 0, st>>>(reinterpret_cast<const float*>(X), dY, rows, kin, nout, P, Pb, nc, cr,
-                                               nob > 4);
+    if (kin % 128 == 0) {   // two X blocks per wavefront: every dY value is split once per 128 features
+        const int nob = (kin / 128) * (nout / 64);
+        const unsigned grid = (unsigned)(((long long)nc * nob + 3) / 4);
+        wgrad_x3_kernel<true, 2><<<grid, 256, 0, st>>>(reinterpret_cast<const float*>(X), dY, rows, kin, nout, P, Pb, nc, cr,
+                                                      nob > 4);
+    } else {
+        const int nob = (kin / 64) * (nout / 64);
+        const unsigned grid = (unsigned)(((long long)nc * nob + 3) / 4);
+        wgrad_x3_kernel<true, 1><<<grid, 256, 0, st>>>(reinterpret_cast<const float*>(X), dY, rows, kin, nout, P, Pb, nc, cr,
+                                                      nob > 4);
+    }
     int rc = launched("tspgnn_wgrad_bf16x_f32");
     if (rc) return rc;
     const int n = kin * nout;
@@ -993,7 +1024,7 @@ extern "C" int tspgnn_wgrad_f32(const float* X, const float* dY, long long rows,
     if (av == 4 && bv == 4 && rows >= 4096) {   // the big reductions over T*rows: bf16 matrix cores, fp32-class accuracy
         const int nob = (kin / 64) * (nout / 64);
         const unsigned grid = (unsigned)(((long long)nc * nob + 3) / 4);
-        wgrad_x3_kernel<false><<<grid, 256, 0, st>>>(X, dY, rows, kin, nout, P, Pb, nc, cr, nob > 4);
+        wgrad_x3_kernel<false, 1><<<grid, 256, 0, st>>>(X, dY, rows, kin, nout, P, Pb, nc, cr, nob > 4);
         rc = launched("tspgnn_wgrad_f32");
     } else if (av == 4 && bv == 4) TSPGNN_WG(4, 4);
     else if (av == 4 && bv == 2) TSPGNN_WG(4, 2);
