@@ -49,6 +49,28 @@ rocprofv3 --kernel-trace --stats -d $O/kt_c2t -o k -- python $R/bench.py --mode 
 f=$(find $O/kt_c2t -name "*.db" | head -1)
 stats $f "round 5: python bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline (C2 training step, HIP-graph replay)" $O/c2_train_kernel_stats.txt
 python $R/bench.py --workload c5 --mode train --steps 3 --warmup 2 --no-cpu-baseline --no-graph > $O/c5_train_bench.json 2> $O/c5_train_bench.err
+rm -rf $O/kt_c5t
+rocprofv3 --kernel-trace --stats -d $O/kt_c5t -o k -- python $R/bench.py --workload c5 --mode train --steps 1 --warmup 1 --no-cpu-baseline --no-graph > $O/kt_c5t.log 2>&1
+f=$(find $O/kt_c5t -name "*.db" | head -1)
+stats $f "round 5: python bench.py --workload c5 --mode train --steps 1 --warmup 1 --no-cpu-baseline --no-graph (C5 shard training step, bf16 storage; 1 + 1 steps)" $O/c5_train_kernel_stats.txt
+# the recomputing message-MLP backward (opt-in) against the default, alternating; the kernels alone; the weight-gradient
+# reduction at the C5 shapes
+{
+  for rep in 1 2; do for rc in 0 1; do
+    echo -n "TSPGNN_RECOMPUTE=$rc (weight gradients in the launch): "
+    TSPGNN_RECOMPUTE=$rc python $R/bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys, json; print(json.loads(sys.stdin.readlines()[-1])['ms_per_step'], 'ms per C2 training step')"
+  done; done
+  for rc in 0 1; do
+    echo -n "TSPGNN_RECOMPUTE=1 TSPGNN_RECOMPUTE_DW=0 vs default, rc=$rc: "
+    TSPGNN_RECOMPUTE=$rc TSPGNN_RECOMPUTE_DW=0 python $R/bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys, json; print(json.loads(sys.stdin.readlines()[-1])['ms_per_step'], 'ms per C2 training step')"
+  done
+  for v in 0 1; do
+    echo -n "TSPGNN_MLP_BWD_H2=$v: "
+    TSPGNN_MLP_BWD_H2=$v python $R/bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys, json; print(json.loads(sys.stdin.readlines()[-1])['ms_per_step'], 'ms per C2 training step')"
+  done
+  RC_DW=1 python $R/tools/rc_bench.py 50; RC_DW=0 python $R/tools/rc_bench.py 50
+  python $R/tools/wgrad_bench.py c5; python $R/tools/wgrad_bench.py c2
+} 2>&1 | grep -v amdgpu > $O/train_variants.txt
 find $O -name "*.db" -delete
 # loop vs step-by-step over batch sizes (what loop_plan.max_edge_tiles was set from), the loop's phase trace, the staged
 # serving path, the full-size gradient anchors, the edge-once bound of the row-sum
