@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "r05")
 DST = os.path.join(ROOT, "profiles")
 KEEP = ["*_bench.json", "*_forward_kernel_stats.txt", "*_forward_timeline.txt", "*_loop_kernel_stats.txt", "c2_train_kernel_stats.txt",
-        "c5_train_kernel_stats.txt", "train_variants.txt",
+        "c5_train_kernel_stats.txt", "train_variants.txt", "fuzz_parity.txt",
         "loop_vs_steps.txt", "loop_trace.txt", "stager_breakdown.txt", "grad_anchor_report.txt", "rowsum_once_bound.txt"]
 n = 0
 for pat in KEEP:

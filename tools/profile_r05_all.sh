@@ -83,6 +83,15 @@ TSPGNN_LOOP_MAX_TILES=4 timeout 300 python $R/tools/loop_trace.py > $O/loop_trac
 timeout 300 python $R/tools/stager_breakdown.py 2>&1 | grep -v amdgpu > $O/stager_breakdown.txt
 TOP=6 timeout 600 python $R/tools/grad_anchor_report.py 2>&1 | grep -v amdgpu > $O/grad_anchor_report.txt
 timeout 400 python $R/tools/rowsum_once_bound.py 2>&1 | grep -v amdgpu > $O/rowsum_once_bound.txt
+# randomised parity sweeps: default path, the opt-in recomputing backward (both forms), bf16 storage, determinism
+{
+echo "## python tests/fuzz_parity.py 150 5"; timeout 900 python $R/tests/fuzz_parity.py 150 5 2>&1 | grep -v amdgpu | tail -12
+echo "## TSPGNN_RECOMPUTE=1 python tests/fuzz_parity.py 90 7   (recomputing message-MLP backward, weight gradients in the launch)"; TSPGNN_RECOMPUTE=1 timeout 900 python $R/tests/fuzz_parity.py 90 7 2>&1 | grep -v amdgpu | tail -8
+echo "## TSPGNN_RECOMPUTE=1 TSPGNN_RECOMPUTE_DW=0 python tests/fuzz_parity.py 60 9"; TSPGNN_RECOMPUTE=1 TSPGNN_RECOMPUTE_DW=0 timeout 900 python $R/tests/fuzz_parity.py 60 9 2>&1 | grep -v amdgpu | tail -8
+echo "## BF16=1 python tests/fuzz_parity.py 60 11"; BF16=1 timeout 900 python $R/tests/fuzz_parity.py 60 11 2>&1 | grep -v amdgpu | tail -8
+echo "## DET=1 python tests/fuzz_parity.py 40 13"; DET=1 timeout 900 python $R/tests/fuzz_parity.py 40 13 2>&1 | grep -v amdgpu | tail -6
+echo "## DET=1 TSPGNN_RECOMPUTE=1 python tests/fuzz_parity.py 30 15"; DET=1 TSPGNN_RECOMPUTE=1 timeout 900 python $R/tests/fuzz_parity.py 30 15 2>&1 | grep -v amdgpu | tail -6
+} > $O/fuzz_parity.txt 2>&1
 # counters of the cell launch (C2 forward)
 TAG=r05cell WORKLOAD=c2 SKIP_TRAFFIC=1 $R/tools/profile_r04.sh > $O/profile_cell.log 2>&1
 ls $O | head -80
