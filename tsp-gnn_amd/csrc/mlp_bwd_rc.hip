@@ -1,21 +1,18 @@
-// Message-MLP backward that RECOMPUTES its hidden activations (tspgnn_mlp_bwd_rc_h2; the training step's byte diet,
-// DESIGN 4).
-//
-// The taped form (dense_bwd.hip: mlp_bwd_kernel) made the training FORWARD write the L-1 hidden activations of every
-// edge row and step (77 MB per C2 step for the three pushed layers of E_msg_V) -- which kept the message MLP out of the
-// cell launch (the fused launch is write-bound with them) -- and ran its data gradient on the fp32 matrix instruction
-// (3 x 256 v_mfma_f32_16x16x4_f32 per 16-row tile: the launch was MFMA-bound at 49 us).  Here the backward launch
-//   * recomputes a_1 .. a_{L-1} from the chain's input rows exactly as the f16x2 forward formed them (dense_layer_h2's
-//     arithmetic, same packed 2^s W, same bias block), so the relu masks are the forward's own; the chain's output a_L
-//     (the messages: they exist anyway) is read for the last mask;
-//   * runs the data gradient G_l = dpre_l W_l^T on the fp16 matrix cores like the cells' dh = dz Kh^T
-//     (dense_bwd_h2.hip): row normalised by a power of two, second piece scaled into fp16's normal range and accumulated
-//     apart (split2s / kblock_h2_side);
-//   * hands a_1 .. a_{L-1} and dpre_0 .. dpre_{L-1} to the weight-gradient reduction (wgrad_x3_kernel) through chunk
-//     buffers of the BACKWARD pass -- the forward tapes only the messages.
-// With tspgnn_mlp_bwd_rc_task.partial the weight gradients are formed in the launch as well (mlp_bwd_rcw_kernel below).
-// Both forms are parity-green; neither pays at C2 (DESIGN_HISTORY, round 5), so the training step keeps the taped form
-// by default and these are opt-in (GraphNN.recompute_messages).
+// Message-MLP backward on the fp16 matrix cores (f16x2).  Three kernels share one chain -- masks, then G_l = dpre_l W_l^T
+// with every row normalised by a power of two and the second fp16 piece scaled into the normal range and accumulated apart
+// (split2s / kblock_h2_side, as the cells' dh = dz Kh^T in dense_bwd_h2.hip):
+//   mlp_bwd_h2_kernel   (tspgnn_mlp_bwd_multi_h2, the DEFAULT of the f16x2 and bf16 training steps): the TAPED backward --
+//                       masks from the saved activations, dpre written for the weight-gradient reduction, several MLPs per
+//                       launch, widths 64 and 128 -- replacing 3 x 256 (d = 64) v_mfma_f32_16x16x4_f32 per tile;
+//   mlp_bwd_rc_kernel   (tspgnn_mlp_bwd_rc_h2, opt-in): the hidden activations a_1 .. a_{L-1} are RECOMPUTED from the chain's
+//                       input rows exactly as the f16x2 forward formed them (dense_layer_h2's arithmetic, same packed 2^s W,
+//                       same bias block: the relu masks are the forward's own; a_L, the messages, is read), so the training
+//                       forward tapes only the messages and can run the MLP inside the cell launch; a_l and dpre_l leave
+//                       through chunk buffers of the backward pass for wgrad_x3_kernel;
+//   mlp_bwd_rcw_kernel  (tspgnn_mlp_bwd_rc_task.partial, opt-in): the same with the weight gradients formed in the launch.
+// The taped form moves 205 MB per C2 step and is bound by them; the recomputing forms are parity-green and deterministic but
+// do not pay at C2 (DESIGN_HISTORY, round 5: 50 us and 82 us in the step against 50 + 27 us), hence opt-in
+// (GraphNN.recompute_messages / recompute_weight_gradients).
 #include "common.h"
 #include "bf16_tile.h"
 #include "h2_tile.h"
