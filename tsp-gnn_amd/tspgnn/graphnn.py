@@ -731,15 +731,15 @@ class GraphNN(object):
         # default: the tape makes the training forward HBM-write-bound, and there the two plain launches at full occupancy
         # measured 0.2 ms per step FASTER than the fused one (C2: 11.75 vs 11.95 ms)
         self.fuse_training_messages = os.environ.get("TSPGNN_FUSE_TRAINING", "0") == "1"
+        # training (f16x2 and bf16 storage, widths 64 / 128): the message MLPs' data gradient on the fp16 matrix cores
+        # (tspgnn_mlp_bwd_multi_h2) instead of the fp32 matrix instruction (TSPGNN_MLP_BWD_H2=0: A/B)
+        self.mlp_backward_h2 = os.environ.get("TSPGNN_MLP_BWD_H2", "1") != "0"
         # training (f16x2, pushed message MLPs of width 64), OPT-IN (TSPGNN_RECOMPUTE=1): the backward recomputes the MLP's
         # hidden activations (tspgnn_mlp_bwd_rc_h2) so that the forward tapes only the messages and runs the message MLP
         # inside the cell launch as the inference plan does; with recompute_weight_gradients (TSPGNN_RECOMPUTE_DW, default on
         # within the mode) the MLP's weight gradients are formed in that launch too.  Both forms are parity-green and
         # deterministic; off by default because they do not pay at C2 (round 5, one box: taped 10.98-11.19 ms per training
         # step, recomputed 11.23-11.33 ms, with the weight gradients in the launch 11.7 vs 11.3 ms -- DESIGN_HISTORY)
-        # training (f16x2, width 64): the message MLPs' data gradient on the fp16 matrix cores (tspgnn_mlp_bwd_multi_h2)
-        # instead of the fp32 matrix instruction (TSPGNN_MLP_BWD_H2=0: A/B)
-        self.mlp_backward_h2 = os.environ.get("TSPGNN_MLP_BWD_H2", "1") != "0"
         self.recompute_messages = os.environ.get("TSPGNN_RECOMPUTE", "0") == "1"
         self.recompute_weight_gradients = os.environ.get("TSPGNN_RECOMPUTE_DW", "1") != "0"
         # GEMM arithmetic of the inference forward, all fp32-class in accuracy: "f16x2" = fp16 matrix cores on
