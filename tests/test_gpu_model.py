@@ -736,6 +736,34 @@ def test_bf16_storage_training_gradients(cuda_device, name, d, T):
     assert end_to_end < 3 * max(spread, 1e-2)
 
 
+def test_bf16_training_large_weight_keeps_the_fp32_mlp_backward(cuda_device):
+    """The bf16-storage backward runs the message MLPs' data gradient on the fp16 matrix cores (tspgnn_mlp_bwd_multi_h2), whose
+    packing 2^6 W^T overflows fp16 for |w| >= 1024 -- a magnitude bf16 storage itself carries.  The pass packs first, looks at
+    the range guard's weight word and keeps the fp32 matrix instruction when it is beyond half the fp16 range: a network with
+    one such weight gets the gradients of the fp32 path, bit for bit, and they are finite."""
+    d, T = 64, 3
+    t = pack_tuple("ragged_B6", 1)
+    params = P.init_params(d, seed=4, perturb=True)
+    params = {k: np.array(v, copy=True) for k, v in params.items()}
+    params["TSP/E_msg_V_MLP_layer_2/kernel"][3, 5] = 2000.0      # (bf16-exact; 2^6 * 2000 > 65504)
+    res = []
+    for h2 in (True, False):
+        model = tspgnn.build_network(d, float_dtype=torch.bfloat16)
+        sess = tspgnn.Session(model)
+        sess.run(tspgnn.global_variables_initializer())
+        model.store.load(params)
+        model["gnn"].mlp_backward_h2 = h2
+        EV, W, C, route_exists, n_vertices, n_edges = t
+        feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+                model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+        sess.loss_and_grads(feed)
+        torch.cuda.synchronize()
+        res.append(model.store.grad_dict())
+    for k in res[0]:
+        assert np.isfinite(res[0][k]).all(), k
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
 def test_bf16_storage_train_steps(cuda_device):
     """sess.run(train_step) in the bf16-storage mode: the loss follows the straight-through oracle's over three Adam
     steps and the fp32 master variables move as the oracle's do."""

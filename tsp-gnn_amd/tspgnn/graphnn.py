@@ -751,6 +751,7 @@ class GraphNN(object):
             raise ValueError("TSPGNN_GEMM must be one of %s, got %r" % (sorted(GEMM_ARITH), self.gemm))
         self._h2_off_at = None       # store.assignments at which the weights were found outside the f16x2 range
         self._h2_force_off = False
+        self._mlp_h2_native_ok = False   # bf16-storage backward: the last eager pass found the MLP weights inside the f16x2 range
         self.check_model()
         self._init_parameters()
 
@@ -1070,6 +1071,13 @@ class GraphNN(object):
         if arith == "h2" and (self._h2_force_off or self._h2_off_at == self.store.assignments):
             return "x3"
         return arith
+
+    def training_packs_h2(self):
+        """A training step of this network packs weights into fp16 pieces (the f16x2 forward and backward, or the bf16-storage
+        mode's message-MLP backward): a replayed training graph has to watch the range guard's weight word."""
+        if self.float_dtype == torch.bfloat16:
+            return bool(self.mlp_backward_h2 and self._mlp_h2_native_ok)
+        return self.active_arith() == "h2"
 
     def forced_off_h2(self):
         """Context manager: f16x2 disabled inside (Session's re-run of a batch whose activations overflowed)."""
@@ -1884,6 +1892,23 @@ class GraphNN(object):
             budget = min(budget, avail // 2)
         CH = max(1, min(T, int(budget // max(per_step, 1)))) if T > 0 else 1
         DZ = {v: torch.empty((CH, n[v], 4 * d), **f32) for v, d in self.var.items()}
+        # bf16-storage tape: the f16x2 data gradient of the message MLPs packs 2^s W^T into fp16 pieces, which the bf16 forward
+        # never vetted -- pack now and look at the guard's weight word (one 4-byte read per backward pass): beyond half the fp16
+        # range the pass uses tspgnn_mlp_bwd_multi_f32.  A pass being CAPTURED cannot look: it follows the eager pass before it
+        # (Session.capture_train_step warms up eagerly) and its replays watch the word at the f16x2 guard's lag
+        mlp_h2_native = bool(native and self.mlp_backward_h2 and self._mlp_h2_native_ok)
+        if native and self.mlp_backward_h2 and device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            store = self.store
+            for (v, i), acts in tape.acts.items():
+                mlp = self._msg_MLPs[self.loop[v][i]["msg"]]
+                if mlp.backward_h2_ok(acts):
+                    for l0, nl in mlp._chunks():
+                        mlp.wt_packed_h2(l0, l0 + nl - 1, mlp.sizes[-1])
+            guard = store.h2_guard()
+            bits = int(guard[1].item())
+            guard[1:2].zero_()
+            store.h2_packs_pending = 0
+            mlp_h2_native = self._mlp_h2_native_ok = bits < store.H2_WEIGHT_LIMIT_BITS
         DPRE, RCA, RCP = {}, {}, {}
         for (v, i), acts in tape.acts.items():
             u = self.loop[v][i]
@@ -2023,7 +2048,7 @@ class GraphNN(object):
                         mlp = self._msg_MLPs[u["msg"]]
                         (acts_t, acts_stride), dpre = tape.acts_at((v, i), t), DPRE[(v, i)]
                         keep.append(acts_t)
-                        h2 = bool((bwd_arith == "h2" or native) and self.mlp_backward_h2 and mlp.backward_h2_ok(acts_t))
+                        h2 = bool((bwd_arith == "h2" or mlp_h2_native) and self.mlp_backward_h2 and mlp.backward_h2_ok(acts_t))
                         if pushed[v]:   # the chain ends at the last hidden activation (a relu layer: masked by its output)
                             task = mlp.backward_prefix_task(dpre.shape[0], dy, acts_t, acts_stride, acts_t[dpre.shape[0] - 1],
                                                             dpre[:, k], dpre.stride(0), ndH[src], True, gather_uv=gather_uv, h2=h2)

@@ -202,7 +202,7 @@ class Mlp(object):
             for j in range(last - first + 1):
                 Wt = self.store.view(self.layer_names[first + j] + "/kernel").t().contiguous()
                 _lib.call("tspgnn_pack_weights_h2", _lib.ptr(Wt), _lib.ptr(out[j * 4 * d * d:(j + 1) * 4 * d * d]), d, d,
-                          None, st)
+                          self.store.h2_absmax_ptr(), st)     # (max |2^s W| joins the store's range guard)
             return out
         return self.store.packed(("mlpT.h2", self.name, first, last), build)
 

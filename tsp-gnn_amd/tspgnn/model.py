@@ -728,6 +728,7 @@ class Session(object):
                     torch.cuda.synchronize()
                     self.last_range_bits = act
                     gnn._h2_off_at = store.assignments
+                    gnn._mlp_h2_native_ok = False
                     store.h2_guard().zero_()
                     del inflight[:]
                     self._adam["step"] = int(self._adam["t"].item())   # the device counter did not count the skipped steps
@@ -740,12 +741,12 @@ class Session(object):
                                "the next ones would not be safe")
                     dead[0] = ("f16x2 range exceeded during replayed training steps: %s.  This replay closure is finished "
                                "(its graph holds the f16x2 kernels): call capture_train_step() again -- it will run on "
-                               "bf16x3" % why)
+                               "bf16x3 (bf16 storage: with the message MLPs' backward on the fp32 matrix instruction)" % why)
                     raise RuntimeError(dead[0])
             ga.replay()
             self.allreduce_grads(b.B, out["stats"])   # device-side only: no host sync between the two graphs
             gb.replay()
-            if gnn.active_arith() == "h2":
+            if gnn.training_packs_h2():
                 words = ring[count[0] % (LAG + 1)]
                 count[0] += 1
                 words.copy_(store.h2_guard(), non_blocking=True)
