@@ -632,3 +632,30 @@ def test_mlp_backward_taped_h2(cuda_device, d, bf16):
         for l, ref in enumerate(want):
             scale = np.maximum(np.abs(ref).max(1, keepdims=True), 1e-30)
             assert (np.abs(dpre[l].cpu().numpy() - ref) / scale).max() < TOL, ("dpre", l)
+
+
+def test_mlp_backward_h2_rows_of_subnormal_and_zero_gradients(cuda_device):
+    """A gradient row whose largest entry is an fp32 subnormal (or zero) must come out as (about) zero, not as NaN: the row
+    is normalised by a power of two before its fp16 split, and 2^-e has to stay finite (h2_row_exponent)."""
+    d, rows, L, mask = 64, 48, 2, 0b01
+    rng = np.random.RandomState(3)
+    Ws = [(rng.randn(d, d) / np.sqrt(d)).astype(np.float32) for _ in range(L)]
+    acts = rng.randn(1, rows, d).astype(np.float32)
+    Y = rng.randn(rows, d).astype(np.float32)
+    dY = rng.randn(rows, d).astype(np.float32)
+    dY[5] = 0.0
+    dY[6] = 1e-42          # fp32 subnormals
+    dY[7] = -3e-39
+    wt = _h2_blocks(Ws, [None] * L, cuda_device, transposed=True)
+    dpre = empty((L, rows, d), cuda_device, 7.0)
+    dX = empty((rows, d), cuda_device, 7.0)
+    task = _lib.MlpBwdTask(_lib.ptr(dev(dY, cuda_device)), _lib.ptr(wt), _lib.ptr(dev(acts, cuda_device)), rows * d,
+                           _lib.ptr(dev(Y, cuda_device)), _lib.ptr(dpre), rows * d, _lib.ptr(dX), 0, rows, L, mask, None, 0)
+    _lib.call_multi("tspgnn_mlp_bwd_multi_h2", [task], d)
+    torch.cuda.synchronize()
+    out = dX.cpu().numpy()
+    assert np.isfinite(out).all() and np.isfinite(dpre.cpu().numpy()).all()
+    assert np.abs(out[5:8]).max() < 1e-30
+    G = dY.astype(np.float64) @ Ws[1].astype(np.float64).T
+    G = (G * (acts[0] > 0)) @ Ws[0].astype(np.float64).T
+    assert rel_err(out[8:], G[8:]) < 4 * TOL

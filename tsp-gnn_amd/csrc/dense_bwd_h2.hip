@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
                 for (int r = 0; r < 4; ++r) m = fmaxf(m, __builtin_fabsf(acc[t][r]));
             }
             m = max_over_lane_groups16_swap(m);
-            const int e = m > 0.f ? __builtin_amdgcn_frexp_expf(m) : 0;   // m = f * 2^e, f in [0.5, 1)
+            const int e = h2_row_exponent(m);   // m = f * 2^e, f in [0.5, 1)
             const float up = __builtin_ldexpf(1.0f, -e), down = __builtin_ldexpf(1.0f, e);
             // (the row's second piece is the SCALED one of split2s, accumulated apart: entries far below the row's
             // largest keep a relative, not an absolute, accuracy)

@@ -256,6 +256,14 @@ __device__ __forceinline__ float max_over_lane_groups16_swap(float v) {
     return fmaxf(s, t);
 }
 
+// The power of two a gradient row is normalised by before its fp16 split (m = the row's largest magnitude = f * 2^e,
+// f in [0.5, 1)).  Clamped to +-100: 2^-e and 2^e stay normal fp32 numbers for a row of subnormal junk (m ~ 1e-40 made
+// 2^-e = inf and the row NaN instead of ~0) as for an absurdly large one.
+__device__ __forceinline__ int h2_row_exponent(float m) {
+    const int e = m > 0.f ? __builtin_amdgcn_frexp_expf(m) : 0;
+    return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+
 // kblock_h2_side for NP row tiles at once (one fragment fetch feeds NP independent chains; per output tile the MFMAs and
 // their order are those of kblock_h2_side).
 template <int NT, int NP>

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024) void mlp_bwd_rc_kernel(const tspgnn_mlp_bwd_r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) m = fmaxf(m, __builtin_fabsf(gr[0][t][r]));
             m = max_over_lane_groups16_swap(m);
-            const int e = m > 0.f ? __builtin_amdgcn_frexp_expf(m) : 0;
+            const int e = h2_row_exponent(m);
             const float up = __builtin_ldexpf(1.0f, -e), down = __builtin_ldexpf(kH2InvScale, e);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(1024) void mlp_bwd_h2_kernel(const MlpBwdTaskTableH
 #pragma unroll
                 for (int q = 0; q < 4; ++q) m = fmaxf(m, __builtin_fabsf(gr[0][t][q]));
             m = max_over_lane_groups16_swap(m);
-            const int e = m > 0.f ? __builtin_amdgcn_frexp_expf(m) : 0;
+            const int e = h2_row_exponent(m);
             const float up = __builtin_ldexpf(1.0f, -e), down = __builtin_ldexpf(kH2InvScale, e);
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kRcwWaves * 64) void mlp_bwd_rcw_kernel(const tspgn
 #pragma unroll
                     for (int q = 0; q < 4; ++q) m = fmaxf(m, __builtin_fabsf(gr[0][t][q]));
                 m = max_over_lane_groups16_swap(m);
-                const int e = m > 0.f ? __builtin_amdgcn_frexp_expf(m) : 0;
+                const int e = h2_row_exponent(m);
                 const float up = __builtin_ldexpf(1.0f, -e), down = __builtin_ldexpf(kH2InvScale, e);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
