@@ -258,6 +258,9 @@ def main():
     loss = float(out["stats"][0].item())
     if not np.isfinite(loss):
         raise SystemExit("non-finite loss in the timed region")
+    # the device-side guard words of the timed region: a one-launch loop whose wait expired raises here, and a
+    # batch that left the f16x2 range would have been timed on an arithmetic the product then replaces -- say so
+    guard_bits = sess.last_range_bits if sess.range_exceeded() else 0
     # ---- the fresh-batch path (">= 6x at 8 GPUs hinges on the host packer and launch overhead"): every
     # batch is NEW host instances -> tspgnn_host_pack_batch (native) -> upload on a side stream behind the previous
     # batch -> copied into the buffers of the captured graph -> replay.  Every rank packs its own shard concurrently, so at
@@ -315,7 +318,8 @@ def main():
                           "batches": args.serve_batches, "ms_per_batch": round(1e3 * dt_stage / args.serve_batches, 4),
                           "value": round(world * args.serve_batches * T / dt_stage, 2), "unit": "mp-steps/s",
                           "host_stage_ms_per_batch_one_thread": round(stage_ms, 3),
-                          "finite": bool(all(torch.isfinite(k).all().item() for k in keep))}
+                          "finite": bool(all(torch.isfinite(k).all().item() for k in keep)),
+                          "range_guard_bits": sess.last_range_bits if sess.range_exceeded() else 0}   # (raises on a loop status)
             else:
                 staged = None
 
@@ -344,7 +348,8 @@ def main():
                      "ms_per_batch": round(1e3 * dt_serve / args.serve_batches, 4),
                      "value": round(world * args.serve_batches * T / dt_serve, 2), "unit": "mp-steps/s",
                      "host_pack_ms_per_batch_one_thread": round(pack_ms, 3), "n_gpus": world,
-                     "finite": bool(all(torch.isfinite(k).all().item() for k in keep))}
+                     "finite": bool(all(torch.isfinite(k).all().item() for k in keep)),
+                     "range_guard_bits": sess.last_range_bits if sess.range_exceeded() else 0}
             if staged is not None:   # the staged path is the serving path of a fixed-shape workload: it leads the block
                 staged["n_gpus"] = world
                 staged["vs_resident"] = round(staged["ms_per_batch"] / (1e3 * elapsed / args.steps), 4)
@@ -357,11 +362,15 @@ def main():
             serve = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     train = None
-    if args.mode == "forward" and args.train_steps > 0:
+    # N > 1: the line's `value` is the TRAINING step's whole-job rate -- the only step of this path with
+    # a collective (one RCCL all-reduce of the gradient bucket per step) -- timed over exactly --steps steps
+    # after --warmup, barrier-bracketed, max over ranks; the collective-free forward moves to `forward_value`.
+    n_train, w_train = (args.steps, max(1, args.warmup)) if world > 1 else (args.train_steps, 1)
+    if args.mode == "forward" and n_train > 0:
         # the training step (backward + RCCL all-reduce of the 462 KB gradient bucket + fused optimiser), reported
-        # next to the headline number; a failure here (e.g. the collective) must not lose the forward measurement
+        # next to the forward number; a failure here (e.g. the collective) must not lose the forward measurement
         try:
-            dt_train, tout = timed(make_train_fn(), 1, args.train_steps)
+            dt_train, tout = timed(make_train_fn(), w_train, n_train)
             allreduce_us = None
             if world > 1:      # the step's one collective alone: the bucket, back to back, HIP events on this stream
                 sess.store.zero_grad()
@@ -377,19 +386,19 @@ def main():
                 tm = torch.tensor([e0.elapsed_time(e1) * 1e3 / 20], dtype=torch.float64, device=device)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 allreduce_us = round(float(tm.item()), 2)
-            train = {"ms_per_batch": round(1e3 * dt_train / args.train_steps, 3),
+            train = {"ms_per_batch": round(1e3 * dt_train / n_train, 3),
                      "rccl_ranks": dist.get_world_size() if world > 1 else 1,
                      "backend": dist.get_backend() if world > 1 else None,
                      "allreduce_us": allreduce_us,
                      "allreduce_bytes": 4 * (sess.store.theta.numel() + sess.store.BUCKET_TAIL) if world > 1 else None,
-                     "ms_per_step": round(1e3 * dt_train / args.train_steps, 3),
-                     "value": round(world * args.train_steps * T / dt_train, 2), "unit": "mp-steps/s",
-                     "mp_steps_per_s": round(world * args.train_steps * T / dt_train, 2),
+                     "ms_per_step": round(1e3 * dt_train / n_train, 3),
+                     "value": round(world * n_train * T / dt_train, 2), "unit": "mp-steps/s",
+                     "mp_steps_per_s": round(world * n_train * T / dt_train, 2),
                      "n_gpus": world, "scaling": "weak", "global_batch": len(sizes) * world,
                      "collective": "one all-reduce (RCCL) of the %d-byte bucket [gradient | batch size, statistics, "
                                    "range flag] per step" % (4 * (sess.store.theta.numel() + sess.store.BUCKET_TAIL))
                                    if world > 1 else None,
-                     "steps": args.train_steps, "loss": float(tout["stats"][0].item()),
+                     "steps": n_train, "loss": float(tout["stats"][0].item()),
                      "global_norm": float(tout["global_norm"].item()),
                      "what": "forward + backward through T steps + gradient all-reduce (world %d) + L2/clip/Adam: the step "
                              "north_star scales over GPUs (whole-job mp-steps/s = n_gpus * steps * T / max-over-ranks time; "
@@ -704,12 +713,21 @@ def main():
         if not args.no_cpu_baseline and world == 1 and float(M) * N * 4 < 16e9:   # rank 0, N=1 only; dense EV must fit
             cpu_baseline = run_cpu_baseline(d, batch, T, args.cpu_seconds, M)
 
+        # which step the headline fields describe: the forward pass at N = 1 (BASELINE's metric as the reference runs it),
+        # the training step -- with its all-reduce -- at N > 1
+        train_ok = world > 1 and isinstance(train, dict) and "error" not in train
+        head_value = train["value"] if train_ok else round(mp_steps_per_s, 2)
+        head_ms = train["ms_per_step"] if train_ok else round(ms_per_step, 4)
         result = {
             "metric": "message-passing steps/sec (edges aggregated/sec) at n=40, batch=128, T=32"
                       + ("" if args.workload == "c2" else " [measured on workload %s, not the metric's configuration]" % args.workload),
-            "value": round(mp_steps_per_s, 2), "unit": "mp-steps/s",
+            "value": head_value, "unit": "mp-steps/s",
+            "value_is": ("training step: forward + backward + ONE all-reduce (%s) of the gradient bucket over %d ranks + "
+                         "L2 / clip / Adam" % ((train or {}).get("backend"), world)) if train_ok
+                        else ("forward pass" if world == 1 else "forward pass (NO collective): the training leg failed, see `train`"),
+            "forward_value": round(mp_steps_per_s, 2), "forward_ms_per_step": round(ms_per_step, 4),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": head_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16 storage, f32 accumulate" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": "%s: %d complete Euclidean graphs n=%s, d=%d, T=%d, %s, forward pass "
                                    "(E_init -> T x {msg MLPs, SpMM pair, LN-LSTMs} -> vote -> loss)%s"
@@ -733,9 +751,11 @@ def main():
             "allreduce_us": (train or {}).get("allreduce_us") if world > 1 else None,
             "train_value": (train or {}).get("value"),
             "train_ms_per_step": (train or {}).get("ms_per_step"),
-            "scaling_note": ("`value` = forward passes of %d independent shards (no data-path collective: weak scaling by "
-                             "construction); `train_value` = whole-job mp-steps/s of the training step, whose gradient "
-                             "bucket crosses all %d ranks once per step" % (world, world)) if world > 1 else None,
+            "scaling_note": ("`value` = whole-job mp-steps/s of the TRAINING step (%d ranks x %d steps x T / max-over-ranks "
+                             "time), whose gradient bucket crosses all ranks once per step; `forward_value` = forward passes of "
+                             "%d independent shards (no data-path collective: weak scaling by construction)"
+                             % (world, args.steps, world)) if world > 1 else None,
+            "range_guard_bits": guard_bits,
             "train": train,
             "serve": serve,
             "kernels_us": {k: {"n": v["n"], "avg_us": round(v["avg_us"], 2)} for k, v in kernels_us.items()},
@@ -814,6 +834,8 @@ def plumbing_main(args, rank, world):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "plumbing: %d ranks, shards of 2-4 tiny graphs, d=%d, no kernels" % (world, d),
                        "global_batch": int(total_b), "parallelism": "shard-by-instance x%d, one all-reduce of the bucket" % world},
+            "value_is": "the data-parallel bucket's ONE all-reduce per step (the collective the N > 1 headline -- the training "
+                        "step -- contains); no kernels", "forward_value": None,
             "plumbing": True, "roofline": None, "cpu_baseline": None,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
             "allreduce_us": round(1e6 * dt / args.steps, 1), "allreduce_bytes": 4 * store.bucket.numel(),

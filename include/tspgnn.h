@@ -32,8 +32,9 @@ extern "C" {
 #define TSPGNN_EINVAL (-1)      /* bad argument (null pointer, negative size, unsupported d) */
 #define TSPGNN_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
 
-#define TSPGNN_ABI_VERSION 3   /* 2: range_flag in the task structures, pack_weights_h2 / adam_clip_step arguments;
-                                  3: tspgnn_mp_loop_h2 (the whole T-step loop as one launch) */
+#define TSPGNN_ABI_VERSION 4   /* 2: range_flag in the task structures, pack_weights_h2 / adam_clip_step arguments;
+                                  3: tspgnn_mp_loop_h2 (the whole T-step loop as one launch);
+                                  4: tspgnn_mp_resident_h2 (the loop as one launch, states through memory) */
 
 /* ABI version of the loaded library (== TSPGNN_ABI_VERSION of the header it was built from). */
 int tspgnn_version(void);
@@ -287,6 +288,59 @@ typedef struct tspgnn_mp_loop_args {
                                                s_memrealtime ticks per phase of the loop (tools/loop_trace.py) */
 } tspgnn_mp_loop_args;
 int tspgnn_mp_loop_h2(const tspgnn_mp_loop_args* args, int d, void* stream);
+
+/*
+ * The same loop (graphnn.py:175-179 over while_body, graphnn.py:142-173; wiring of model.py:53-104) as ONE launch of
+ * resident workgroups with the edge states kept in MEMORY between the steps -- the form for batches whose edge tiles
+ * outnumber what tspgnn_mp_loop_h2 holds in registers (BASELINE's n=40, batch=128 and beyond).  Arithmetic, operand
+ * formats and summation orders are again those of tspgnn_lnlstm_mlp_fwd_multi_h2 + tspgnn_csr_rowsum_f32 launched T
+ * times (bit-identical results).  Per compute unit one workgroup of TSPGNN_RESIDENT_WAVES wavefronts:
+ *   - EDGE workgroups keep Kh and the message MLP in LDS for the whole loop and hand out WORK ITEMS -- 16-row edge tiles
+ *     and shares of the V<-E row-sum -- through one LDS ticket that runs through all T steps: item k is item k mod W of
+ *     step k div W.  A tile's states live in private slot arrays (`e_hs`, `e_cs`: [slots * 16, d], blocked by tile,
+ *     updated in place, write-through stores and L1-bypassing loads: they never leave the Infinity Cache at C2 sizes);
+ *     a tile of step t waits for its own step t-1 (an LDS word per tile) and for its group's projected messages;
+ *   - the items of a step are ordered by CLASS (the groups of an XCD are cut into classes, tspgnn/resident_plan.py): while
+ *     the vertex chain of one class runs -- row-sum, vertex cells, message MLP, projection: ~25 us that nothing else of
+ *     that class can overlap -- the workgroup's wavefronts work on the tiles of the other class;
+ *   - VERTEX workgroups come in two kinds, neither with a barrier or a second LDS residency inside the loop: CELL workgroups
+ *     (K[2d,4d] resident) and MESSAGE workgroups (message MLP + projection resident); h' crosses between them through `vh`.
+ * Synchronisation is per group of consecutive instances through the three parity-split counters of tspgnn_mp_loop_h2
+ * (message tiles arrived, vertex rows aggregated, vertex tiles projected) and a fourth (vertex tiles updated): the
+ * ordering argument is the same.  `counters` = 4 * 32 * n_groups + 32 words here.
+ * `plan`: int32 -- grid headers of TSPGNN_RESIDENT_HDR_INTS, then items of TSPGNN_RESIDENT_ITEM_INTS (layout documented in
+ * tspgnn/resident_plan.py and csrc/mp_resident_h2.hip).  `counters` as for tspgnn_mp_loop_h2, zeroed by the caller before
+ * every launch.  `lds_words`: LDS words the plan's largest edge workgroup needs behind the weights (one per tile, and
+ * TSPGNN_RESIDENT_SHARE_ROWS * (1 + TSPGNN_RESIDENT_SHARE_CAP) per row-sum share whose edge lists it keeps there).
+ */
+#define TSPGNN_RESIDENT_WAVES 12
+#define TSPGNN_RESIDENT_HDR_INTS 8
+#define TSPGNN_RESIDENT_ITEM_INTS 8
+#define TSPGNN_RESIDENT_SHARE_ROWS 8   /* vertex rows per row-sum share */
+#define TSPGNN_RESIDENT_SHARE_CAP 48   /* edge ids per vertex row of a share kept in LDS */
+typedef struct tspgnn_mp_resident_args {
+    const float* e_h0; const float* e_c0;   /* [M,d] row-major initial states; e_c0 NULL = zeros */
+    float* e_h; float* e_c;                 /* [M,d] final states */
+    float* e_hs; float* e_cs;               /* [n_slots*16, d] scratch: the states between the steps, by tile slot */
+    const int32_t* uv;
+    const void* e_K; const float* e_ln;
+    const void* e_mlp_wb; int e_mlp_layers; unsigned e_relu_mask;
+    float* msg[2];
+    const float* v_h0; const float* v_c0; float* v_h; float* v_c;
+    const int32_t* rowptr; const int32_t* eid;
+    const void* v_K; const float* v_ln;
+    const float* v_zbias; const float* v_zscale;
+    const void* v_mlp_wb; int v_mlp_layers; unsigned v_relu_mask;
+    const void* v_proj_w;
+    float* zx[2];
+    float* vagg[2];
+    float* vh[2];                           /* [N,d] scratch: the vertex states h between the steps, by step parity */
+    const int32_t* plan; unsigned* counters; int n_groups; int grid; int n_slots; int lds_words;
+    int M; int N; int T; int z_centered;
+    unsigned* range_flag; unsigned* status;
+    unsigned long long* trace;              /* optional (development), as tspgnn_mp_loop_args */
+} tspgnn_mp_resident_args;
+int tspgnn_mp_resident_h2(const tspgnn_mp_resident_args* args, int d, void* stream);
 
 /* ------------------------------------------------------------------ bf16 storage, fp32 accumulate
  *

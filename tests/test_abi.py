@@ -45,7 +45,7 @@ def test_abi_version_and_struct_layouts_agree(tmp_path):
     pairs = {"tspgnn_mlp_task": _lib.MlpTask, "tspgnn_lstm_task": _lib.LstmTask, "tspgnn_cell_mlp_task": _lib.CellMlpTask,
              "tspgnn_mlp_task_bf16": _lib.MlpTaskB, "tspgnn_lstm_task_bf16": _lib.LstmTaskB,
              "tspgnn_lstm_bwd_task": _lib.LstmBwdTask, "tspgnn_mlp_bwd_task": _lib.MlpBwdTask, "tspgnn_mlp_bwd_rc_task": _lib.MlpBwdRcTask,
-             "tspgnn_mp_loop_args": _lib.MpLoopArgs}
+             "tspgnn_mp_loop_args": _lib.MpLoopArgs, "tspgnn_mp_resident_args": _lib.MpResidentArgs}
     src = ["#include <stdio.h>", "#include <stddef.h>", '#include "tspgnn.h"', "int main(void) {"]
     for cname, cls in pairs.items():
         src.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
@@ -68,7 +68,7 @@ def test_abi_version_and_struct_layouts_agree(tmp_path):
 
 
 def test_version_and_error_string():
-    assert _lib.lib.tspgnn_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib.tspgnn_version() == _lib.ABI_VERSION == 4
     status = _lib.lib.tspgnn_gather2_sum_f32(None, None, None, 4, 4, 3, None)   # d=3: rejected before launch
     assert status == -1
     assert b"multiple of 4" in _lib.lib.tspgnn_last_error()

@@ -25,6 +25,7 @@ def test_bench_plumbing_json_contract(ranks):
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "rccl_ranks", "allreduce_us"):
         assert key in r, key
     assert r["plumbing"] is True and "PLUMBING" in r["metric"]
+    assert "all-reduce" in r["value_is"]      # N > 1: the headline carries the collective (the GPU line: the training step)
     assert r["n_gpus"] == ranks and r["rccl_ranks"] == ranks and r["backend"] == "gloo"
     assert r["steps"] == 4 and r["warmup"] == 1 and r["scaling"] == "weak" and r["higher_is_better"] is True
     assert r["reduced_gradient_ok"] is True                # sum_r B_r (r + 1) / sum_r B_r on every rank

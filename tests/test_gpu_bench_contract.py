@@ -33,6 +33,8 @@ def test_bench_json_contract(cuda_device):
         assert key in cpu, key
     assert cpu["kind"] == "port" and cpu["cores"] >= 1
     assert "error" not in (r.get("train") or {})
+    # N = 1: the headline is the forward pass (BASELINE's metric as the reference runs it), no guard bit was raised
+    assert r["value_is"] == "forward pass" and r["forward_value"] == r["value"] and r["range_guard_bits"] == 0
 
 
 def test_bench_two_ranks_gloo_on_one_gpu(cuda_device):
@@ -52,6 +54,12 @@ def test_bench_two_ranks_gloo_on_one_gpu(cuda_device):
     assert r["config"]["global_batch"] == 2 * r["config"]["per_gpu_batch"]
     assert abs(r["value"] - 2 * 32 * 1e3 / r["ms_per_step"]) / r["value"] < 1e-3      # whole-job aggregate
     assert "error" not in r["train"] and "world 2" in r["train"]["what"]
+    # N > 1: the headline IS the training step -- the only step of this path with a collective --
+    # timed over exactly --steps steps; the collective-free forward sits in its own field
+    assert r["value"] == r["train"]["value"] and r["ms_per_step"] == r["train"]["ms_per_step"]
+    assert r["train"]["steps"] == r["steps"] == 3 and r["train"]["rccl_ranks"] == 2
+    assert r["value_is"].startswith("training step") and "all-reduce" in r["value_is"]
+    assert r["forward_value"] > r["value"] and r["forward_ms_per_step"] < r["ms_per_step"]
 
 
 def test_bench_spawns_its_own_ranks(cuda_device):

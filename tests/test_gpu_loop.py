@@ -1,6 +1,7 @@
-"""tspgnn_mp_loop_h2 -- the whole T-step loop (graphnn.py:175-179) as one launch of resident workgroups with the edge
-states in registers and per-group synchronisation -- against the stepwise launches it replaces (bit-identical: same
-arithmetic, same summation orders) and against the float64 oracle (1e-5, BASELINE.json)."""
+"""The whole T-step loop (graphnn.py:175-179) as one launch of resident workgroups with per-group synchronisation, in both
+forms -- tspgnn_mp_loop_h2 (edge states in registers) and tspgnn_mp_resident_h2 (edge states through memory, work items by
+LDS ticket) -- against the stepwise launches they replace (bit-identical: same arithmetic, same summation orders) and
+against the float64 oracle (1e-5, BASELINE.json)."""
 import numpy as np
 import pytest
 import torch
@@ -16,11 +17,14 @@ pytestmark = pytest.mark.gpu
 REL_TOL = 1e-5
 
 
-@pytest.fixture(autouse=True)
-def every_batch_that_fits(monkeypatch):
-    """By default the loop only takes batches of <= 3 resident tiles per wavefront (where it is the faster path,
-    loop_plan.max_edge_tiles); the tests exercise everything the kernel holds."""
+@pytest.fixture(autouse=True, params=["loop", "resident"])
+def kind(request, monkeypatch):
+    """By default the register-resident loop only takes batches of <= 3 resident tiles per wavefront (where it is the
+    faster path, loop_plan.max_edge_tiles) and the memory-resident one the larger ones; the tests exercise everything each
+    kernel holds."""
     monkeypatch.setenv("TSPGNN_LOOP_MAX_TILES", "4")
+    monkeypatch.setenv("TSPGNN_LOOP_KIND", request.param)
+    return request.param
 
 
 def forward(params, t, T, loop, d=64):
@@ -34,6 +38,9 @@ def forward(params, t, T, loop, d=64):
             model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
     b = sess.prepare(feed)
     used = b.adj.loop_plan is not None and loop
+    if used:
+        import os
+        assert b.adj.loop_plan[3] == os.environ["TSPGNN_LOOP_KIND"]
     pred, last = sess.run([model["predictions"], model["last_states"]], feed_dict=feed)
     return pred, last, used
 

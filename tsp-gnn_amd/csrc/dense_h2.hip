@@ -70,36 +70,6 @@ __global__ __launch_bounds__(256) void pack_weights_h2_kernel(const float* __res
     }
 }
 
-// One Dense(D) layer on the lane's part of a 16-row tile, activations chained in registers (D layout).  `bias` holds
-// 2^s * b; the output comes back at its true scale.
-template <int D>
-__device__ __forceinline__ void dense_layer_h2(f32x4 (&a)[D / 16], const _Float16* wh, const _Float16* wl, const float* bias,
-                                               bool relu, int g, int rl, float& wit) {
-    constexpr int NT = D / 16, KB = D / 32;
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = ld4(bias + t * 16 + g * 4);
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = a[2 * kb + (j >> 2)][j & 3];
-        f16x8 bh, bl;
-        split2w(x, bh, bl, wit);
-        kblock_h2<NT>(acc, wh, wl, kb, g, rl, bh, bl);
-    }
-    const f32x2 inv = {kH2InvScale, kH2InvScale};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (relu) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
-        }
-        a[t].lo = acc[t].lo * inv;
-        a[t].hi = acc[t].hi * inv;
-    }
-}
-
 constexpr int kMaxTasksH2 = 4;
 
 // ---------------------------------------------------------------------------------- MLP (f16x2)

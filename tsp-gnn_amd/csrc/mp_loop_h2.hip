@@ -37,13 +37,13 @@
 // ordering argument in DESIGN.md).
 #include "common.h"
 #include "h2_tile.h"
+#include "loop_sync.h"
 #include "mfma_tile.h"
 
 #include <type_traits>
 
 namespace tspgnn {
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kLoopWaves = TSPGNN_LOOP_WAVES;
 constexpr int kLoopDesc = TSPGNN_LOOP_DESC_INTS;
 constexpr int kLoopEdgeTiles = 4;
@@ -51,48 +51,6 @@ constexpr int kLoopVertTiles = 2;
 #ifndef LOOP_PAIR
 #define LOOP_PAIR 4   // which stages step two resident tiles together (see pair_step)
 #endif
-constexpr int kAuxWT = 17;                 // sc0 sc1: write-through store / L1-bypassing load
-constexpr unsigned kSpinLimit = 1u << 19;  // polls (each ~1 us: a load round trip + s_sleep)
-
-__device__ __forceinline__ int vzero() {   // a zero the optimiser cannot see: keeps uniform addresses on the vector path
-    int z;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-    return z;
-}
-__device__ __forceinline__ unsigned ld_word(const unsigned* p) {
-    return __hip_atomic_load(p + vzero(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Wave-uniform wait until *cnt >= target.
-__device__ __forceinline__ void wait_ge(const unsigned* cnt, unsigned target, bool& dead, unsigned* status) {
-    if (target == 0u || dead) return;
-    unsigned spins = 0;
-    for (;;) {
-        const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_word(cnt));
-        if (v >= target) break;
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 127u) == 0u) {
-            const unsigned s = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_word(status));
-            if (s != 0u || spins > kSpinLimit) {
-                dead = true;
-                if ((threadIdx.x & 63) == 0) atomicOr(status, 1u);
-                break;
-            }
-        }
-    }
-}
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void arrive(unsigned* cnt, unsigned n) {
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long long bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 ld4wt(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, kAuxWT));
-}
-__device__ __forceinline__ void st4wt(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, kAuxWT);
-}
 
 // Dense(D) whose input arrives as the two fp16 pieces of the operand (dense_layer_h2 minus its split: same MFMAs, same
 // order, same epilogue).
@@ -117,64 +75,8 @@ __device__ __forceinline__ void dense_layer_h2_pieces(const f16x8 (&bh)[D / 32],
         a[t].hi = acc[t].hi * inv;
     }
 }
-// (the existing one, dense_h2.hip)
-template <int D>
-__device__ __forceinline__ void dense_layer_h2_loop(f32x4 (&a)[D / 16], const _Float16* wh, const _Float16* wl,
-                                                    const float* bias, bool relu, int g, int rl, float& wit) {
-    constexpr int NT = D / 16, KB = D / 32;
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = ld4(bias + t * 16 + g * 4);
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = a[2 * kb + (j >> 2)][j & 3];
-        f16x8 bh, bl;
-        split2w(x, bh, bl, wit);
-        kblock_h2<NT>(acc, wh, wl, kb, g, rl, bh, bl);
-    }
-    const f32x2 inv = {kH2InvScale, kH2InvScale};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (relu) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
-        }
-        a[t].lo = acc[t].lo * inv;
-        a[t].hi = acc[t].hi * inv;
-    }
-}
-
-// Optional phase trace (args.trace != NULL selects the TRACE variant of the kernel): per (workgroup, wavefront) 8 sums of
-// s_memrealtime ticks (100 MHz), see tools/loop_trace.py for the phases.
-template <bool ON>
-struct LoopTrace {
-    unsigned long long* dst;
-    unsigned long long prev;
-    unsigned long long acc[ON ? 16 : 1];
-    __device__ __forceinline__ void begin(unsigned long long* p) {
-        if constexpr (ON) {
-            dst = p;
-            for (int i = 0; i < 16; ++i) acc[i] = 0;
-            prev = __builtin_amdgcn_s_memrealtime();
-        }
-    }
-    __device__ __forceinline__ void mark(int i) {
-        if constexpr (ON) {
-            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            acc[i] += now - prev;
-            prev = now;
-        }
-    }
-    __device__ __forceinline__ void flush() {
-        if constexpr (ON) {
-            if ((threadIdx.x & 63) == 0)
-                for (int i = 0; i < 16; ++i) dst[i] = acc[i];
-        }
-    }
-};
-
+// (args.trace != NULL selects the TRACE variant of the kernel, LoopTrace in loop_sync.h: see tools/loop_trace.py for the
+// phases)
 template <int D, bool CENTERED, bool TRACE>
 __global__ __launch_bounds__(kLoopWaves * 64) void mp_loop_h2_kernel(const tspgnn_mp_loop_args a) {
     constexpr int TPG = D / 16, NT4 = D / 4, KBH = D / 32;
@@ -698,7 +600,7 @@ __global__ __launch_bounds__(kLoopWaves * 64) void mp_loop_h2_kernel(const tspgn
                 for (int ly = 0; ly < L; ++ly) {
                     const _Float16* wh = reinterpret_cast<const _Float16*>(lds_wb + (size_t)ly * LAYER_BYTES);
                     const float* bias = reinterpret_cast<const float*>(lds_wb + (size_t)ly * LAYER_BYTES + 2 * D * D * 2);
-                    dense_layer_h2_loop<D>(hn[j], wh, wh + D * D, bias, (mask >> ly) & 1u, g, rl, wit);
+                    dense_layer_h2<D>(hn[j], wh, wh + D * D, bias, (mask >> ly) & 1u, g, rl, wit);
                 }
                 // Zx = 2^s (y Kx), a gate (TPG column tiles) at a time on the same operand pieces
                 f16x8 yh[KBH], yl[KBH];
@@ -783,7 +685,15 @@ extern "C" int tspgnn_mp_loop_h2(const tspgnn_mp_loop_args* args, int d, void* s
         a.trace ? (a.z_centered ? &mp_loop_h2_kernel<D, true, true> : &mp_loop_h2_kernel<D, false, true>)
                 : (a.z_centered ? &mp_loop_h2_kernel<D, true, false> : &mp_loop_h2_kernel<D, false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return fail((int)e, "mp_loop_h2: hipFuncSetAttribute(%d B): %s", (int)lds_bytes, hipGetErrorString(e));
+    if (e != hipSuccess)
+        return fail(TSPGNN_EUNSUPPORTED, "mp_loop_h2: hipFuncSetAttribute(%d B): %s", (int)lds_bytes, hipGetErrorString(e));
+    // every wait inside the launch assumes all `grid` workgroups are resident at once: ask the runtime (the caller falls
+    // back to the stepwise launches on TSPGNN_EUNSUPPORTED)
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), kLoopWaves * 64, lds_bytes);
+    if (e != hipSuccess || per_cu < 1)
+        return fail(TSPGNN_EUNSUPPORTED, "mp_loop_h2: a workgroup of %d threads and %zu bytes of LDS is not resident on this device",
+                    kLoopWaves * 64, lds_bytes);
     fn<<<a.grid, kLoopWaves * 64, lds_bytes, as_stream(stream)>>>(a);
     return launched("tspgnn_mp_loop_h2");
 }

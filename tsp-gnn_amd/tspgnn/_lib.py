@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSPGNN_LIB") or os.path.join(_HERE, "libtspgnn.so")   # (TSPGNN_LIB: A/B builds)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_int, c_uint, c_float, c_void_p, c_char_p, c_longlong = (ctypes.c_int, ctypes.c_uint, ctypes.c_float,
                                                           ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong)
@@ -43,6 +43,7 @@ SIGNATURES = {
     "tspgnn_lnlstm_fwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_mlp_fwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_mp_loop_h2": [c_void_p, c_int, c_void_p],
+    "tspgnn_mp_resident_h2": [c_void_p, c_int, c_void_p],
     "tspgnn_lnlstm_bwd_multi_f32": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_bwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_bwd_multi_bf16": [c_void_p, c_int, c_int, c_void_p],
@@ -130,6 +131,23 @@ class MpLoopArgs(ctypes.Structure):
                 ("v_zbias", c_void_p), ("v_zscale", c_void_p), ("v_mlp_wb", c_void_p), ("v_mlp_layers", c_int),
                 ("v_relu_mask", c_uint), ("v_proj_w", c_void_p), ("zx", c_void_p * 2), ("vagg", c_void_p * 2),
                 ("plan", c_void_p), ("counters", c_void_p), ("n_groups", c_int), ("grid", c_int),
+                ("M", c_int), ("N", c_int), ("T", c_int), ("z_centered", c_int),
+                ("range_flag", c_void_p), ("status", c_void_p), ("trace", c_void_p)]
+
+
+class MpResidentArgs(ctypes.Structure):
+    """tspgnn_mp_resident_args (include/tspgnn.h): the T-step loop as one launch, edge states through memory."""
+    _fields_ = [("e_h0", c_void_p), ("e_c0", c_void_p), ("e_h", c_void_p), ("e_c", c_void_p),
+                ("e_hs", c_void_p), ("e_cs", c_void_p), ("uv", c_void_p),
+                ("e_K", c_void_p), ("e_ln", c_void_p), ("e_mlp_wb", c_void_p), ("e_mlp_layers", c_int),
+                ("e_relu_mask", c_uint), ("msg", c_void_p * 2),
+                ("v_h0", c_void_p), ("v_c0", c_void_p), ("v_h", c_void_p), ("v_c", c_void_p),
+                ("rowptr", c_void_p), ("eid", c_void_p), ("v_K", c_void_p), ("v_ln", c_void_p),
+                ("v_zbias", c_void_p), ("v_zscale", c_void_p), ("v_mlp_wb", c_void_p), ("v_mlp_layers", c_int),
+                ("v_relu_mask", c_uint), ("v_proj_w", c_void_p), ("zx", c_void_p * 2), ("vagg", c_void_p * 2),
+                ("vh", c_void_p * 2),
+                ("plan", c_void_p), ("counters", c_void_p), ("n_groups", c_int), ("grid", c_int),
+                ("n_slots", c_int), ("lds_words", c_int),
                 ("M", c_int), ("N", c_int), ("T", c_int), ("z_centered", c_int),
                 ("range_flag", c_void_p), ("status", c_void_p), ("trace", c_void_p)]
 

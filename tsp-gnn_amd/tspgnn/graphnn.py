@@ -20,6 +20,7 @@ import torch
 
 from . import _lib
 from . import loop_plan
+from . import resident_plan
 from . import variables as V
 from .instance_loader import SparseEV
 from .mlp import Mlp, wgrad
@@ -101,11 +102,35 @@ def loop_enabled():
     return os.environ.get("TSPGNN_LOOP", "1") != "0"
 
 
+def loop_kind():
+    """Which one-launch form a batch may get: "auto" (default) = tspgnn_mp_loop_h2 (edge states in registers) for batches of
+    <= loop_plan.max_edge_tiles() tiles per wavefront, tspgnn_mp_resident_h2 (edge states through memory, LDS ticket) for
+    larger ones; TSPGNN_LOOP_KIND=loop / resident force one form (tests, A/B runs)."""
+    return os.environ.get("TSPGNN_LOOP_KIND", "auto")
+
+
+def choose_loop_plan(e_start, v_start, grid):
+    """-> (plan int32 ndarray, meta) or None; meta = (n_groups, grid, kind, n_slots, lds_words), kind "loop"
+    (loop_plan.py, tspgnn_mp_loop_h2) or "resident" (resident_plan.py, tspgnn_mp_resident_h2)."""
+    kind = loop_kind()
+    if kind in ("auto", "loop"):
+        built = loop_plan.build(e_start, v_start, grid=grid)
+        if built is not None:
+            return built[0], (built[1], grid, "loop", 0, 0)
+    if kind in ("auto", "resident"):
+        built = resident_plan.build(e_start, v_start, grid=grid)
+        if built is not None and kind == "auto" and not resident_plan.in_auto_window(int(e_start[-1])):
+            built = None
+        if built is not None:
+            return built["plan"], (built["n_groups"], grid, "resident", built["n_slots"], built["lds_words"])
+    return None
+
+
 def _make_loop_plan(ev, device):
-    """Work plan of tspgnn_mp_loop_h2 for a SparseEV on a GPU: built where the batch is packed (host side, cached per
-    block structure), uploaded with the adjacency -- a captured forward then serves any batch copied into its buffers
-    (DeviceBatch.copy_from copies the plan too).  None: no GPU, switched off, or the batch does not fit the resident
-    design."""
+    """Work plan of the one-launch T-step loop for a SparseEV on a GPU: built where the batch is packed (host side, cached
+    per block structure), uploaded with the adjacency -- a captured forward then serves any batch copied into its buffers
+    (DeviceBatch.copy_from copies the plan too).  None: no GPU, switched off, or the batch does not fit a resident
+    design.  -> (int32 device tensor, n_groups, grid, kind, n_slots, lds_words)."""
     dev = torch.device(device)
     if dev.type != "cuda" or not loop_enabled() or ev.shape[0] == 0:
         return None
@@ -116,11 +141,11 @@ def _make_loop_plan(ev, device):
             return None
     grid = torch.cuda.get_device_properties(dev).multi_processor_count
     grid -= grid % 8
-    built = loop_plan.build(blocks[0], blocks[1], grid=grid)
+    built = choose_loop_plan(blocks[0], blocks[1], grid)
     if built is None:
         return None
-    plan, n_groups = built
-    return (torch.from_numpy(plan).to(dev), n_groups, grid)
+    plan, meta = built
+    return (torch.from_numpy(plan).to(dev),) + meta
 
 
 class _States(dict):
@@ -188,7 +213,7 @@ class DeviceAdjacency(object):
         self.csr_t = csr_t  # same for the transpose
         self.uv = uv        # int32 [R,2] if the matrix is 0/1 with exactly two ones per row
         self._degrees = {}
-        self.loop_plan = None   # (int32 device tensor, n_groups, grid): work plan of tspgnn_mp_loop_h2 (loop_plan.py)
+        self.loop_plan = None   # (int32 device tensor, n_groups, grid, kind, n_slots, lds_words): _make_loop_plan
 
     def row_degrees(self, transpose=False):
         """Stored entries per row (of the transpose) as fp32, computed once per matrix."""
@@ -1281,7 +1306,9 @@ class GraphNN(object):
             for arr, d in pre_calls:
                 _lib.call_multi("tspgnn_mlp_fwd_multi_" + arith, arr, d)
             if loop_launch is not None:
-                return loop_launch(T)
+                done = loop_launch(T)
+                if done is not None:
+                    return done
             for t in range(T):
                 kind = (t & 1, t < T - 1, t == 0)
                 if kind not in built:
@@ -1320,7 +1347,7 @@ class GraphNN(object):
         adj = mats[ue["mat"]]
         if adj.loop_plan is None or adj.csr_t[2] is not None:
             return None
-        plan_t, n_groups, grid = adj.loop_plan
+        plan_t, n_groups, grid, kind, n_slots, lds_words = adj.loop_plan
         cell_e, cell_v = self._RNN_cells[ve], self._RNN_cells[vv]
         if cell_v.dx != 64 or cell_e.dx != 64:
             return None
@@ -1331,7 +1358,7 @@ class GraphNN(object):
         _, _, _, e_out1, _, _ = message(vv, 0, 1)
         v_wb, v_n, v_mask, _, v_pw, zx0 = message(ve, 0, 0)
         _, _, _, _, _, zx1 = message(ve, 0, 1)
-        if e_out0 is None or zx0 is None or e_n > 4 or v_n > 4 or v_n < 1:
+        if e_out0 is None or zx0 is None or e_n > 3 or v_n > 4 or v_n < 1:   # (e_n <= 3: resident next to Kh in LDS)
             return None
         if pushed[vv]:
             mlp_e = self._msg_MLPs[uvx["msg"]]
@@ -1343,10 +1370,17 @@ class GraphNN(object):
         out_e = LSTMStateTuple(c=torch.empty((M, 64), **f32), h=torch.empty((M, 64), **f32))
         out_v = LSTMStateTuple(c=torch.empty((N, 64), **f32), h=torch.empty((N, 64), **f32))
         vagg = [torch.empty((N, 64), **f32), torch.empty((N, 64), **f32)]
-        counters = torch.zeros(3 * 32 * n_groups + 32, dtype=torch.int32, device=f32["device"])
+        counters = torch.zeros(4 * 32 * n_groups + 32, dtype=torch.int32, device=f32["device"])
         guard = self.store.h2_guard()
         fs_e, fs_v = first_state[ve], first_state[vv]
-        a = _lib.MpLoopArgs()
+        resident = kind == "resident"
+        a = _lib.MpResidentArgs() if resident else _lib.MpLoopArgs()
+        if resident:   # the edge states between the steps, by tile slot (private to the launch)
+            slots = [torch.empty((n_slots * 16, 64), **f32), torch.empty((n_slots * 16, 64), **f32)]
+            a.e_hs, a.e_cs, a.n_slots, a.lds_words = _lib.ptr(slots[0]), _lib.ptr(slots[1]), n_slots, lds_words
+            vh = [torch.empty((N, 64), **f32), torch.empty((N, 64), **f32)]
+            a.vh[0], a.vh[1] = _lib.ptr(vh[0]), _lib.ptr(vh[1])
+            keep.extend([slots, vh])
         a.e_h0, a.e_c0, a.e_h, a.e_c = _lib.ptr(fs_e.h), _lib.ptr(fs_e.c), _lib.ptr(out_e.h), _lib.ptr(out_e.c)
         a.uv, a.e_K, a.e_ln = _lib.ptr(adj.uv), _lib.ptr(e_K), _lib.ptr(cell_e.ln())
         a.e_mlp_wb, a.e_mlp_layers, a.e_relu_mask = _lib.ptr(e_wb), e_n, e_mask
@@ -1362,14 +1396,29 @@ class GraphNN(object):
         a.range_flag, a.status = guard.data_ptr(), guard.data_ptr() + 8
         trace = None
         if os.environ.get("TSPGNN_LOOP_TRACE"):   # development: per-wavefront phase times (tools/loop_trace.py)
-            trace = self.loop_trace = torch.zeros((grid, loop_plan.WAVES, 16), dtype=torch.int64, device=f32["device"])
+            trace = self.loop_trace = torch.zeros((grid, resident_plan.WAVES if resident else loop_plan.WAVES, 16),
+                                                  dtype=torch.int64, device=f32["device"])
         a.trace = _lib.ptr(trace)
         keep.extend([out_e, out_v, vagg, counters, plan_t, v_K, zb, deg, e_K, a, trace])
 
+        unsupported = [False]
+
         def launch(T):
+            """-> the final states, or None when the device cannot keep the launch's workgroups resident (the entry point
+            asks the runtime before it launches anything and answers TSPGNN_EUNSUPPORTED): the caller then runs the
+            stepwise launches."""
+            if unsupported[0]:
+                return None
             a.T = int(T)
             counters.zero_()
-            _lib.call("tspgnn_mp_loop_h2", ctypes.byref(a), 64, _lib.current_stream())
+            try:
+                _lib.call("tspgnn_mp_resident_h2" if resident else "tspgnn_mp_loop_h2", ctypes.byref(a), 64,
+                          _lib.current_stream())
+            except _lib.TspgnnError as e:
+                if e.status != -2:
+                    raise
+                unsupported[0] = True
+                return None
             return {ve: out_e, vv: out_v}
         return launch
 

@@ -245,8 +245,7 @@ class BatchStager(object):
     (round 4) at 9-17 % behind the resident-batch rate at C2, the one packer thread nearly as slow as the forward itself."""
 
     def __init__(self, sess, template_instances, time_steps, dev=0.02, target_cost=None, slots=3):
-        from . import loop_plan
-        from .graphnn import DeviceAdjacency, loop_enabled
+        from .graphnn import DeviceAdjacency, choose_loop_plan, loop_enabled
         from .model import DeviceBatch
         if sess.device.type != "cuda":
             raise RuntimeError("BatchStager needs a GPU session (pinned staging, asynchronous copies)")
@@ -259,9 +258,9 @@ class BatchStager(object):
         if loop_enabled() and M > 0:
             grid = torch.cuda.get_device_properties(sess.device).multi_processor_count
             grid -= grid % 8
-            built = loop_plan.build(np.concatenate([[0], np.cumsum(n_edges)]), np.concatenate([[0], np.cumsum(self.sizes)]), grid=grid)
+            built = choose_loop_plan(np.concatenate([[0], np.cumsum(n_edges)]), np.concatenate([[0], np.cumsum(self.sizes)]), grid)
             if built is not None:
-                plan, self.plan_meta = built[0], (built[1], grid)
+                plan, self.plan_meta = built
         self.offsets, self.nbytes, total = stage_layout(M, N, B, 0 if plan is None else plan.size)
         self.M, self.N, self.B = M, N, B
         self.slots = max(2, int(slots))
@@ -280,7 +279,7 @@ class BatchStager(object):
         csr_t = (view(2, torch.int32, (N + 1,)), view(1, torch.int32, (2 * M,)), None)
         adj = DeviceAdjacency((M, N), sess.device, csr, csr_t, uv=uv)
         if plan is not None:
-            adj.loop_plan = (view(7, torch.int32, (plan.size,)), self.plan_meta[0], self.plan_meta[1])
+            adj.loop_plan = (view(7, torch.int32, (plan.size,)),) + tuple(self.plan_meta)
         b = DeviceBatch()
         b.adj, b.M, b.N, b.B, b.T = adj, M, N, B, self.T
         b.WC, b.labels, b.seg = view(3, torch.float32, (M, 2)), view(4, torch.float32, (B,)), view(5, torch.int32, (B + 1,))
