@@ -536,8 +536,8 @@ int tspgnn_mlp_bwd_multi_h2(const tspgnn_mlp_bwd_task* tasks, int n_tasks, int d
  * chain's input, its output and the incoming gradient; both GEMM chains on the fp16 matrix cores (f16x2):
  *   a_0 = X,  a_{l+1} = act_l(a_l W_l + b_l)  (recomputed as the f16x2 forward forms them; a_L = Yout is read),
  *   dpre_l = G_{l+1} * [a_{l+1} > 0]  (G_L = dY, or dY[uv[r][0]] + dY[uv[r][1]]),   G_l = dpre_l W_l^T,   dX (+)= G_0.
- * The operands of the weight gradients leave through `acts` (a_1 .. a_{L-1}: layer l+1 at acts + l * acts_stride) and
- * `dpre` (dpre_l at dpre + l * dpre_stride), buffers of the backward pass (either may be NULL).  d = 64, 1 <= n_layers <= 3.
+ * The weight gradients { a_l^T dpre_l, colsum(dpre_l) } are formed in the same launch (`partial`).  d = 64, 1 <= n_layers <= 3.
+ * Opt-in (TSPGNN_RECOMPUTE=1): parity-green, slower than the taped backward at C2.
  */
 typedef struct tspgnn_mlp_bwd_rc_task {
     const float* X;          /* [rows, d]: the chain's input rows */
@@ -548,9 +548,9 @@ typedef struct tspgnn_mlp_bwd_rc_task {
     const int32_t* uv;       /* optional, [rows, 2]: gather-init mode as in tspgnn_mlp_bwd_task */
     float* dX; int accumulate_dx;
     int rows; int n_layers; unsigned relu_mask;
-    float* acts; long long acts_stride;
-    float* dpre; long long dpre_stride;
-    float* partial;          /* != NULL (then acts == dpre == NULL): the weight gradients are formed in the launch --
+    float* acts; long long acts_stride;      /* must be NULL / 0 (ABI 4: the form that handed the recomputed activations and */
+    float* dpre; long long dpre_stride;      /* pre-activation gradients to tspgnn_wgrad_f32 was removed; layout kept)        */
+    float* partial;          /* required: the weight gradients are formed in the launch --
                                 partial[workgroup] += { a_l^T dpre_l , colsum(dpre_l) }_l, per workgroup [W_0, b_0, W_1, ...];
                                 tspgnn_mlp_bwd_rc_partial_floats(d, n_layers) floats, zeroed by the caller before the first
                                 launch of a backward pass, ACCUMULATED by every launch, folded in a fixed order by

@@ -13,15 +13,15 @@ ANCHORS = {
     # name: (sizes, T)  -- BASELINE.json configs[0], [1], [3]
     "c1": (lambda: [20] * 32, 8),
     "c2": (lambda: [40] * 128, 32),
-    "c4": (lambda: [int(x) for x in np.random.RandomState(0).randint(20, 81, size=512)], 8),   # (T = 2 until round 5)
+    "c4": (lambda: [int(x) for x in np.random.RandomState(0).randint(20, 81, size=512)], 32),   # (T = 2, then 8, until round 6: now the depth `bench.py --workload c4` runs)
 }
 ANCHOR_ROWS = 512
 
 
 # BASELINE config 5 at one GPU's graph size and depth (n=200, d=128, T=64, bf16 embeddings / fp32 accumulate) on 4 of the 32
 # graphs of a shard: oracle = torch_oracle.forward(..., bf16=True), the float64 restatement with the build's rounding points
-# "c5shard": ALL 32 graphs of one GPU's shard of config 5 (M = 636 800 edges, the size `bench.py --workload c5` runs) at T = 2
-BF16_ANCHORS = {"c5": (lambda: [200] * 4, 128, 64), "c5shard": (lambda: [200] * 32, 128, 2)}
+# "c5shard": ALL 32 graphs of one GPU's shard of config 5 (M = 636 800 edges, the size `bench.py --workload c5` runs) at T = 8
+BF16_ANCHORS = {"c5": (lambda: [200] * 4, 128, 64), "c5shard": (lambda: [200] * 32, 128, 8)}   # (c5shard: T = 2 until round 6)
 
 
 def bf16_anchor_inputs(name):
@@ -66,8 +66,24 @@ def anchor_rows(n_rows):
 # LayerNorm parameters / biases (init_params(perturb=True): with gamma = 1, beta = 0 and zero biases whole gradient
 # blocks would sit at their symmetric points).  Kept per variable: its 2-norm, its largest entry, 64 sampled entries, and
 # what the op-for-op float32 autograd restatement loses on the same variable (the error budget of any fp32 backward).
-GRAD_ANCHORS = {"c2": (lambda: [40] * 128, 2), "c1": (lambda: [20] * 32, 8)}
+# Round 6: "c2t8" = C2 four times as deep (T = 8: ~16 GB of float64 autograd in the build container), and with every anchor
+# the CONDITIONING of each variable's gradient: the largest change of the float64 gradient (sampled entries, 2-norm) when
+# every variable entry moves by ONE fp32 ulp (w * (1 +- 2^-23), random signs, GRAD_PERTURBATIONS draws).  An fp32-class
+# backward cannot be asked for less than that -- it computes the exact gradient of a network whose weights are a rounding
+# away -- and tests/test_gpu_anchors.py asks every arithmetic for 2x that, with no arithmetic-specific allowance.
+GRAD_ANCHORS = {"c2": (lambda: [40] * 128, 2), "c1": (lambda: [20] * 32, 8), "c2t8": (lambda: [40] * 128, 8)}
 GRAD_SAMPLES = 64
+GRAD_PERTURBATIONS = 3
+
+
+def ulp_perturbed(params, draw):
+    """Every entry of every variable moved by one fp32 ulp (relative 2^-23), signs from a generator seeded by ``draw``."""
+    rng = np.random.RandomState(7919 + draw)
+    out = {}
+    for k, v in params.items():
+        a = np.asarray(v, dtype=np.float64)
+        out[k] = a * (1.0 + (rng.randint(0, 2, size=a.shape) * 2 - 1) * 2.0 ** -23)
+    return out
 
 # "Far from init" weights (round 5): the float64 oracle trained for 2 000 Adam steps at lr 1e-3 (model.py:160-167 with a
 # larger step) on synthetic batches -- LayerNorm gains, biases and kernels with the statistics of a trained network, not

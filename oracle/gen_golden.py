@@ -151,19 +151,24 @@ def gen_anchors(only=None):
         print("anchor", name, "T", T, "M", EV.shape[0], "loss %.9f" % data["loss"], "%.1f s" % (time.time() - t0))
 
 
-def gen_grad_anchors():
-    """anchor_grad_*.npz: float64 gradients at full size (oracle/anchors.py, GRAD_ANCHORS)."""
+def gen_grad_anchors(only=None):
+    """anchor_grad_*.npz: float64 gradients at full size, what the op-for-op float32 restatement loses per variable, and
+    the per-variable spread of the float64 gradient under one-ulp perturbations of the weights (oracle/anchors.py)."""
     import time
     import torch
     from oracle import torch_oracle as TO
+    from oracle.anchors import GRAD_PERTURBATIONS, ulp_perturbed
 
     torch.set_num_threads(os.cpu_count() or 1)
     for name in GRAD_ANCHORS:
+        if only is not None and name not in only:
+            continue
         batch, params, T, finger = grad_anchor_inputs(name)
         EV, W, C, route_exists, n_vertices, n_edges = batch
         ob = {"ev_uv": EV.uv, "W": W, "C": C, "route_exists": route_exists, "n_vertices": n_vertices, "n_edges": n_edges}
         t0 = time.time()
         out, g = TO.loss_and_grads(params, ob, T, dtype=torch.float64)
+        print("  float64 gradient %.1f s" % (time.time() - t0), flush=True)
         _, g32 = TO.loss_and_grads(params, ob, T, dtype=torch.float32)
         data = {"T": np.int64(T), "d": np.int64(64), "fingerprint": finger, "loss": np.float64(out["loss"].item())}
         gmax = max(float(np.abs(v).max()) for v in g.values())
@@ -174,10 +179,24 @@ def gen_grad_anchors():
             data["norm:" + k] = np.float64(np.sqrt((flat ** 2).sum()))
             data["absmax:" + k] = np.float64(np.abs(flat).max())
             data["sample:" + k] = flat[idx]
-            data["err32:" + k] = np.float64(np.abs(np.asarray(g32[k], dtype=np.float64).reshape(-1) - flat).max())
+            f32 = np.asarray(g32[k], dtype=np.float64).reshape(-1)
+            data["err32:" + k] = np.float64(np.abs(f32 - flat).max())
+            data["err32_norm:" + k] = np.float64(abs(float(np.sqrt((f32 ** 2).sum())) - float(np.sqrt((flat ** 2).sum()))))
+            data["ulp_spread:" + k] = np.float64(0.0)
+            data["ulp_spread_norm:" + k] = np.float64(0.0)
+        for draw in range(GRAD_PERTURBATIONS):
+            _, gp = TO.loss_and_grads(ulp_perturbed(params, draw), ob, T, dtype=torch.float64)
+            for k, v in g.items():
+                a, b = np.asarray(v, dtype=np.float64).reshape(-1), np.asarray(gp[k], dtype=np.float64).reshape(-1)
+                idx = grad_sample_index(k, a.size)
+                data["ulp_spread:" + k] = np.float64(max(float(data["ulp_spread:" + k]), float(np.abs(a[idx] - b[idx]).max())))
+                data["ulp_spread_norm:" + k] = np.float64(max(float(data["ulp_spread_norm:" + k]),
+                                                              abs(float(np.sqrt((a ** 2).sum())) - float(np.sqrt((b ** 2).sum())))))
+            print("  perturbation %d %.1f s" % (draw, time.time() - t0), flush=True)
+        data["ulp_perturbations"] = np.int64(GRAD_PERTURBATIONS)
         np.savez_compressed(os.path.join(OUT, "anchor_grad_%s.npz" % name), **data)
         print("grad anchor", name, "T", T, "M", EV.shape[0], "loss %.9f" % data["loss"], "|g|max %.3e" % gmax,
-              "%.1f s" % (time.time() - t0))
+              "%.1f s" % (time.time() - t0), flush=True)
 
 
 def gen_trained():
@@ -298,3 +317,5 @@ if __name__ == "__main__":
             gen_bf16_anchors(only=w[5:].split(","))
         if w.startswith("anchors:"):
             gen_anchors(only=w[8:].split(","))
+        if w.startswith("grads:"):
+            gen_grad_anchors(only=w[6:].split(","))

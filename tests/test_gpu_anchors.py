@@ -1,6 +1,6 @@
 """Full-size parity against committed float64 anchors (tests/golden/anchor_*.npz, written by oracle/gen_golden.py in
 the build container): BASELINE.json's C1 (n=20, B=32, T=8), C2 -- the headline configuration (n=40, B=128, T=32) --
-and C4 (ragged n in 20..80, B=512, T=2), every GEMM arithmetic of the forward, at the 1e-5 relative tolerance
+and C4 (ragged n in 20..80, B=512, T=32: the depth `bench.py --workload c4` runs), every GEMM arithmetic of the forward, at the 1e-5 relative tolerance
 north_star states.  The oracle does not run here: the test regenerates the inputs, checks their fingerprints, runs
 the HIP forward and compares predictions, loss, and the column sums / 512 sampled rows of E.h, E.c, V.h, V.c."""
 import os
@@ -96,15 +96,20 @@ def test_bf16_storage_at_config5_depth(cuda_device, name):
 
 
 @pytest.mark.parametrize("gemm", ["f16x2", "bf16x3"])
-@pytest.mark.parametrize("name", ["c2", "c1"])
+@pytest.mark.parametrize("name", ["c2", "c2t8", "c1"])
 def test_full_size_gradients_match_float64_anchor(cuda_device, name, gemm):
-    """The training step's gradients at FULL size -- C2 (M = 99 840 edges) at T = 2, C1 at its own T = 8 -- against committed
-    float64 autograd gradients (tests/golden/anchor_grad_*.npz, oracle/gen_golden.py grads): per variable the 2-norm and 64
-    sampled entries.  Bar per variable, relative to max(its largest entry, 1e-3 of the largest gradient entry overall):
-    max(1e-5, 2 x what the op-for-op float32 autograd restatement loses on that variable, what it loses on its worst
-    variable) -- test_gradient_parity_with_autograd_oracle's bar at the size the benchmark runs, where a bias gradient is
-    a sum over 10^5 rows (measured round 5, C2 at T = 2: fp32 restatement worst 1.9e-4; HIP f16x2 backward 8.4e-4 before
-    its dz operand got a scaled second piece, see split2s in csrc/h2_tile.h)."""
+    """The training step's gradients at FULL size -- C2 (M = 99 840 edges) at T = 2 and at T = 8, C1 at its own T = 8 --
+    against committed float64 autograd gradients (tests/golden/anchor_grad_*.npz, oracle/gen_golden.py grads): per variable
+    the 2-norm and 64 sampled entries.  ONE bar for every arithmetic (no arithmetic-specific slack), per
+    variable, relative to max(its largest entry, 1e-3 of the largest gradient entry overall):
+        max(1e-5,  2 x what the op-for-op float32 autograd restatement loses on that variable  (forward error of fp32
+                   arithmetic on exact operands: sums of 10^5 near-cancelling rows),
+                   2 x how far the variable's float64 gradient moves when every weight moves by ONE fp32 ulp  (the
+                   anchor's `ulp_spread`: backward error -- an fp32-class kernel computes the exact gradient of a network
+                   a rounding away; at C2 the LayerNorm shifts of the vertex cell move 8e-4 under that perturbation, which is
+                   where the f16x2 path -- whose weight packing rounds to 22 bits -- sits, see profiles/r06_grad_anchor_report.txt)).
+    The variable's 2-norm (the one check that sees every entry) gets the same bar built from the norm's own two figures.
+    """
     import torch
     import tspgnn
     from oracle.anchors import grad_anchor_inputs, grad_sample_index
@@ -125,24 +130,19 @@ def test_full_size_gradients_match_float64_anchor(cuda_device, name, gemm):
     assert abs(float(out["stats"][0].item()) - float(z["loss"])) < REL_TOL
     gscale = float(z["grad_absmax"])
     worst = (0.0, None)
-    # what the fp32 restatement loses on its WORST variable (relative to that variable's scale): sums over 10^5 rows with
-    # heavy cancellation cost any fp32-class arithmetic about this much, on one variable or another
-    fp32_worst = max(float(z["err32:" + k]) / max(float(z["absmax:" + k]), 1e-3 * gscale) for k in g)
-    # f16x2 (the default training arithmetic: f16x2 forward and cell backward): measured 8.4e-4 on its worst variable at C2
-    # (LayerNorm shifts of the vertex cell, biases of E_msg_V: sums over 10^5 rows downstream of the edge cell's dz) where
-    # the fp32 restatement's worst is 1.9e-4 and bf16x3 forward + fp32-MFMA backward 1.5e-4 -- 4.5x; one cell-backward
-    # launch alone is at 1e-7 in both arithmetics (tools/cell_bwd_colsum_probe.py), the source is not isolated
-    slack = 5.0 if gemm == "f16x2" else 1.0
     for k in g:
         # the oracle's gradients include the L2 term 1e-10 * w (model.py:163-166); the HIP backward adds it in the optimiser
         ref = z["sample:" + k] - 1e-10 * np.asarray(params[k], dtype=np.float64).reshape(-1)[grad_sample_index(k, params[k].size)]
         got = np.asarray(g[k], dtype=np.float64).reshape(-1)[grad_sample_index(k, params[k].size)]
         scale = max(float(z["absmax:" + k]), 1e-3 * gscale)
-        bar = max(1e-5, 2.0 * float(z["err32:" + k]) / scale, slack * fp32_worst)
+        bar = max(1e-5, 2.0 * float(z["err32:" + k]) / scale, 2.0 * float(z["ulp_spread:" + k]) / scale)
         err = float(np.abs(got - ref).max()) / scale
-        nerr = abs(float(np.sqrt((np.asarray(g[k], dtype=np.float64) ** 2).sum())) - float(z["norm:" + k])) / max(float(z["norm:" + k]), 1e-3 * gscale)
+        nscale = max(float(z["norm:" + k]), 1e-3 * gscale)
+        nbar = max(1e-5, 2.0 * float(z["err32_norm:" + k]) / nscale, 2.0 * float(z["ulp_spread_norm:" + k]) / nscale)
+        whole = np.asarray(g[k], dtype=np.float64) + 1e-10 * np.asarray(params[k], dtype=np.float64)   # (+ the L2 term, as above)
+        nerr = abs(float(np.sqrt((whole ** 2).sum())) - float(z["norm:" + k])) / nscale
         if err / bar > worst[0]:
             worst = (err / bar, "%s: %.2e against a bar of %.2e" % (k, err, bar))
         assert err < bar, (k, err, bar)
-        assert nerr < bar, (k, "norm", nerr)
+        assert nerr < nbar, (k, "norm", nerr, nbar)
     print("gradient anchor %s %s (T=%d): worst variable %s" % (name, gemm, T, worst[1]))

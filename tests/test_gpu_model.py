@@ -199,6 +199,74 @@ def test_generic_graphnn_wiring_two_inputs(cuda_device):
     assert rel_err(out["U"].h.cpu().numpy(), Uh) < REL_TOL and rel_err(out["W"].c.cpu().numpy(), Wc) < REL_TOL
 
 
+class _Square(object):
+    """A loop entry's 'fun' that brings its own vector-Jacobian product along (GraphNN._fun_vjp)."""
+
+    def __call__(self, x):
+        return x * x
+
+    def vjp(self, h, g_out):
+        return 2.0 * h * g_out
+
+
+@pytest.mark.parametrize("gemm", ["f16x2", "f32"])
+def test_generic_wiring_trains_through_fun_and_appended_matrix_entries(cuda_device, gemm):
+    """The last two loop-entry kinds of graphnn.py:142-173 under tf.gradients (model.py:166): a Python 'fun' ahead of the
+    message MLP (graphnn.py:149-151) -- one differentiated by autograd on the call, one with its own vjp -- and a matrix
+    appended to the cell input as it is (graphnn.py:163-165; a constant: its columns only meet the cell kernel).  Forward
+    states and EVERY variable's gradient (plus the gradient w.r.t. the initial embeddings) against float64 autograd over the
+    oracle's op-for-op helpers on the same wiring, for a loss that is a fixed linear functional of the final states."""
+    from tspgnn import variables as V
+    d, T = 32, 3
+    store = V.VariableStore()
+    rng = np.random.RandomState(1)
+    A = (rng.randn(9, 7) * (rng.rand(9, 7) < 0.6)).astype(np.float32)       # valued "M": U x W
+    F = rng.randn(9, 32).astype(np.float32)                                  # appended to U's cell input as it is
+    half_tanh = lambda x: 0.5 * torch.tanh(x)    # noqa: E731
+    gnn = tspgnn.GraphNN({"U": d, "W": d}, {"M": ("U", "W"), "F": ("U", 32)}, {"c": ("W", "U"), "b": ("U", "W")},
+                         {"U": [{"var": "U", "fun": half_tanh}, {"mat": "M", "msg": "c", "var": "W"}, {"mat": "F"}],
+                          "W": [{"mat": "M", "transpose?": True, "msg": "b", "var": "U", "fun": _Square()}]},
+                         name="G", store=store)
+    gnn.gemm = gemm
+    store.finalize(cuda_device); store.initialize(seed=6)
+    sd = {k: v.astype(np.float64) for k, v in store.state_dict().items()}
+    U0 = rng.randn(9, d).astype(np.float32); W0 = rng.randn(7, d).astype(np.float32)
+    wU = rng.randn(9, d).astype(np.float32); wW = rng.randn(7, d).astype(np.float32)
+    dev_t = lambda a: torch.from_numpy(a).to(cuda_device)    # noqa: E731
+    store.zero_grad()
+    states, tape = gnn.forward_train({"M": A, "F": F}, {"U": dev_t(U0), "W": dev_t(W0)}, T)
+    dinit = gnn.backward(tape, {"U": (dev_t(wU), None), "W": (None, dev_t(wW))})
+    torch.cuda.synchronize()
+    got = store.grad_dict()
+
+    # float64 autograd over the oracle's helpers, same wiring
+    p = TO.to_torch(sd, torch.float64, requires_grad=True)
+    A64, F64 = torch.tensor(A, dtype=torch.float64), torch.tensor(F, dtype=torch.float64)
+    Uh = torch.tensor(U0, dtype=torch.float64, requires_grad=True)
+    Wh = torch.tensor(W0, dtype=torch.float64, requires_grad=True)
+    uh, wh, uc, wc = Uh, Wh, torch.zeros(9, d, dtype=torch.float64), torch.zeros(7, d, dtype=torch.float64)
+    for _ in range(T):
+        xu = torch.cat([0.5 * torch.tanh(uh), A64 @ TO.mlp(wh, p, "G/c"), F64], dim=1)
+        xw = A64.T @ TO.mlp(uh * uh, p, "G/b")
+        (uh, uc), (wh, wc) = (TO.lnlstm_cell(xu, uh, uc, p, None, base="G/U_cell/layer_norm_basic_lstm_cell"),
+                              TO.lnlstm_cell(xw, wh, wc, p, None, base="G/W_cell/layer_norm_basic_lstm_cell"))
+    assert rel_err(states["U"].h.cpu().numpy(), uh.detach().numpy()) < REL_TOL
+    assert rel_err(states["W"].c.cpu().numpy(), wc.detach().numpy()) < REL_TOL
+    loss = (uh * torch.tensor(wU, dtype=torch.float64)).sum() + (wc * torch.tensor(wW, dtype=torch.float64)).sum()
+    names = list(p.keys())
+    grads = torch.autograd.grad(loss, [p[k] for k in names] + [Uh, Wh], allow_unused=True)
+    gscale = max(float(g.abs().max()) for g in grads if g is not None)
+    for k, g in zip(names, grads[:len(names)]):
+        ref = np.zeros_like(sd[k]) if g is None else g.numpy()
+        scale = max(np.abs(ref).max(), 1e-3 * gscale)
+        assert np.abs(got[k].astype(np.float64) - ref).max() / scale < 2e-5, k
+    # the F columns of U's kernel saw a gradient (rows [2d, 2d + 32) of kernel[dx + d, 4d]), F itself none
+    kU = got["G/U_cell/layer_norm_basic_lstm_cell/kernel"]
+    assert np.abs(kU[2 * d:2 * d + 32]).max() > 1e-4 * gscale
+    for v, g in (("U", grads[-2]), ("W", grads[-1])):
+        assert rel_err(dinit[v][0].cpu().numpy(), g.numpy()) < 2e-5, v
+
+
 def test_c2_full_size_properties(cuda_device):
     """BASELINE configs[1] (n=40, B=128, d=64, T=32) at full size: finite outputs, the paired
     instances (same graph, C*(1-/+dev)) differ, and shuffling the problems permutes predictions."""
@@ -832,13 +900,12 @@ def test_pushed_training_gradients_equal_the_plain_form(cuda_device, name, d, T)
         assert np.abs(gp[k] - gu[k]).max() / scale < 1e-4, k
 
 
-@pytest.mark.parametrize("fused_dw", [True, False])
 @pytest.mark.parametrize("name,d,T", [("ragged_B6", 64, 4), ("n20_B32", 64, 5), ("n5_B2", 64, 1)])
-def test_recomputed_training_gradients_equal_the_taped_form(cuda_device, name, d, T, fused_dw):
-    """Training with the pushed message MLP's backward recomputing its hidden activations (tspgnn_mlp_bwd_rc_h2, opt-in;
-    the forward then tapes only the messages and runs the MLP inside the cell launch; ``fused_dw``: the MLP's weight
-    gradients formed in the same launch) against the taped form: same loss, bit-identical states, gradients equal up to
-    the arithmetic of the data gradient (fp16 matrix cores on scaled splits instead of the fp32 matrix instruction)."""
+def test_recomputed_training_gradients_equal_the_taped_form(cuda_device, name, d, T):
+    """Training with the pushed message MLP's backward recomputing its hidden activations and forming the MLP's weight
+    gradients in the same launch (tspgnn_mlp_bwd_rc_h2, opt-in; the forward then tapes only the messages and runs the MLP
+    inside the cell launch) against the taped form: same loss, bit-identical states, gradients equal up to the arithmetic of
+    the data gradient (fp16 matrix cores on scaled splits instead of the fp32 matrix instruction)."""
     t = pack_tuple(name, 1)
     params = P.init_params(d, seed=8, perturb=True)
     grads = []
@@ -848,7 +915,6 @@ def test_recomputed_training_gradients_equal_the_taped_form(cuda_device, name, d
         sess.run(tspgnn.global_variables_initializer())
         model.store.load(params)
         model["gnn"].recompute_messages = rc
-        model["gnn"].recompute_weight_gradients = fused_dw
         EV, W, C, route_exists, n_vertices, n_edges = t
         feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
                 model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}

@@ -138,3 +138,29 @@ def test_batch_prefetcher_keeps_the_order_with_several_workers():
         for b in tspgnn.BatchPrefetcher(sess, iter(insts), 2, workers=2, pack=bad):
             seen.append(b.M)
     assert seen == got[:4]
+
+
+def test_abandoned_batch_prefetcher_is_collected_and_releases_its_workers():
+    """a consumer that drops a BatchPrefetcher half-way (no close(), no `with`) must not leave its worker
+    threads blocked on the full queue for the life of the process -- the threads hold the shared state, not the
+    prefetcher, so the prefetcher is collected and its finaliser closes the state."""
+    import gc
+    import time
+    import weakref
+    import tspgnn
+    model = tspgnn.build_network(32)
+    sess = tspgnn.Session(model, device="cpu")
+    rng = np.random.RandomState(1)
+    insts = [[tspgnn.random_instance(5, rng) for _ in range(2)] for _ in range(40)]
+    pf = tspgnn.BatchPrefetcher(sess, iter(insts), 2, workers=2, depth=2,
+                                pack=lambda inst: tspgnn.InstanceLoader.create_batch(inst, dev=0.02))
+    next(pf)                                  # the workers now sit on a full queue
+    threads = list(pf._state._threads)
+    ref = weakref.ref(pf)
+    del pf
+    gc.collect()
+    assert ref() is None, "the prefetcher is still referenced (by its own workers?)"
+    deadline = time.time() + 10.0
+    while any(t.is_alive() for t in threads) and time.time() < deadline:
+        time.sleep(0.02)
+    assert not any(t.is_alive() for t in threads), "worker threads outlived the abandoned prefetcher"

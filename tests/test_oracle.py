@@ -218,3 +218,56 @@ def test_tensorflow_published_constants_for_clip_round_and_l2():
     assert float(cost) == 7.0
     (grad,) = torch.autograd.grad(cost, [p])
     assert grad.tolist() == [1.0, 0.0, 3.0, 2.0]
+
+
+def test_layer_norm_reproduces_tensorflow_layers_test():
+    """tf.contrib.layers.layer_norm as TensorFlow 1.x's own test states it (tensorflow/contrib/layers/python/layers/
+    layers_test.py, LayerNormTest.doOutputTest -- testOutput2DInput runs it on shape (10, 300)): for inputs
+    randn * sigma + mu with mu in (0, 1e2), sigma in (1, 0.1), gamma = 1, beta = 0 (the variables' own initialisers),
+    normalising over axis 1, the output must have mean 0 and variance 1 per row, and equal
+        gamma * (x - mean) / sqrt(1e-12 + var) + beta        -- BIASED variance, epsilon 1e-12 inside the root
+    to the test's tolerance (1e-5 at these shapes; the TensorFlow source is not in this image -- the set-up is quoted from
+    memory of it, the numbers follow from the formula).  That is the function LayerNormBasicLSTMCell._norm calls (graphnn.py:168-170 through
+    tf.contrib.rnn) -- the epsilon and the biased variance are what the HIP kernels' ln_gate restates (csrc/mfma_tile.h)."""
+    rng = np.random.RandomState(0)
+    for mu in (0.0, 1e2):
+        for sigma in (1.0, 0.1):
+            x = rng.randn(10, 300) * sigma + mu
+            want = (x - x.mean(1, keepdims=True)) / np.sqrt(1e-12 + x.var(1, keepdims=True))
+            got_t = TO.layer_norm(torch.tensor(x), torch.ones(300, dtype=torch.float64), torch.zeros(300, dtype=torch.float64)).numpy()
+            got_n = NO.layer_norm(x, np.ones(300), np.zeros(300))
+            for got in (got_t, got_n):
+                assert np.abs(got.mean(1)).max() < 1e-5 and np.abs(got.var(1) - 1.0).max() < 1e-5
+                assert np.abs(got - want).max() < 1e-5
+    # a constant row: variance 0, and the 1e-12 INSIDE the root decides -- 0 * 1e6 = 0, not NaN (TF: rsqrt(var + eps))
+    flat = np.full((2, 8), 3.0)
+    assert np.array_equal(TO.layer_norm(torch.tensor(flat), torch.ones(8, dtype=torch.float64), torch.zeros(8, dtype=torch.float64)).numpy(),
+                          np.zeros((2, 8)))
+
+
+def test_adam_reproduces_tensorflow_adam_test_basic():
+    """tf.train.AdamOptimizer as TensorFlow 1.x's own test states it (tensorflow/python/training/adam_test.py,
+    AdamOptimizerTest.testBasic): var0 = [1, 2], var1 = [3, 4], CONSTANT gradients g0 = [0.1, 0.1], g1 = [0.01, 0.01],
+    default hyper-parameters (lr 1e-3, beta1 0.9, beta2 0.999, epsilon 1e-8), three steps, expected values from the test's
+    own adam_update_numpy:  lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t),  m, v exponential averages,
+    p -= lr_t * m / (sqrt(v) + eps)  -- epsilon OUTSIDE the root and un-corrected ("epsilon hat").  Written out here
+    independently of oracle.adam_step (for a constant gradient m_t = (1 - beta1^t) g and v_t = (1 - beta2^t) g^2 in closed
+    form; the TensorFlow source is not in this image, the set-up is quoted from memory of it).  The reference's step
+    (model.py:160-167) uses lr = 2e-5; the rule is the same."""
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    p = {"var0": np.array([1.0, 2.0]), "var1": np.array([3.0, 4.0])}
+    g = {"var0": np.array([0.1, 0.1]), "var1": np.array([0.01, 0.01])}
+    m = {k: np.zeros(2) for k in p}
+    v = {k: np.zeros(2) for k in p}
+    want = {k: a.copy() for k, a in p.items()}
+    for t in range(1, 4):
+        p, m, v = TO.adam_step(p, g, m, v, t, lr=lr)
+        for k in want:       # the closed form of adam_update_numpy under a constant gradient
+            lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+            want[k] = want[k] - lr_t * ((1 - b1 ** t) * g[k]) / (np.sqrt((1 - b2 ** t) * g[k] ** 2) + eps)
+            assert np.allclose(p[k], want[k], rtol=0, atol=1e-15), (t, k)
+            assert np.allclose(m[k], (1 - b1 ** t) * g[k], atol=1e-17) and np.allclose(v[k], (1 - b2 ** t) * g[k] ** 2, atol=1e-19)
+    # three steps of ~lr each: the numbers the TF test arrives at (to the 1e-6 of its assertAllCloseAccordingToType)
+    assert np.allclose(p["var0"], [0.997, 1.997], atol=1e-6) and np.allclose(p["var1"], [2.997, 3.997], atol=1e-6)
+    # and the first step is NOT lr * g: Adam's first move is lr * sign(g) (up to epsilon) whatever the gradient's size
+    assert abs((1.0 - 0.997) / 3 - lr) < 1e-7

@@ -20,8 +20,11 @@ for name in os.environ.get("ANCHORS", "c2,c1").split(","):
             ref = z["sample:" + k] - 1e-10 * np.asarray(params[k], dtype=np.float64).reshape(-1)[idx]
             got = np.asarray(g[k], dtype=np.float64).reshape(-1)[idx]
             scale = max(float(z["absmax:" + k]), 1e-3 * gscale)
-            rows.append((float(np.abs(got - ref).max()) / scale, float(z["err32:" + k]) / scale, float(z["absmax:" + k]) / gscale, k))
+            rows.append((float(np.abs(got - ref).max()) / scale, float(z["err32:" + k]) / scale,
+                         float(z["ulp_spread:" + k]) / scale if "ulp_spread:" + k in z.files else float("nan"), k))
         rows.sort(reverse=True)
         print("==", name, gemm, "T", T)
-        for e, e32, rel, k in rows[:int(os.environ.get("TOP", "12"))]:
-            print("  err %.2e  fp32-restatement %.2e  ratio %.1f  |g|max/global %.1e  %s" % (e, e32, e / max(e32, 1e-30), rel, k))
+        for e, e32, sp, k in rows[:int(os.environ.get("TOP", "12"))]:
+            print("  err %.2e  fp32-restatement %.2e  one-ulp spread %.2e  err / max(2 e32, 2 spread, 1e-5) = %.2f  %s"
+                  % (e, e32, sp, e / max(2 * e32, 2 * sp, 1e-5), k))
+        print("  worst err / bar over all variables: %.2f" % max(e / max(2 * e32, 2 * sp, 1e-5) for e, e32, sp, _ in rows))

@@ -58,142 +58,6 @@ __device__ __forceinline__ void dense_layer_h2_np(f32x4 (&out)[NP][4], const f32
         }
 }
 
-struct MlpBwdRcTable {
-    tspgnn_mlp_bwd_rc_task task;
-};
-
-template <int L>
-__global__ __launch_bounds__(1024) void mlp_bwd_rc_kernel(const tspgnn_mlp_bwd_rc_task tk) {
-    constexpr int D = 64;
-    constexpr int LAYER_BYTES = 2 * D * D * 2 + D * 4;   // forward block: two fp16 pieces + the bias (2^s b)
-    constexpr int WT_BYTES = 2 * D * D * 2;
-    constexpr int WBYTES = (L - 1) * LAYER_BYTES + L * WT_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[WBYTES + 16];
-    unsigned char* lds_f = lds;
-    unsigned char* lds_t = lds + (L - 1) * LAYER_BYTES;
-    int* ticket = reinterpret_cast<int*>(lds + WBYTES);
-    const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4;
-
-    const float* __restrict__ X = tk.X;
-    const float* __restrict__ Yout = tk.Yout;
-    const float* __restrict__ dY = tk.dY;
-    const int2* __restrict__ uv = reinterpret_cast<const int2*>(tk.uv);
-    float* __restrict__ dX = tk.dX;
-    float* __restrict__ acts = tk.acts;
-    float* __restrict__ dpre = tk.dpre;
-    const int rows = tk.rows;
-    const unsigned relu_mask = tk.relu_mask;
-    const int tiles_total = (rows + 15) / 16;
-
-    if (L > 1) h2_copy_to_lds(lds_f, tk.wb, (L - 1) * LAYER_BYTES, tid, blockDim.x);
-    h2_copy_to_lds(lds_t, tk.wt, L * WT_BYTES, tid, blockDim.x);
-    const int t_beg = (int)((long long)tiles_total * blockIdx.x / gridDim.x);
-    const int t_end = (int)((long long)tiles_total * (blockIdx.x + 1) / gridDim.x);
-    if (tid == 0) *ticket = t_beg;
-    h2_stage_wait();
-    __syncthreads();
-
-    for (;;) {
-        int tile = 0;
-        if (lane == 0) tile = atomicAdd(ticket, 1);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= t_end) break;
-        const int row = tile * 16 + rl;
-        const bool valid = row < rows;
-        const unsigned rc = (unsigned)(valid ? row : rows - 1);
-        const size_t rbase = (size_t)rc * D + g * 4;
-        f32x4 a[L][1][4];     // a[l] = input of layer l (a[0] = the chain's input rows)
-        f32x4 gr[1][4];       // the gradient travelling down the chain
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a[0][0][t] = ld4(X + rbase + t * 16);
-        if (uv != nullptr) {   // the adjoint of the V<-E row-sum, formed on the fly
-            const int2 ends = uv[rc];
-            const float* pu = dY + (size_t)ends.x * D + g * 4;
-            const float* pv = dY + (size_t)ends.y * D + g * 4;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) gr[0][t] = ld4(pu + t * 16) + ld4(pv + t * 16);
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) gr[0][t] = ld4(dY + rbase + t * 16);
-        }
-        if ((relu_mask >> (L - 1)) & 1u) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f32x4 y = ld4(Yout + rbase + t * 16);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gr[0][t][r] = y[r] > 0.f ? gr[0][t][r] : 0.f;
-            }
-        }
-        // ---- forward again: a_1 .. a_{L-1}, handed to the weight-gradient reduction
-#pragma unroll
-        for (int l = 0; l + 1 < L; ++l) {
-            const _Float16* wf = reinterpret_cast<const _Float16*>(lds_f + l * LAYER_BYTES);
-            const float* bf = reinterpret_cast<const float*>(lds_f + l * LAYER_BYTES + 2 * D * D * 2);
-            dense_layer_h2_np<1>(a[l + 1], a[l], wf, wf + D * D, bf, (relu_mask >> l) & 1u, g, rl);
-            if (acts != nullptr && valid) {
-                float* dst = acts + (size_t)l * tk.acts_stride + rbase;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) st4(dst + t * 16, a[l + 1][0][t]);
-            }
-        }
-        // ---- backward: gr = dpre_l on entry of layer l
-#pragma unroll
-        for (int l = L - 1; l >= 0; --l) {
-            if (dpre != nullptr && valid) {
-                float* dst = dpre + (size_t)l * tk.dpre_stride + rbase;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) st4(dst + t * 16, gr[0][t]);
-            }
-            // G_l = dpre_l W_l^T (packed 2^s W_l^T): the row normalised to [0.5, 1), scaled second piece apart
-            const _Float16* wt = reinterpret_cast<const _Float16*>(lds_t + l * WT_BYTES);
-            f32x4 out[1][4], side[1][4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) out[0][t] = side[0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            float m = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) m = fmaxf(m, __builtin_fabsf(gr[0][t][r]));
-            m = max_over_lane_groups16_swap(m);
-            const int e = h2_row_exponent(m);
-            const float up = __builtin_ldexpf(1.0f, -e), down = __builtin_ldexpf(kH2InvScale, e);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                f16x8 bh[1], bm[1];
-                float xv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xv[j] = gr[0][2 * kb + (j >> 2)][j & 3] * up;
-                split2s(xv, bh[0], bm[0]);
-                kblock_h2_side_multi<4, 1>(out, side, wt, wt + D * D, kb, g, rl, bh, bm);
-            }
-            const float fold = 1.0f / 2048.0f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = fmaf(side[0][t][r], fold, out[0][t][r]) * down;
-                    if (l > 0 && ((relu_mask >> (l - 1)) & 1u)) v = a[l][0][t][r] > 0.f ? v : 0.f;
-                    gr[0][t][r] = v;
-                }
-        }
-        if (dX != nullptr && valid) {
-            float* p = dX + rbase;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) st4(p + t * 16, tk.accumulate_dx ? ld4(p + t * 16) + gr[0][t] : gr[0][t]);
-        }
-    }
-}
-
-template <int L>
-static int launch_mlp_bwd_rc(const tspgnn_mlp_bwd_rc_task& tk, hipStream_t st) {
-    const long long tiles = ((long long)tk.rows + 15) / 16;
-    int grid = n_cus();
-    const long long max_grid = (tiles + 15) / 16;
-    if (grid > max_grid) grid = (int)max_grid;
-    mlp_bwd_rc_kernel<L><<<grid, 1024, 0, st>>>(tk);
-    return launched("tspgnn_mlp_bwd_rc_h2");
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // The TAPED backward (dense_bwd.hip's mlp_bwd_kernel: masks from the saved activations, dpre written for the weight-gradient
 // reduction) with its data gradient on the fp16 matrix cores instead of 256 (d = 64; 1024 at d = 128) v_mfma_f32_16x16x4_f32
@@ -594,18 +458,14 @@ extern "C" int tspgnn_mlp_bwd_rc_h2(const tspgnn_mlp_bwd_rc_task* task, int d, v
     TSPGNN_REQUIRE(t.Yout || !((t.relu_mask >> (t.n_layers - 1)) & 1u), "mlp_bwd_rc_h2: a relu on the last layer needs Yout");
     TSPGNN_REQUIRE(t.acts_stride >= 0 && t.dpre_stride >= 0, "mlp_bwd_rc_h2: negative stride");
     hipStream_t st = as_stream(stream);
-    if (t.partial != nullptr) {   // weight gradients formed in the launch
-        TSPGNN_REQUIRE(!t.acts && !t.dpre, "mlp_bwd_rc_h2: partial excludes acts / dpre");
-        switch (t.n_layers) {
-            case 1: return launch_mlp_bwd_rcw<1>(t, st);
-            case 2: return launch_mlp_bwd_rcw<2>(t, st);
-            default: return launch_mlp_bwd_rcw<3>(t, st);
-        }
-    }
+    // (round 6: the form that handed the recomputed activations and pre-activation gradients to tspgnn_wgrad was removed --
+    // as byte-bound as the tape it replaced, DESIGN_HISTORY round 5; what stays forms the weight gradients in the launch)
+    TSPGNN_REQUIRE(t.partial != nullptr && !t.acts && !t.dpre,
+                   "mlp_bwd_rc_h2: weight gradients are formed in the launch (partial != NULL; acts / dpre must be NULL)");
     switch (t.n_layers) {
-        case 1: return launch_mlp_bwd_rc<1>(t, st);
-        case 2: return launch_mlp_bwd_rc<2>(t, st);
-        default: return launch_mlp_bwd_rc<3>(t, st);
+        case 1: return launch_mlp_bwd_rcw<1>(t, st);
+        case 2: return launch_mlp_bwd_rcw<2>(t, st);
+        default: return launch_mlp_bwd_rcw<3>(t, st);
     }
 }
 

@@ -760,13 +760,12 @@ class GraphNN(object):
         # (tspgnn_mlp_bwd_multi_h2) instead of the fp32 matrix instruction (TSPGNN_MLP_BWD_H2=0: A/B)
         self.mlp_backward_h2 = os.environ.get("TSPGNN_MLP_BWD_H2", "1") != "0"
         # training (f16x2, pushed message MLPs of width 64), OPT-IN (TSPGNN_RECOMPUTE=1): the backward recomputes the MLP's
-        # hidden activations (tspgnn_mlp_bwd_rc_h2) so that the forward tapes only the messages and runs the message MLP
-        # inside the cell launch as the inference plan does; with recompute_weight_gradients (TSPGNN_RECOMPUTE_DW, default on
-        # within the mode) the MLP's weight gradients are formed in that launch too.  Both forms are parity-green and
-        # deterministic; off by default because they do not pay at C2 (round 5, one box: taped 10.98-11.19 ms per training
-        # step, recomputed 11.23-11.33 ms, with the weight gradients in the launch 11.7 vs 11.3 ms -- DESIGN_HISTORY)
+        # hidden activations and forms the MLP's weight gradients in the same launch (tspgnn_mlp_bwd_rc_h2), so that the
+        # forward tapes only the messages and runs the message MLP inside the cell launch as the inference plan does.
+        # Parity-green and deterministic; off by default because it does not pay at C2 (round 5, one box: taped 10.98-11.19 ms
+        # per training step, this form 11.6-11.7 ms).  The variant that handed the recomputed activations to tspgnn_wgrad
+        # instead (11.23-11.33 ms) was removed in round 6 -- DESIGN_HISTORY
         self.recompute_messages = os.environ.get("TSPGNN_RECOMPUTE", "0") == "1"
-        self.recompute_weight_gradients = os.environ.get("TSPGNN_RECOMPUTE_DW", "1") != "0"
         # GEMM arithmetic of the inference forward, all fp32-class in accuracy: "f16x2" = fp16 matrix cores on
         # two-piece splits of the fp32 operands (csrc/dense_h2.hip, the default); "bf16x3" = bf16 matrix cores on
         # exact three-piece splits (csrc/dense_x3.hip); "f32" = fp32 MFMA.  TSPGNN_GEMM in the environment selects
@@ -1602,15 +1601,23 @@ class GraphNN(object):
         device = next(iter(initial_embeddings.values())).device
         f32 = dict(dtype=torch.float32, device=device)
         stored = dict(dtype=self.float_dtype, device=device)   # what the tape keeps of h, messages, activations
-        mats = {}
+        mats, dense = {}, {}
         for v in self.var:
             for u in self.loop[v]:
-                if "fun" in u or "var" not in u:
-                    raise NotImplementedError("training supports loop entries made of var / msg / mat only")
+                if ("fun" in u or "var" not in u) and bf16:
+                    raise NotImplementedError("bf16-storage training supports loop entries made of var / msg / mat only")
+                if "var" not in u:
+                    # graphnn.py:163-165: the matrix itself joins the cell input -- a constant of the step (a placeholder:
+                    # tf.gradients stops there); its columns only meet the cell kernel's rows
+                    if u["mat"] not in dense:
+                        a = adjacency_matrices[u["mat"]]
+                        a = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+                        dense[u["mat"]] = a.to(device=device, dtype=torch.float32).contiguous()
+                    continue
                 if "mat" in u and u["mat"] not in mats:
                     mats[u["mat"]] = DeviceAdjacency.wrap(adjacency_matrices[u["mat"]], device)
         tape = Tape()
-        tape.T, tape.mats = T, mats
+        tape.T, tape.mats, tape.dense = T, mats, dense
         tape.folded = {v: self._folded(v, mats) for v in self.var}
         n = {v: initial_embeddings[v].shape[0] for v in self.var}
         tape.H = {v: torch.empty((T + 1, n[v], d), **stored) for v, d in self.var.items()}
@@ -1629,9 +1636,7 @@ class GraphNN(object):
                                                                                     # inference mode does)
             tape.C[v][0].zero_()
             for i, u in enumerate(self.loop[v]):
-                if "msg" in u:
-                    mlp = self._msg_MLPs[u["msg"]]
-                    src = u["var"]
+                if "msg" in u and "var" in u:
                     tape.acts[(v, i)] = None     # allocated below, once the arithmetic (hence the tape's form) is known
         tape.fused = False
         tape.rc = {}
@@ -1702,7 +1707,15 @@ class GraphNN(object):
             msg_out, mlp_tasks = {}, {}
             for v in self.var:
                 for i, u in enumerate(self.loop[v]):
+                    if "var" not in u:          # an appended matrix: joins the cell input in aggregate()
+                        msg_out[(v, i)] = tape.dense[u["mat"]]
+                        continue
                     y = tape.H[u["var"]][t]
+                    if "fun" in u:              # graphnn.py:149-151 (the backward differentiates it again: _fun_vjp)
+                        y = u["fun"](y)
+                        if not torch.is_tensor(y) or y.shape != tape.H[u["var"]][t].shape:
+                            raise ValueError("loop entry 'fun' must map [rows, d] to a tensor of the same shape")
+                        y = y.to(torch.float32).contiguous()
                     if "msg" in u:
                         mlp = self._msg_MLPs[u["msg"]]
                         acts = tape.acts[(v, i)]
@@ -1748,10 +1761,13 @@ class GraphNN(object):
                 inputs = []
                 for i, u in enumerate(self.loop[v]):
                     y = msg_out[(v, i)]
-                    if "mat" in u:
+                    if "var" not in u:
+                        if single:
+                            tape.X[v][t].copy_(y)
+                    elif "mat" in u:
                         y = mats[u["mat"]].matmul(y, transpose=u.get("transpose?", False),
                                                   out=tape.X[v][t] if single else None)
-                    elif single and "msg" not in u:
+                    elif single and ("msg" not in u or "fun" in u):
                         tape.X[v][t].copy_(y)
                     inputs.append(y)
                 if not single:
@@ -1904,6 +1920,23 @@ class GraphNN(object):
                 return self._backward(tape, dstates)
         return self._backward(tape, dstates)
 
+    @staticmethod
+    def _fun_vjp(fun, h, g_out):
+        """g_out (gradient w.r.t. fun(h)) pulled back to h.  A loop entry's 'fun' is the caller's own code (graphnn.py:149-151
+        applies it to the states inside the TF graph, and tf.gradients differentiates it there): either it brings its
+        vector-Jacobian product along -- ``fun.vjp(h, g_out) -> g_in`` -- or it is made of differentiable torch operations
+        and is differentiated the same way TF would, by the framework's autograd on this one call."""
+        vjp = getattr(fun, "vjp", None)
+        if vjp is not None:
+            return vjp(h, g_out).to(torch.float32)
+        with torch.enable_grad():
+            x = h.detach().to(torch.float32).requires_grad_(True)
+            y = fun(x)
+            if not y.requires_grad:       # a function that ignores its argument (or detaches): zero gradient
+                return torch.zeros_like(x)
+            (g_in,) = torch.autograd.grad(y, x, grad_outputs=g_out.to(y.dtype))
+        return g_in
+
     def _backward(self, tape, dstates):
         T, mats = tape.T, tape.mats
         device = self.store.theta.device
@@ -1921,11 +1954,11 @@ class GraphNN(object):
         # the pre-activations of the chunk (4d + the MLP layers' d floats per row and step) fit the budget -- the C2
         # case, ~6 GB -- else the largest chunk that does (a C5 shard: 84 GB for all 64 steps)
         pushed = getattr(tape, "pushed", None) or {v: False for v in self.var}
-        rc = getattr(tape, "rc", None) or {}      # entries whose backward recomputes the hidden activations
-        rc_dw = self.recompute_weight_gradients   # ... and forms the weight gradients in the same launch (no chunk buffers)
+        rc = getattr(tape, "rc", None) or {}      # entries whose backward recomputes the hidden activations and forms the
+                                                  # weight gradients in the same launch (no chunk buffers)
         per_step = sum(n[v] * 4 * d * 4 for v, d in self.var.items())
         per_step += sum(self._msg_MLPs[self.loop[v][i]["msg"]].n_square * n[self.loop[v][i]["var"]]
-                        * self.var[self.loop[v][i]["var"]] * 4 * ((0 if rc_dw else 2) if rc.get((v, i)) else 1)
+                        * self.var[self.loop[v][i]["var"]] * 4 * (0 if rc.get((v, i)) else 1)
                         for (v, i) in tape.acts)
         per_step += sum(tape.X[v].shape[1] * 4 * self.var[v] * 4 for v in self.var if folded[v] is not None)   # DZX
         per_step += sum(n[v] * 4 for v in self.var if (getattr(tape, "pushed", None) or {}).get(v))          # degrees
@@ -1958,16 +1991,14 @@ class GraphNN(object):
             guard[1:2].zero_()
             store.h2_packs_pending = 0
             mlp_h2_native = self._mlp_h2_native_ok = bits < store.H2_WEIGHT_LIMIT_BITS
-        DPRE, RCA, RCP = {}, {}, {}
+        DPRE, RCP = {}, {}
         for (v, i), acts in tape.acts.items():
             u = self.loop[v][i]
             mlp = self._msg_MLPs[u["msg"]]
-            if rc.get((v, i)) and rc_dw:
+            if rc.get((v, i)):
                 RCP[(v, i)] = mlp.backward_rc_partial(mlp.n_square - 1)   # workgroup partials of {dW, db}, all T steps
                 continue
             DPRE[(v, i)] = torch.empty((mlp.n_square - (1 if pushed[v] else 0), CH, n[u["var"]], self.var[u["var"]]), **f32)
-            if rc.get((v, i)):   # the recomputed hidden activations a_1 .. a_{L-1} of the chunk's steps
-                RCA[(v, i)] = torch.empty((max(mlp.n_square - 2, 1), CH, n[u["var"]], self.var[u["var"]]), **f32)
         # LayerNorm-gradient partials of all T steps accumulate here (zeroed); one fold per cell after the loop
         ws = {v: _lib.workspace("tspgnn_lnlstm_bwd_workspace_floats", d, device=device).zero_() for v, d in self.var.items()}
         DZX = {v: torch.empty((CH, tape.X[v].shape[1], 4 * self.var[v]), **f32) for v in self.var if folded[v] is not None}
@@ -2001,10 +2032,11 @@ class GraphNN(object):
                 mlp = self._msg_MLPs[u["msg"]]
                 src, dsrc = u["var"], self.var[u["var"]]
                 layers = dpre.shape[0]      # (a pushed entry's last layer has its gradient formed on the receiving side)
-                if rc.get((v, i)):
-                    inputs = [tape.h_steps(src, t0, t1)] + [RCA[(v, i)][l, :steps].reshape(-1, dsrc) for l in range(layers - 1)]
-                else:
-                    inputs = [tape.h_steps(src, t0, t1)] + [tape.acts_steps((v, i), l, t0, t1) for l in range(layers - 1)]
+                first = tape.h_steps(src, t0, t1)
+                if "fun" in u:      # the MLP's input rows are fun(h), step by step as the forward formed them
+                    with torch.no_grad():
+                        first = torch.cat([u["fun"](tape.h(src, t)).to(torch.float32) for t in range(t0, t1)], dim=0).contiguous()
+                inputs = [first] + [tape.acts_steps((v, i), l, t0, t1) for l in range(layers - 1)]
                 mlp.backward_weights(inputs, [dpre[l, :steps].reshape(-1, dsrc) for l in range(layers)], steps * n[src],
                                      n_layers=layers)
 
@@ -2065,10 +2097,29 @@ class GraphNN(object):
                 off = 0
                 for i, u in enumerate(self.loop[v]):
                     w = self._update_width(u)
+                    if "var" not in u:      # an appended matrix is a constant of the graph: its columns' gradient ends here
+                        off += w
+                        continue
                     dy = dX[v] if len(self.loop[v]) == 1 else dX[v][:, off:off + w].contiguous()
                     off += w
                     src = u["var"]
                     gather_uv = None
+                    if "fun" in u:
+                        # graphnn.py:149-151: y = fun(h) ahead of the message MLP.  The gradient w.r.t. fun's OUTPUT is formed
+                        # apart (adjoint product, the MLP's backward on its own, never fused with another writer of dh), then
+                        # pulled back through fun (_fun_vjp) and added to dh of the source
+                        if "mat" in u:
+                            dy = mats[u["mat"]].matmul(dy, transpose=not u.get("transpose?", False))
+                        if "msg" in u:
+                            mlp = self._msg_MLPs[u["msg"]]
+                            (acts_t, acts_stride), dpre = tape.acts_at((v, i), t), DPRE[(v, i)]
+                            g_out = torch.empty((n[src], self.var[src]), **f32)
+                            mlp.backward_data(dy, acts_t, acts_stride, None, dpre[:, k], dpre.stride(0), g_out, accumulate=False,
+                                              h2=False)
+                        else:
+                            g_out = dy
+                        ndH[src].add_(self._fun_vjp(u["fun"], tape.h(src, t), g_out))
+                        continue
                     if "mat" in u and folded[v] is None:   # adjoint of mat (x) y is mat^T (x) dy and vice versa
                         adj = mats[u["mat"]]
                         if u.get("transpose?", False) and adj.uv is not None and "msg" in u and src not in targets \
@@ -2083,13 +2134,8 @@ class GraphNN(object):
                             raise NotImplementedError("recomputed message MLP: a second writer of the source's gradient")
                         h_src = tape.h(src, t)
                         keep.append(h_src)
-                        if rc_dw:
-                            task = mlp.backward_rc_task(mlp.n_square - 1, h_src, tape.acts[(v, i)][0, t], dy, ndH[src], True,
-                                                        gather_uv=gather_uv, partial=RCP[(v, i)])
-                        else:
-                            dpre, rca = DPRE[(v, i)], RCA[(v, i)]
-                            task = mlp.backward_rc_task(mlp.n_square - 1, h_src, tape.acts[(v, i)][0, t], dy, ndH[src], True,
-                                                        rca[:, k], rca.stride(0), dpre[:, k], dpre.stride(0), gather_uv=gather_uv)
+                        task = mlp.backward_rc_task(mlp.n_square - 1, h_src, tape.acts[(v, i)][0, t], dy, ndH[src], True,
+                                                    gather_uv=gather_uv, partial=RCP[(v, i)])
                         rc_tasks.append((mlp, task, dy))
                         targets.append(src)
                         continue

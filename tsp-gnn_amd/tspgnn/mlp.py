@@ -211,20 +211,17 @@ class Mlp(object):
         kind, d, n_sq, head = self._plan
         return kind == "square" and d == 64 and 1 <= n_layers <= min(3, n_sq) and len(self._chunks()) == 1
 
-    def backward_rc_task(self, n_layers, x, y_out, dY, dX, accumulate, acts=None, acts_stride=0, dpre=None, dpre_stride=0,
-                         gather_uv=None, partial=None):
+    def backward_rc_task(self, n_layers, x, y_out, dY, dX, accumulate, gather_uv=None, partial=None):
         """An _lib.MlpBwdRcTask for the first ``n_layers`` square layers: the data gradient from the chain's input ``x``,
-        its output ``y_out`` and the incoming gradient -- the hidden activations are recomputed (csrc/mlp_bwd_rc.hip).
-        ``partial`` (backward_rc_partial()): the weight gradients are formed in the same launch and accumulate there over
-        the launches of a backward pass (folded by backward_rc_finish()); else the recomputed activations and the
-        pre-activation gradients leave through ``acts`` / ``dpre`` for backward_weights()."""
+        its output ``y_out`` and the incoming gradient -- the hidden activations are recomputed (csrc/mlp_bwd_rc.hip) and
+        the weight gradients formed in the same launch: they accumulate in ``partial`` (backward_rc_partial()) over the
+        launches of a backward pass and are folded by backward_rc_finish()."""
         kind, d, n_sq, head = self._plan
         return _lib.MlpBwdRcTask(_lib.ptr(x), _lib.ptr(self.wb_packed_split("h2", 0, n_layers - 1, d)),
                                  _lib.ptr(self.wt_packed_h2(0, n_layers - 1, d)), _lib.ptr(y_out), _lib.ptr(dY),
                                  _lib.ptr(gather_uv), _lib.ptr(dX), 1 if accumulate else 0,
                                  dY.shape[0] if gather_uv is None else gather_uv.shape[0], n_layers,
-                                 self.relu_mask(0, n_layers), _lib.ptr(acts), acts_stride, _lib.ptr(dpre), dpre_stride,
-                                 _lib.ptr(partial))
+                                 self.relu_mask(0, n_layers), None, 0, None, 0, _lib.ptr(partial))
 
     def backward_rc_partial(self, n_layers):
         kind, d, n_sq, head = self._plan

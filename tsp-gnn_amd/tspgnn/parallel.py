@@ -11,6 +11,7 @@
   allocator does not recycle them under kernels that still read them.
 """
 import threading
+import weakref
 
 import numpy as np
 import torch
@@ -42,14 +43,11 @@ def shard_instances(instances, world_size, pair=True):
     return out
 
 
-class BatchPrefetcher(object):
-    """Iterates device-resident batches: ``for dev_batch in BatchPrefetcher(sess, batch_iter, time_steps)``.
-
-    ``batch_iter`` yields create_batch 6-tuples (host) -- or, with ``pack=``, whatever ``pack(item)`` turns into one (e.g.
-    lists of instances with ``pack=lambda inst: InstanceLoader.create_batch(inst, dev)``: the packing then runs on the
-    workers, in parallel, instead of inside the iterator).  While the caller runs step i on the main stream, ``workers``
-    threads pack the next batches (CSR build included; the native packer releases the GIL) and enqueue their uploads on
-    side streams; batches come out in the iterator's order."""
+class _PrefetchState(object):
+    """Everything the worker threads of a BatchPrefetcher touch.  The threads hold THIS object, never the prefetcher: an
+    abandoned prefetcher is then collected like any other object, and its finaliser (weakref.finalize -> close()) releases
+    the workers -- a bound method of the prefetcher as the thread target kept it alive for the life of the process, its
+    uploaded batches with it."""
 
     def __init__(self, sess, batch_iter, time_steps, depth=2, pinned=False, workers=1, pack=None):
         """``pinned``: stage uploads through pinned host memory (non-blocking copies).  Off by default: measured on
@@ -122,30 +120,14 @@ class BatchPrefetcher(object):
 
     def close(self):
         """Stop early: the workers end after the batch they are packing, batches already uploaded are dropped (their GPU
-        memory returns to the allocator).  Called by ``__del__`` and on leaving a ``with`` block; a consumer that abandons
-        the iterator without it would leave the workers blocked on a full queue for the life of the process."""
+        memory returns to the allocator)."""
         with self._lock:
             if self._exhausted_at is None or self._exhausted_at > self._next_out:
                 self._exhausted_at = self._next_out
             self._ready.clear()
             self._lock.notify_all()
 
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        self.close()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-    def __iter__(self):
-        return self
-
-    def __next__(self):
+    def next_batch(self):
         with self._lock:
             while True:
                 if self._next_out in self._ready:
@@ -170,6 +152,41 @@ class BatchPrefetcher(object):
             for t in b.tensors():
                 t.record_stream(cur)
         return b
+
+
+class BatchPrefetcher(object):
+    """Iterates device-resident batches: ``for dev_batch in BatchPrefetcher(sess, batch_iter, time_steps)``.
+
+    ``batch_iter`` yields create_batch 6-tuples (host) -- or, with ``pack=``, whatever ``pack(item)`` turns into one (e.g.
+    lists of instances with ``pack=lambda inst: InstanceLoader.create_batch(inst, dev)``: the packing then runs on the
+    workers, in parallel, instead of inside the iterator).  While the caller runs step i on the main stream, ``workers``
+    threads pack the next batches (CSR build included; the native packer releases the GIL) and enqueue their uploads on
+    side streams; batches come out in the iterator's order."""
+
+    def __init__(self, sess, batch_iter, time_steps, depth=2, pinned=False, workers=1, pack=None):
+        """See _PrefetchState.__init__ for the arguments (``pinned``, ``workers``, ``depth``, ``pack``)."""
+        self._state = _PrefetchState(sess, batch_iter, time_steps, depth=depth, pinned=pinned, workers=workers, pack=pack)
+        self.workers, self.depth = self._state.workers, self._state.depth
+        # runs when this handle is collected (or at interpreter exit): the workers hold only the state object
+        self._finalizer = weakref.finalize(self, self._state.close)
+
+    def close(self):
+        """Stop early: the workers end after the batch they are packing, batches already uploaded are dropped (their GPU
+        memory returns to the allocator).  Also runs on leaving a ``with`` block and when the prefetcher is garbage
+        collected -- an abandoned iterator does not leave workers blocked on a full queue."""
+        self._state.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return self._state.next_batch()
 
 
 def stage_layout(M, N, B, plan_ints):
