@@ -64,7 +64,7 @@ def dense_flops_per_step(N, M, d, folded=True):
     return mlp + M * 2 * d * 4 * d + N * 2 * 2 * d * 4 * d + N * 2 * d * 4 * d
 
 
-PROFILE_ROUNDS = ("r05", "r04", "r03")   # newest first: the rocprofv3 summaries bench.py quotes (profiles/<round>_<workload>_...)
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03")   # newest first: the rocprofv3 summaries bench.py quotes (profiles/<round>_<workload>_...)
 
 
 def csrc_fingerprint():

@@ -307,7 +307,10 @@ int tspgnn_mp_loop_h2(const tspgnn_mp_loop_args* args, int d, void* stream);
  *     (K[2d,4d] resident) and MESSAGE workgroups (message MLP + projection resident); h' crosses between them through `vh`.
  * Synchronisation is per group of consecutive instances through the three parity-split counters of tspgnn_mp_loop_h2
  * (message tiles arrived, vertex rows aggregated, vertex tiles projected) and a fourth (vertex tiles updated): the
- * ordering argument is the same.  `counters` = 4 * 32 * n_groups + 32 words here.
+ * ordering argument is the same.  `counters` = 4 * 32 * n_groups + 32 words here (the last 32: the placement check).
+ * The kernel's one dependence on WHERE workgroups run -- an L1-only invalidate before re-gathering projected messages, valid
+ * when a group's producers and consumers share an XCD's L2 -- is verified inside the launch and replaced by an agent-scope
+ * acquire when it does not hold.
  * `plan`: int32 -- grid headers of TSPGNN_RESIDENT_HDR_INTS, then items of TSPGNN_RESIDENT_ITEM_INTS (layout documented in
  * tspgnn/resident_plan.py and csrc/mp_resident_h2.hip).  `counters` as for tspgnn_mp_loop_h2, zeroed by the caller before
  * every launch.  `lds_words`: LDS words the plan's largest edge workgroup needs behind the weights (one per tile, and
@@ -336,6 +339,8 @@ typedef struct tspgnn_mp_resident_args {
     float* vagg[2];
     float* vh[2];                           /* [N,d] scratch: the vertex states h between the steps, by step parity */
     const int32_t* plan; unsigned* counters; int n_groups; int grid; int n_slots; int lds_words;
+    int n_active;                           /* workgroups of the plan with work (edge + cell + message) */
+    int flags;                              /* bit 0: take the placement-independent acquire (tests; see PLACEMENT in the kernel) */
     int M; int N; int T; int z_centered;
     unsigned* range_flag; unsigned* status;
     unsigned long long* trace;              /* optional (development), as tspgnn_mp_loop_args */

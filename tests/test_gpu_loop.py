@@ -109,3 +109,20 @@ def test_loop_replays_are_bit_identical_and_serve_fresh_batches(cuda_device):
     assert torch.equal(replay()["predictions"], want_b)
     assert not torch.equal(want_a, want_b)
     assert not sess.range_exceeded()
+
+
+def test_resident_loop_without_the_placement_assumption(cuda_device, kind, monkeypatch):
+    """tspgnn_mp_resident_h2 checks inside the launch that a group's workgroups share an XCD (the one thing its L1-only
+    invalidate leans on) and takes the agent-scope acquire when they do not; TSPGNN_RES_SAFE=1 raises the mismatch flag by
+    hand: the results must be the same bits either way."""
+    if kind != "resident":
+        pytest.skip("the placement check belongs to the memory-resident form")
+    t = tspgnn.synthetic_batch([40] * 48 + [17, 23, 31], seed=11)
+    params = P.init_params(64, seed=4, perturb=True)
+    fast = forward(params, t, 7, True)
+    monkeypatch.setenv("TSPGNN_RES_SAFE", "1")
+    safe = forward(params, t, 7, True)
+    steps = forward(params, t, 7, False)
+    assert fast[2] and safe[2]
+    assert_bit_equal(fast, steps)
+    assert_bit_equal(safe, steps)

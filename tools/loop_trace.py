@@ -43,7 +43,7 @@ e1.record()
 torch.cuda.synchronize()
 print("eager forward with trace: %.3f ms" % e0.elapsed_time(e1))
 tr = model["gnn"].loop_trace.cpu().numpy().astype(np.float64) * 0.01 / T     # us per step
-plan, G, grid = b.adj.loop_plan
+plan, G, grid = b.adj.loop_plan[:3]
 p = plan.cpu().numpy().reshape(grid, LP.WAVES, LP.DESC)
 print("\n".join(__doc__.split("\n")[2:]))
 for role, name in ((1, "edge"), (2, "vertex")):

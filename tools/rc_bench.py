@@ -35,13 +35,9 @@ Y = torch.empty((rows, d), device=dev)
 task = _lib.MlpTask(_lib.ptr(X), _lib.ptr(wb), _lib.ptr(Y), None, 0, rows, L, 7, None, None, None)
 _lib.call_multi("tspgnn_mlp_fwd_multi_h2", [task], d)
 part = torch.zeros(int(_lib.lib.tspgnn_mlp_bwd_rc_partial_floats(d, L)), device=dev)
-acts = torch.empty((L - 1, rows, d), device=dev)
-dpre = torch.empty((L, rows, d), device=dev)
 dX = torch.zeros((rows, d), device=dev)
 t = _lib.MlpBwdRcTask(_lib.ptr(X), _lib.ptr(wb), _lib.ptr(wt), _lib.ptr(Y), _lib.ptr(dYs), _lib.ptr(uvd), _lib.ptr(dX), 1, rows, L, 7,
-                      None, 0, None, 0, _lib.ptr(part)) if os.environ.get("RC_DW", "1") == "1" else \
-    _lib.MlpBwdRcTask(_lib.ptr(X), _lib.ptr(wb), _lib.ptr(wt), _lib.ptr(Y), _lib.ptr(dYs), _lib.ptr(uvd), _lib.ptr(dX), 1, rows, L, 7,
-                      _lib.ptr(acts), rows * d, _lib.ptr(dpre), rows * d, None)
+                      None, 0, None, 0, _lib.ptr(part))     # (weight gradients in the launch: the one form kept, round 6)
 tp = ctypes.cast(ctypes.pointer(t), ctypes.c_void_p)
 for _ in range(5):
     _lib.call("tspgnn_mlp_bwd_rc_h2", tp, d, None)

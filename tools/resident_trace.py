@@ -43,7 +43,7 @@ e1.record()
 torch.cuda.synchronize()
 print("eager forward with trace: %.3f ms" % e0.elapsed_time(e1))
 tr = model["gnn"].loop_trace.cpu().numpy().astype(np.float64) * 0.01 / T     # us per step
-plan, G, grid, kind, n_slots, lds_words = b.adj.loop_plan
+plan, G, grid, kind, n_slots, lds_words, n_active = b.adj.loop_plan
 assert kind == "resident"
 hdr = plan.cpu().numpy()[:grid * RP.HDR].reshape(grid, RP.HDR)
 print("\n".join(__doc__.split("\n")[2:]))

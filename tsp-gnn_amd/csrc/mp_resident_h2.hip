@@ -13,34 +13,42 @@
 //   * EDGE workgroups keep Kh and the message MLP's layers in LDS for the whole loop.  Work is handed out by ONE LDS ticket
 //     that runs through all steps: item k = item (k mod W) of step (k div W), W = the workgroup's items per step (plan).
 //     An item is a 16-row edge TILE (gather Zx[u] + Zx[v], h Kh on the matrix cores, gates, message MLP, message rows out:
-//     the body of lnlstm_mlp_fwd_h2_kernel, bit for bit) or a SHARE of the V<-E row-sum (a few vertex rows, the summation
-//     order of csr_rowsum_kernel).  Any wavefront takes any item: three wavefronts per SIMD cover each other's latency
-//     chains within a step AND across the step boundary.  A tile's states h, c live in slot arrays private to the launch
-//     ([slots * 16, d], blocked by tile, in place), stored write-through and loaded past the L1 (sc0 sc1): at C2 sizes
-//     they stay in the Infinity Cache.  A tile of step t waits for its own step t-1 (one LDS word per tile, set by whoever ran
-//     it) and for its group's projected messages Zx_t (device counter; the value last seen is cached in LDS per group, and the
-//     wavefront that saw it change invalidates the CU's L1 once -- the gathers of the other wavefronts keep their L1 reuse).
+//     the body of lnlstm_mlp_fwd_h2_kernel, bit for bit) or a SHARE of the V<-E row-sum (<= 8 vertex rows, the summation
+//     order of csr_rowsum_kernel; its edge lists wait in LDS, two rows' loads in flight at once).  Any wavefront takes any
+//     item: three wavefronts per SIMD cover each other's latency chains within a step AND across the step boundary; the
+//     next ticket is taken while the current item still computes.  A tile's states h, c live in slot arrays private to the
+//     launch ([slots * 16, d], blocked by tile, in place), stored write-through and loaded past the L1 (a plain load was
+//     measured to return a stale line at 256 instances).  A tile of step t waits for its own step t-1 (one LDS word per
+//     tile, set by whoever ran it) and for its group's projected messages Zx_t (device counter; the value last seen is
+//     cached in LDS per group, and the wavefront that saw it change invalidates the CU's L1 once -- the gathers of the other
+//     wavefronts keep their L1 reuse).  A finished tile is PUBLISHED (its LDS word, its group's message counter) behind the
+//     GEMM of the wavefront's next tile, where its stores have long drained -- not behind a wait of its own.
 //   * The items of a step are ordered BY CLASS (plan): the groups of an XCD are cut into two classes, and a workgroup's
 //     step is [row-sum shares A][tiles A][row-sum shares B][tiles B].  The vertex chain of a class -- row-sum, vertex cells,
-//     message MLP, projection: ~25 us that nothing of the same class can overlap, and one tile latency (~10 us) before it
-//     can start -- then has 1.5 step times to complete instead of one: the other class's tiles run meanwhile.
-//   * VERTEX workgroups (each serves ONE class) run the vertex cells in lock step through two LDS residencies per step,
-//     <= 2 tiles of 16 vertex rows per wavefront, states through memory -- the vertex branch of mp_loop_h2_kernel.
+//     message MLP, projection, and one tile latency before it can start -- then has 1.5 step times to complete instead
+//     of one: the other class's tiles run meanwhile (measured: one class 49 us per C2 step, two 42-44, three 47).
+//   * VERTEX workgroups come in two kinds, neither with a barrier or a second LDS residency inside the loop: CELL
+//     workgroups keep K[2d,4d] (128 KB) and run the vertex cells, MESSAGE workgroups keep the message MLP + the projection
+//     matrix (113 KB) and turn h' into the projected messages; h' crosses between them through the vertex states' parity
+//     buffers `vh` and a fourth counter per group.  (The lock-step form with both residencies in one workgroup -- mp_loop's --
+//     spent 15 of its 35 us per step in barriers and re-staging.)  Every vertex wavefront owns <= 2 tiles for the whole loop.
 //   * Synchronisation: the three parity-split monotone counters per group of mp_loop_h2.hip (message tiles arrived, vertex
-//     rows aggregated, vertex tiles projected), same thresholds, same ordering argument; hand-offs through
-//     loop_sync.h.  Deadlock freedom: an item of step t waits only for items of steps < t, every workgroup takes its items
-//     in ticket order, and all `grid` workgroups are resident (checked by the host against the occupancy the runtime
-//     reports) -- by induction on the step every wait ends.  Every wait is bounded all the same (status word).
+//     rows aggregated, vertex tiles projected) + one (vertex tiles updated); same thresholds, same ordering argument
+//     (tests/test_resident_plan.py replays the protocol under random schedules); hand-offs through loop_sync.h.
+//     Deadlock freedom: an item of step t waits only for items of steps < t, every workgroup takes its items in ticket
+//     order, and all `grid` workgroups are resident (the entry point asks the runtime's occupancy query) -- by induction
+//     on the step every wait ends.  Every wait is bounded all the same (status word).
 //
 // Plan (int32, tspgnn/resident_plan.py): grid headers of 8 ints
-//     [0] role 0 idle / 1 edge / 2 vertex   [1] first item   [2] items per step (edge: W; vertex: tiles)
+//     [0] role 0 idle / 1 edge / 2 vertex cells / 3 vertex messages   [1] first item   [2] items per step (edge: W; vertex: tiles)
 //     [3] first state slot (edge)           [4] first group touched (edge: base of the LDS cache of Zx counters)
-//     [5] tiles of the workgroup (edge: LDS words)
+//     [5] tiles of the workgroup (edge: LDS words)   [6] class (vertex)
 // then items of 8 ints
-//     edge tile:   [0] first row  [1] valid rows  [2] group  [3] local tile index >= 0  [4] vertex tiles of the group
-//     share:       [0] v0         [1] v1          [2] group  [3] -1                     [4] edge tiles of the group
-//                  [5] offset (ints) of the share's edge-list block in the workgroup's LDS words, or -1
-//     vertex tile: [0] first row  [1] valid rows  [2] group  [3] -2                     [4] vertex rows of the group
+//     edge tile:    [0] first row  [1] valid rows  [2] group  [3] local tile index >= 0  [4] vertex tiles of the group
+//     share:        [0] v0         [1] v1          [2] group  [3] -1                     [4] edge tiles of the group
+//                   [5] offset (ints) of the share's edge-list block in the workgroup's LDS words, or -1
+//     vertex tile:  [0] first row  [1] valid rows  [2] group  [3] -2                     [4] cells: vertex rows of the group;
+//                                                                                            messages: vertex tiles of the group
 #include "common.h"
 #include "h2_tile.h"
 #include "loop_sync.h"
@@ -127,6 +135,23 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
     float wit = 0.f;
     unsigned vmin = 0xffffffffu;
     if (role == 0 || n_items == 0) return;
+    // PLACEMENT.  The plan puts everything a group needs on workgroups of one residue b mod 8, and workgroup b runs on XCD
+    // b mod 8 (observed; nothing promises it).  The edge workgroups lean on that for ONE thing: before they gather this
+    // parity's projected messages again they invalidate the CU's L1 only (buffer_inv sc0) -- the producer's write-through
+    // stores are then visible because producer and consumer share an L2.  So the launch CHECKS it: every active workgroup
+    // registers its XCC id under its residue; two ids under one residue (or flags & 1, the tests' switch) raise `mismatch`,
+    // and the edge workgroups, which wait for all registrations before their first item, then take the agent-scope acquire
+    // (L2 included) instead -- slower, correct wherever the workgroups run.
+    unsigned* place = counters + (size_t)a.n_groups * 4 * 32;   // [0..7] XCC id + 1 of residue r, [8] registered, [9] mismatch
+    if (tid == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        id = (id & 0xfu) + 1u;
+        const unsigned old = atomicCAS(place + (blockIdx.x & 7), 0u, id);
+        if ((old != 0u && old != id) || (a.flags & 1)) atomicOr(place + 9, 1u);
+        __threadfence();
+        atomicAdd(place + 8, 1u);
+    }
     LoopTrace<TRACE> tr;
     tr.begin(a.trace + ((size_t)blockIdx.x * kResWaves + wave) * 16);
 
@@ -189,7 +214,13 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                 if (lane < cnt && lane < kShareCap) blk[kShareRows + q * kShareCap + lane] = a.eid[beg + lane];
             }
         }
+        if (wave == 0) {    // all registrations in (see PLACEMENT above), then the verdict for the whole workgroup
+            wait_ge(place + 8, (unsigned)a.n_active, dead, a.status);
+            const unsigned bad = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_word(place + 9));
+            if (lane == 0) ctl[1] = (int)bad;
+        }
         __syncthreads();
+        const bool l2_shared = __builtin_amdgcn_readfirstlane(ctl[1]) == 0;
         tr.mark(0);
 
         // The tile this wavefront ran last is PUBLISHED (its LDS word, its group's message counter) only when its stores have
@@ -362,11 +393,11 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                         }
                         // the CU's L1 may hold lines of this parity's Zx from two steps ago: invalidate once, let the
                         // invalidation pass the L1 (a dependent L1-bypassing load behind it), then tell the siblings
-#if RES_L1_INV_ONLY
-                        asm volatile("buffer_inv sc0" ::: "memory");
-#else
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
+                        if (RES_L1_INV_ONLY && l2_shared) {
+                            asm volatile("buffer_inv sc0" ::: "memory");
+                        } else {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        }
                         const unsigned again = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_word(cnt_zx(grp, p)));
                         if (slot < kResSlots && lane == 0 && again >= tgt)
                             __hip_atomic_store(zxc + p * kResSlots + slot, tgt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -722,6 +753,7 @@ extern "C" int tspgnn_mp_resident_h2(const tspgnn_mp_resident_args* args, int d,
     TSPGNN_REQUIRE(!a.v_zbias || a.v_zscale, "mp_resident_h2: v_zbias needs v_zscale");
     TSPGNN_REQUIRE(a.e_h0 != a.e_h && a.v_h0 != a.v_h, "mp_resident_h2: the final states must not alias the initial ones");
     TSPGNN_REQUIRE(a.lds_words >= 0, "mp_resident_h2: lds_words=%d", a.lds_words);
+    TSPGNN_REQUIRE(a.n_active >= 1 && a.n_active <= a.grid, "mp_resident_h2: n_active=%d must be in 1..grid", a.n_active);
     constexpr int D = 64;
     const size_t head = (10 * D + 4 + 2 * kResSlots) * sizeof(float);
     const size_t layer = 2 * D * D * 2 + D * 4;

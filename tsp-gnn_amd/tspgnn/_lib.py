@@ -147,7 +147,7 @@ class MpResidentArgs(ctypes.Structure):
                 ("v_relu_mask", c_uint), ("v_proj_w", c_void_p), ("zx", c_void_p * 2), ("vagg", c_void_p * 2),
                 ("vh", c_void_p * 2),
                 ("plan", c_void_p), ("counters", c_void_p), ("n_groups", c_int), ("grid", c_int),
-                ("n_slots", c_int), ("lds_words", c_int),
+                ("n_slots", c_int), ("lds_words", c_int), ("n_active", c_int), ("flags", c_int),
                 ("M", c_int), ("N", c_int), ("T", c_int), ("z_centered", c_int),
                 ("range_flag", c_void_p), ("status", c_void_p), ("trace", c_void_p)]
 

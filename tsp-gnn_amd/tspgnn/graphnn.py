@@ -110,19 +110,20 @@ def loop_kind():
 
 
 def choose_loop_plan(e_start, v_start, grid):
-    """-> (plan int32 ndarray, meta) or None; meta = (n_groups, grid, kind, n_slots, lds_words), kind "loop"
+    """-> (plan int32 ndarray, meta) or None; meta = (n_groups, grid, kind, n_slots, lds_words, n_active), kind "loop"
     (loop_plan.py, tspgnn_mp_loop_h2) or "resident" (resident_plan.py, tspgnn_mp_resident_h2)."""
     kind = loop_kind()
     if kind in ("auto", "loop"):
         built = loop_plan.build(e_start, v_start, grid=grid)
         if built is not None:
-            return built[0], (built[1], grid, "loop", 0, 0)
+            return built[0], (built[1], grid, "loop", 0, 0, 0)
     if kind in ("auto", "resident"):
         built = resident_plan.build(e_start, v_start, grid=grid)
         if built is not None and kind == "auto" and not resident_plan.in_auto_window(int(e_start[-1])):
             built = None
         if built is not None:
-            return built["plan"], (built["n_groups"], grid, "resident", built["n_slots"], built["lds_words"])
+            return built["plan"], (built["n_groups"], grid, "resident", built["n_slots"], built["lds_words"],
+                                   built["edge_wgs"] + built["vertex_wgs"])
     return None
 
 
@@ -130,7 +131,7 @@ def _make_loop_plan(ev, device):
     """Work plan of the one-launch T-step loop for a SparseEV on a GPU: built where the batch is packed (host side, cached
     per block structure), uploaded with the adjacency -- a captured forward then serves any batch copied into its buffers
     (DeviceBatch.copy_from copies the plan too).  None: no GPU, switched off, or the batch does not fit a resident
-    design.  -> (int32 device tensor, n_groups, grid, kind, n_slots, lds_words)."""
+    design.  -> (int32 device tensor, n_groups, grid, kind, n_slots, lds_words, n_active)."""
     dev = torch.device(device)
     if dev.type != "cuda" or not loop_enabled() or ev.shape[0] == 0:
         return None
@@ -213,7 +214,7 @@ class DeviceAdjacency(object):
         self.csr_t = csr_t  # same for the transpose
         self.uv = uv        # int32 [R,2] if the matrix is 0/1 with exactly two ones per row
         self._degrees = {}
-        self.loop_plan = None   # (int32 device tensor, n_groups, grid, kind, n_slots, lds_words): _make_loop_plan
+        self.loop_plan = None   # (int32 device tensor, n_groups, grid, kind, n_slots, lds_words, n_active): _make_loop_plan
 
     def row_degrees(self, transpose=False):
         """Stored entries per row (of the transpose) as fp32, computed once per matrix."""
@@ -1346,7 +1347,7 @@ class GraphNN(object):
         adj = mats[ue["mat"]]
         if adj.loop_plan is None or adj.csr_t[2] is not None:
             return None
-        plan_t, n_groups, grid, kind, n_slots, lds_words = adj.loop_plan
+        plan_t, n_groups, grid, kind, n_slots, lds_words, n_active = adj.loop_plan
         cell_e, cell_v = self._RNN_cells[ve], self._RNN_cells[vv]
         if cell_v.dx != 64 or cell_e.dx != 64:
             return None
@@ -1377,6 +1378,8 @@ class GraphNN(object):
         if resident:   # the edge states between the steps, by tile slot (private to the launch)
             slots = [torch.empty((n_slots * 16, 64), **f32), torch.empty((n_slots * 16, 64), **f32)]
             a.e_hs, a.e_cs, a.n_slots, a.lds_words = _lib.ptr(slots[0]), _lib.ptr(slots[1]), n_slots, lds_words
+            a.n_active = n_active
+            a.flags = 1 if os.environ.get("TSPGNN_RES_SAFE") == "1" else 0   # (tests: the placement-independent acquire)
             vh = [torch.empty((N, 64), **f32), torch.empty((N, 64), **f32)]
             a.vh[0], a.vh[1] = _lib.ptr(vh[0]), _lib.ptr(vh[1])
             keep.extend([slots, vh])
