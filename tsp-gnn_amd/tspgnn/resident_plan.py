@@ -57,11 +57,12 @@ def msg_tiles_per_wg():
 
 def in_auto_window(edge_rows):
     """Does the default selector (graphnn.choose_loop_plan, TSPGNN_LOOP_KIND unset) hand a batch of this many edge rows to
-    tspgnn_mp_resident_h2?  Measured on MI355X at n = 40, T = 32 against the stepwise launches (profiles/r06_resident_vs_steps.txt):
-    128 instances (C2, 99 840 rows) -2 %..+0.5 % -- inside the box-to-box spread, so C2 stays on the launches it has been
-    measured on for five rounds; 160 instances +-2 %; 192 instances -15 %; 256 instances -2 %.  The window is the stretch where
-    the gain is outside the noise; TSPGNN_LOOP_KIND=resident takes every batch the kernel holds."""
-    return 130000 <= edge_rows <= 175000
+    tspgnn_mp_resident_h2?  Measured on MI355X at n = 40, T = 32 against the stepwise launches (profiles/r06_resident_vs_steps.txt,
+    one box, three alternating runs each): 32 / 64 instances +13 % / +10 % (the register-resident loop's ground), 96: equal,
+    128 (C2, 99 840 rows): -3 %..+2 % -- inside the box-to-box spread, so C2 stays on the launches whose row-sum the roofline
+    line is quoted on --, 160: -1.5 %, 192 (149 760 rows): -16 %, 224: -16 %, 256 (199 680 rows): -6 %.  The window is the
+    stretch where the gain is outside the noise; TSPGNN_LOOP_KIND=resident takes every batch the kernel holds."""
+    return 140000 <= edge_rows <= 205000
 
 
 def share_lead():
