@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--serve-prefetcher", action="store_true", help="serve leg: only the general BatchPrefetcher path "
                                                                     "(skip parallel.BatchStager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (bounded sample)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget (bounded sample)")
     args = ap.parse_args()
 
     import torch
@@ -850,17 +850,36 @@ def plumbing_main(args, rank, world):
     return result
 
 
+def physical_cores():
+    """Physical cores of this host (the CPU baseline runs on physical cores, not SMT threads): distinct
+    (physical id, core id) pairs of /proc/cpuinfo -- psutil's count came back as the logical 128 on the 64-core EPYC of
+    the GPU boxes --, else psutil, else os.cpu_count()."""
+    try:
+        pairs, phys = set(), None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    pairs.add((phys, line.split(":", 1)[1].strip()))
+        if pairs:
+            return min(len(pairs), os.cpu_count() or len(pairs))
+    except OSError:
+        pass
+    try:
+        import psutil
+        return psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        return os.cpu_count()
+
+
 def run_cpu_baseline(d, batch, T, budget_s, M):
     """The oracle's op-for-op dense fp32 restatement of the TF CPU graph (dense EV matmul both
     directions), timed on this host's cores on a BOUNDED sample: as many message-passing steps of
     the full batch as fit the budget.  Checker code used as a reported baseline."""
     import torch
     from oracle import torch_oracle as TO
-    try:
-        import psutil
-        cores = psutil.cpu_count(logical=False) or os.cpu_count()
-    except Exception:
-        cores = os.cpu_count()
+    cores = physical_cores()
     EV, W, C, route_exists, n_vertices, n_edges = batch
     ob = {"ev_uv": EV.uv, "W": W, "C": C, "route_exists": route_exists, "n_vertices": n_vertices, "n_edges": n_edges}
     t1, threads = TO.time_dense_forward(d, ob, 1, cores, warm=0, iters=1)       # also warms the allocator

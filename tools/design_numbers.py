@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Prints the numbers table of DESIGN.md section 9 from the committed round-5 bench lines and kernel summaries
-(profiles/r05_*): python tools/design_numbers.py"""
+"""Prints the numbers table of DESIGN.md section 9 from the committed round-6 bench lines and kernel summaries
+(profiles/r06_*): python tools/design_numbers.py"""
 import json
 import os
 import re
@@ -10,11 +10,11 @@ P = os.path.join(ROOT, "profiles")
 
 
 def bench(w):
-    return json.load(open(os.path.join(P, "r05_%s_bench.json" % w)))
+    return json.load(open(os.path.join(P, "r06_%s_bench.json" % w)))
 
 
 def kernel_us(w, pat, fname="forward_kernel_stats"):
-    for line in open(os.path.join(P, "r05_%s_%s.txt" % (w, fname))):
+    for line in open(os.path.join(P, "r06_%s_%s.txt" % (w, fname))):
         if re.search(pat, line):
             f = line[80:].split()
             return float(f[5]), int(f[4])
@@ -44,9 +44,9 @@ print("| workload (one MI355X) | forward ms | mp-steps/s | V<-E row-sum launch (
       "cell (or loop) launch | row-sum PMC traffic / algorithmic | training step ms | fresh batches ms (vs resident) |")
 print("|---|---|---|---|---|---|---|---|")
 print("\n".join(rows))
-c2t = json.load(open(os.path.join(P, "r05_c2_train_bench.json")))
-c5t = json.load(open(os.path.join(P, "r05_c5_train_bench.json")))
-print("\nTraining, dedicated runs: C2 %.2f ms per step (`r05_c2_train_bench.json`), C5 shard %.1f ms (`r05_c5_train_bench.json`)."
+c2t = json.load(open(os.path.join(P, "r06_c2_train_bench.json")))
+c5t = json.load(open(os.path.join(P, "r06_c5_train_bench.json")))
+print("\nTraining, dedicated runs: C2 %.2f ms per step (`r06_c2_train_bench.json`), C5 shard %.1f ms (`r06_c5_train_bench.json`)."
       % (c2t["ms_per_step"], c5t["ms_per_step"]))
 j = bench("c2")
 g = j["gemm"]["alternatives"]
