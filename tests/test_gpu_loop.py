@@ -126,3 +126,47 @@ def test_resident_loop_without_the_placement_assumption(cuda_device, kind, monke
     assert fast[2] and safe[2]
     assert_bit_equal(fast, steps)
     assert_bit_equal(safe, steps)
+
+
+def test_default_selector_takes_the_resident_loop_in_its_window(cuda_device, kind, monkeypatch):
+    """TSPGNN_LOOP_KIND unset (the shipped default): a batch inside resident_plan.in_auto_window -- 192 instances of n = 40,
+    149 760 edge rows -- goes to tspgnn_mp_resident_h2, C2 (99 840 rows) to the stepwise launches, 32 instances of n = 20 to
+    the register-resident loop; the window batch matches the stepwise launches bit for bit, at 256 instances too (the size
+    at which a plain load of the edge states was caught returning a stale line)."""
+    if kind != "resident":
+        pytest.skip("one run is enough")
+    monkeypatch.delenv("TSPGNN_LOOP_KIND")
+    monkeypatch.delenv("TSPGNN_LOOP_MAX_TILES")
+    params = P.init_params(64, seed=12, perturb=True)
+    model = tspgnn.build_network(64)
+    sess = tspgnn.Session(model)
+
+    def plan_kind(sizes):
+        EV, W, C, route_exists, n_vertices, n_edges = tspgnn.synthetic_batch(sizes, seed=3)
+        b = sess.prepare({model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: 2, model["route_exists"]: route_exists,
+                          model["n_vertices"]: n_vertices, model["n_edges"]: n_edges})
+        return None if b.adj.loop_plan is None else b.adj.loop_plan[3]
+    assert plan_kind([40] * 192) == "resident" and plan_kind([40] * 128) is None and plan_kind([20] * 32) == "loop"
+    for n_inst, T in ((192, 5), (256, 3)):
+        t = tspgnn.synthetic_batch([40] * n_inst, seed=8)
+        if n_inst == 256:
+            monkeypatch.setenv("TSPGNN_LOOP_KIND", "resident")
+        one = forward_any(params, t, T, True)
+        steps = forward_any(params, t, T, False)
+        assert one[2] == "resident" and steps[2] is None
+        assert_bit_equal(one, steps)
+
+
+def forward_any(params, t, T, loop):
+    model = tspgnn.build_network(64)
+    model["gnn"].persistent_loop = loop
+    sess = tspgnn.Session(model)
+    sess.run(tspgnn.global_variables_initializer())
+    model.store.load(params)
+    EV, W, C, route_exists, n_vertices, n_edges = t
+    feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+            model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+    b = sess.prepare(feed)
+    used = b.adj.loop_plan[3] if (b.adj.loop_plan is not None and loop) else None
+    pred, last = sess.run([model["predictions"], model["last_states"]], feed_dict=feed)
+    return pred, last, used

@@ -14,7 +14,8 @@ import tspgnn  # noqa: E402
 
 n_fwd, n_train = int(os.environ.get("NFWD", 3000)), int(os.environ.get("NTRAIN", 300))
 d, T = 64, 32
-batch = tspgnn.synthetic_batch([40] * 128, seed=1234)
+# GRAPHS=192 puts the forward on tspgnn_mp_resident_h2 (the default selector's window); TSPGNN_LOOP_KIND forces a form
+batch = tspgnn.synthetic_batch([40] * int(os.environ.get("GRAPHS", 128)), seed=1234)
 EV, W, C, r, nv, ne = batch
 model = tspgnn.build_network(d)
 sess = tspgnn.Session(model)
@@ -22,6 +23,7 @@ sess.run(tspgnn.global_variables_initializer(seed=0))
 feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T, model["route_exists"]: r,
         model["n_vertices"]: nv, model["n_edges"]: ne}
 b = sess.prepare(feed)
+print("one-launch form:", None if b.adj.loop_plan is None else b.adj.loop_plan[3])
 replay = sess.capture_forward(b)
 first = replay()
 ref_pred = first["predictions"].clone()

@@ -65,27 +65,6 @@ constexpr int kResSlots = 32;       // groups per edge workgroup whose Zx counte
 constexpr int kResVertTiles = 2;
 constexpr int kShareRows = TSPGNN_RESIDENT_SHARE_ROWS;   // vertex rows per row-sum share
 constexpr int kShareCap = TSPGNN_RESIDENT_SHARE_CAP;     // edge ids per vertex row held in LDS
-#ifndef RES_L1_INV_ONLY
-#define RES_L1_INV_ONLY 1
-#endif
-#ifndef RES_STATE_WT
-#define RES_STATE_WT 1   // the edge states between the steps through write-through stores / L1-bypassing loads (0: plain -- measured
-                       // WRONG at 256 instances of n = 40: a plain load can hit a line another wavefront of the CU has since rewritten)
-#endif
-
-#ifndef RES_ST_AUX
-#define RES_ST_AUX 17
-#endif
-#ifndef RES_LD_AUX
-#define RES_LD_AUX 17
-#endif
-__device__ __forceinline__ f32x4 ld4x(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, RES_LD_AUX));
-}
-__device__ __forceinline__ void st4x(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, RES_ST_AUX);
-}
-
 // Wave-uniform wait until the LDS word *w >= target (acquire at workgroup scope: what follows is not hoisted above it).
 __device__ __forceinline__ void lds_wait_ge(const unsigned* w, unsigned target, bool& dead, unsigned* status) {
     if (dead) return;
@@ -190,10 +169,8 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
         __syncthreads();
         const _Float16* Kl = lds_w + total;
         const int2* uv = reinterpret_cast<const int2*>(a.uv);
-#if RES_STATE_WT
         const __amdgpu_buffer_rsrc_t r_hs = make_rsrc(a.e_hs, (long long)a.n_slots * 16 * D * 4);
         const __amdgpu_buffer_rsrc_t r_cs = make_rsrc(a.e_cs, (long long)a.n_slots * 16 * D * 4);
-#endif
         const int total_items = n_items * T;
 
         // The row-sum shares of this workgroup never change: their edge lists wait in LDS behind the per-tile words -- per
@@ -302,7 +279,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                             for (int m = 0; m < NL; ++m) {
                                 const int kk = 4 * m + sub;
                                 const int e = el[kk < cn[u] ? kk : 0];
-                                x[u][m] = ld4x(r_msg_in, ((unsigned)e * D + c * 4) * 4u);
+                                x[u][m] = ld4wt(r_msg_in, ((unsigned)e * D + c * 4) * 4u);
                             }
                         }
 #pragma unroll
@@ -318,7 +295,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                                 s4[r] += __shfl_xor(s4[r], 16);
                                 s4[r] += __shfl_xor(s4[r], 32);
                             }
-                            if (sub == 0 && q0 + u < rows) st4x(r_vagg, ((unsigned)(i0 + q0 + u) * D + c * 4) * 4u, s4);
+                            if (sub == 0 && q0 + u < rows) st4wt(r_vagg, ((unsigned)(i0 + q0 + u) * D + c * 4) * 4u, s4);
                         }
                     }
                 } else {
@@ -341,7 +318,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
 #pragma unroll
                                 for (int kk = 0; kk < 8; ++kk) {
                                     const int e = __shfl(my_e, (l & 48) + h8 + kk);
-                                    x[kk] = ld4x(r_msg_in, ((unsigned)e * D + c * 4) * 4u);
+                                    x[kk] = ld4wt(r_msg_in, ((unsigned)e * D + c * 4) * 4u);
                                 }
 #pragma unroll
                                 for (int kk = 0; kk < 8; ++kk)
@@ -349,7 +326,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                             }
                         }
                         const f32x4 tot = (s[0] + s[1]) + (s[2] + s[3]);   // the order of csr_rowsum_kernel's lane-group butterfly
-                        if (on) st4x(r_vagg, ((unsigned)v * D + c * 4) * 4u, tot);
+                        if (on) st4wt(r_vagg, ((unsigned)v * D + c * 4) * 4u, tot);
                     }
                 }
                 drain_stores();
@@ -393,7 +370,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                         }
                         // the CU's L1 may hold lines of this parity's Zx from two steps ago: invalidate once, let the
                         // invalidation pass the L1 (a dependent L1-bypassing load behind it), then tell the siblings
-                        if (RES_L1_INV_ONLY && l2_shared) {
+                        if (l2_shared) {
                             asm volatile("buffer_inv sc0" ::: "memory");
                         } else {
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -442,17 +419,12 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                     for (int q = 0; q < TPG; ++q)
                         cf[q] = a.e_c0 != nullptr ? ld4(a.e_c0 + ((size_t)rc * D + g * 4 + q * 16)) : f32x4{0.f, 0.f, 0.f, 0.f};
                 } else {
-#if RES_STATE_WT
+                    // (past the L1: a plain load here was measured to return a line another wavefront of the CU had since
+                    // rewritten -- 256 instances of n = 40, max abs difference 4.8e-2 -- DESIGN_HISTORY round 6)
 #pragma unroll
-                    for (int q = 0; q < TPG; ++q) hv[q] = ld4x(r_hs, (soff + q * 256u) * 4u);
+                    for (int q = 0; q < TPG; ++q) hv[q] = ld4wt(r_hs, (soff + q * 256u) * 4u);
 #pragma unroll
-                    for (int q = 0; q < TPG; ++q) cf[q] = ld4x(r_cs, (soff + q * 256u) * 4u);
-#else
-#pragma unroll
-                    for (int q = 0; q < TPG; ++q) hv[q] = ld4(a.e_hs + soff + q * 256u);
-#pragma unroll
-                    for (int q = 0; q < TPG; ++q) cf[q] = ld4(a.e_cs + soff + q * 256u);
-#endif
+                    for (int q = 0; q < TPG; ++q) cf[q] = ld4wt(r_cs, (soff + q * 256u) * 4u);
                 }
 #pragma unroll
                 for (int kb = 0; kb < KBH; ++kb) {
@@ -483,13 +455,8 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                 } else if (valid) {
 #pragma unroll
                     for (int q = 0; q < TPG; ++q) {
-#if RES_STATE_WT
-                        st4x(r_hs, (soff + q * 256u) * 4u, hn[q]);
-                        st4x(r_cs, (soff + q * 256u) * 4u, nc[q]);
-#else
-                        st4(a.e_hs + soff + q * 256u, hn[q]);
-                        st4(a.e_cs + soff + q * 256u, nc[q]);
-#endif
+                        st4wt(r_hs, (soff + q * 256u) * 4u, hn[q]);
+                        st4wt(r_cs, (soff + q * 256u) * 4u, nc[q]);
                     }
                 }
             }
@@ -515,7 +482,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                     const __amdgpu_buffer_rsrc_t r_msg_out = p ? r_msg0 : r_msg1;
                     if (valid) {
 #pragma unroll
-                        for (int q = 0; q < TPG; ++q) st4x(r_msg_out, (rc * D + g * 4 + q * 16) * 4u, hn[q]);
+                        for (int q = 0; q < TPG; ++q) st4wt(r_msg_out, (rc * D + g * 4 + q * 16) * 4u, hn[q]);
                     }
                 }
                 pend_local = local;
@@ -587,14 +554,14 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                     for (int q = 0; q < TPG; ++q) ho[q] = ld4(a.v_h0 + (size_t)rc * D + g * 4 + q * 16);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < TPG; ++q) ho[q] = ld4x(r_h_in, (rc * D + g * 4 + q * 16) * 4u);
+                    for (int q = 0; q < TPG; ++q) ho[q] = ld4wt(r_h_in, (rc * D + g * 4 + q * 16) * 4u);
                 }
                 wait_ge(cnt_vagg(grp[j], p), (unsigned)(((t >> 1) + 1) * gcnt[j]), dead, a.status);
                 asm volatile("" ::: "memory");
                 tr.stamp(0, chosen);
                 f32x4 xo[TPG];
 #pragma unroll
-                for (int q = 0; q < TPG; ++q) xo[q] = ld4x(r_vagg, (rc * D + g * 4 + q * 16) * 4u);
+                for (int q = 0; q < TPG; ++q) xo[q] = ld4wt(r_vagg, (rc * D + g * 4 + q * 16) * 4u);
                 tr.mark(1);
                 f32x4 acc[NT4], cf[TPG];
                 if (a.v_zbias != nullptr) {
@@ -630,7 +597,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                         for (int q = 0; q < TPG; ++q) st4(hd + q * 16, hn[q]);
                     } else {
 #pragma unroll
-                        for (int q = 0; q < TPG; ++q) st4x(r_h_out, (rc * D + g * 4 + q * 16) * 4u, hn[q]);
+                        for (int q = 0; q < TPG; ++q) st4wt(r_h_out, (rc * D + g * 4 + q * 16) * 4u, hn[q]);
                     }
                 }
                 tr.mark(2);
@@ -675,7 +642,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                 const unsigned rc = (unsigned)(row0[j] + (valid ? rl : 0));
                 f32x4 hn[TPG];
 #pragma unroll
-                for (int q = 0; q < TPG; ++q) hn[q] = ld4x(r_h, (rc * D + g * 4 + q * 16) * 4u);
+                for (int q = 0; q < TPG; ++q) hn[q] = ld4wt(r_h, (rc * D + g * 4 + q * 16) * 4u);
                 const unsigned mask = a.v_relu_mask;
                 for (int ly = 0; ly < L; ++ly) {
                     const _Float16* wh = reinterpret_cast<const _Float16*>(lds_wb + (size_t)ly * LAYER_BYTES);
@@ -703,7 +670,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                         kblock_h2_sub<NT4, s * TPG, TPG>(acc, wp, wp + D * 4 * D, kb, g, rl, yh[kb], yl[kb]);
                     if (valid) {
 #pragma unroll
-                        for (int q = 0; q < TPG; ++q) st4x(r_zx_out, (zoff + (unsigned)(s * TPG + q) * 256u) * 4u, acc[q]);
+                        for (int q = 0; q < TPG; ++q) st4wt(r_zx_out, (zoff + (unsigned)(s * TPG + q) * 256u) * 4u, acc[q]);
                     }
                 };
                 gate(std::integral_constant<int, 0>{});
