@@ -42,7 +42,8 @@ sess.forward_device(b)
 e1.record()
 torch.cuda.synchronize()
 print("eager forward with trace: %.3f ms" % e0.elapsed_time(e1))
-tr = model["gnn"].loop_trace.cpu().numpy().astype(np.float64) * 0.01 / T     # us per step
+full = model["gnn"].loop_trace.cpu().numpy().astype(np.float64)
+tr = full[:, :, :16] * 0.01 / T     # us per step
 plan, G, grid, kind, n_slots, lds_words, n_active = b.adj.loop_plan
 assert kind == "resident"
 hdr = plan.cpu().numpy()[:grid * RP.HDR].reshape(grid, RP.HDR)
@@ -59,7 +60,7 @@ for role, name in ((1, "edge"), (2, "cell"), (3, "message")):
         print("  %-9s  " % label + " ".join("%7.2f" % a for a in v[:8]) + "  %7.2f" % v.sum())
 
 # timeline of step T/2 (absolute 100 MHz stamps in slots 8..15), relative to the earliest stamp
-raw = model["gnn"].loop_trace.cpu().numpy().astype(np.float64)[:, :, 8:] * 0.01
+raw = full[:, :, 8:16] * 0.01
 t0 = raw[raw > 0].min()
 names_e = ["item taken", "own step ready", "Zx ready", "tile done", "share taken", "share: msgs ready", "share done", "-"]
 names_c = ["aggregates ready", "-", "h' handed over", "-", "-", "-", "-", "-"]
@@ -89,3 +90,18 @@ if os.environ.get("RES_TRACE_XCD") is not None:
             if len(v) and nm != "-":
                 parts.append("%s %.1f..%.1f" % (nm, v.min(), v.max()))
         print("wg %3d role %d class %d items %2d | " % (b, role, hdr[b, 6], hdr[b, 2]) + " | ".join(parts))
+
+
+# inside ONE tile (the last tile a wavefront ran in step T/2): stamps 16..24 = item decoded, own previous step ready, Zx ready,
+# loads issued, loads landed (an extra vmcnt(0) in the trace build), K GEMM done, gates done, state stores issued, MLP done + message stores issued
+fine = full[:, :, 16:25] * 0.01
+sel = (hdr[:, 0] == 1) & (hdr[:, 2] > 0)
+f = fine[sel].reshape(-1, 9)
+f = f[(f > 0).all(1)]
+names = ["own step ready", "Zx ready", "loads issued", "loads landed", "K GEMM done", "gates done", "state stored", "MLP + msg stores"]
+print("inside one edge tile of step %d, us between consecutive stamps (median / p10 / p90 over %d wavefronts):" % (T // 2, len(f)))
+for i, nm in enumerate(names):
+    dlt = f[:, i + 1] - f[:, i]
+    print("  -> %-18s %6.2f %6.2f %6.2f" % (nm, np.median(dlt), np.percentile(dlt, 10), np.percentile(dlt, 90)))
+tot = f[:, 8] - f[:, 0]
+print("  whole tile          %6.2f %6.2f %6.2f" % (np.median(tot), np.percentile(tot, 10), np.percentile(tot, 90)))

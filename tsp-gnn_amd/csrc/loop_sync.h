@@ -54,15 +54,15 @@ __device__ __forceinline__ void st4wt(__amdgpu_buffer_rsrc_t r, unsigned byte_of
 
 // Optional phase trace (a TRACE variant of a loop kernel): per (workgroup, wavefront) 16 sums of s_memrealtime ticks
 // (100 MHz).
-template <bool ON>
+template <bool ON, int N = 16>
 struct LoopTrace {
     unsigned long long* dst;
     unsigned long long prev;
-    unsigned long long acc[ON ? 16 : 1];
+    unsigned long long acc[ON ? N : 1];
     __device__ __forceinline__ void begin(unsigned long long* p) {
         if constexpr (ON) {
             dst = p;
-            for (int i = 0; i < 16; ++i) acc[i] = 0;
+            for (int i = 0; i < N; ++i) acc[i] = 0;
             prev = __builtin_amdgcn_s_memrealtime();
         }
     }
@@ -82,7 +82,7 @@ struct LoopTrace {
     __device__ __forceinline__ void flush() {
         if constexpr (ON) {
             if ((threadIdx.x & 63) == 0)
-                for (int i = 0; i < 16; ++i) dst[i] = acc[i];
+                for (int i = 0; i < N; ++i) dst[i] = acc[i];
         }
     }
 };

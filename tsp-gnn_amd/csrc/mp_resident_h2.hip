@@ -65,13 +65,28 @@ constexpr int kResSlots = 32;       // groups per edge workgroup whose Zx counte
 constexpr int kResVertTiles = 2;
 constexpr int kShareRows = TSPGNN_RESIDENT_SHARE_ROWS;   // vertex rows per row-sum share
 constexpr int kShareCap = TSPGNN_RESIDENT_SHARE_CAP;     // edge ids per vertex row held in LDS
+// An LDS flag word, read / written RELAXED behind a compiler barrier.  The ordering the protocol needs comes from the hardware's
+// program order per wavefront (what follows is control-dependent on the value, and the writer drains its stores -- vmcnt(0) --
+// before it writes the word); an ACQUIRE at workgroup scope would add an s_waitcnt vmcnt(0), i.e. make the wavefront sit out
+// every load it has just issued (the endpoints' prefetch: ~1 us per tile, tools/resident_trace.py).
+__device__ __forceinline__ unsigned lds_word(const unsigned* w) {
+    asm volatile("" ::: "memory");
+    const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_word_set(unsigned* w, unsigned v) {
+    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+
 // Wave-uniform wait until the LDS word *w >= target (acquire at workgroup scope: what follows is not hoisted above it).
 __device__ __forceinline__ void lds_wait_ge(const unsigned* w, unsigned target, bool& dead, unsigned* status) {
     if (dead) return;
     unsigned spins = 0;
     for (;;) {
-        const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane(
-            (int)__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        const unsigned v = lds_word(w);
         if (v >= target) break;
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 1023u) == 0u) {
@@ -131,8 +146,8 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
         __threadfence();
         atomicAdd(place + 8, 1u);
     }
-    LoopTrace<TRACE> tr;
-    tr.begin(a.trace + ((size_t)blockIdx.x * kResWaves + wave) * 16);
+    LoopTrace<TRACE, 32> tr;   // 0..7 phase sums, 8..15 stamps of one step (per-XCD timeline), 16..31 stamps inside one tile
+    tr.begin(a.trace + ((size_t)blockIdx.x * kResWaves + wave) * 32);
 
     // LayerNorm parameters of this workgroup's cell (as lnlstm_mlp_fwd_h2_kernel: gates i, f, o times -log2(e), forget bias
     // folded into b_f)
@@ -207,8 +222,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
         int pend_local = -1, pend_t = 0, pend_grp = 0;
         auto publish = [&]() {
             if (pend_local >= 0) {
-                if (lane == 0)
-                    __hip_atomic_store(done + pend_local, (unsigned)(pend_t + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lds_word_set(done + pend_local, (unsigned)(pend_t + 1));   // (behind the caller's vmcnt(0))
                 arrive(cnt_msg(pend_grp, 1 - (pend_t & 1)), 1u);
                 pend_local = -1;
             }
@@ -241,6 +255,8 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
             tr.mark(1);
             const bool chosen = t == (T >> 1);
             tr.stamp(local < 0 ? 4 : 0, chosen);
+            const bool fine = chosen && local >= 0;
+            tr.stamp(8, fine);    // item decoded
 
             if (local < 0) {
                 // ---- a share of the V<-E row-sum over the messages of step t: vertex rows [i0, i1) of group grp
@@ -346,8 +362,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                 ends = uv[i0 + (rl0 < i1 ? rl0 : 0)];
             }
             if (!first) {
-                const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane(
-                    (int)__hip_atomic_load(done + local, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                const unsigned v = lds_word(done + local);
                 if (v < (unsigned)t) {
                     flush();
                     lds_wait_ge(done + local, (unsigned)t, dead, a.status);
@@ -355,14 +370,13 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
             }
             tr.mark(4);
             tr.stamp(1, chosen);
+            tr.stamp(9, fine);    // own previous step ready
             {
                 const unsigned tgt = (unsigned)(((t + 1) >> 1) * gcnt);
                 if (tgt != 0u) {
                     const int slot = grp - g_first;
                     unsigned seen = 0u;
-                    if (slot < kResSlots)
-                        seen = (unsigned)__builtin_amdgcn_readfirstlane(
-                            (int)__hip_atomic_load(zxc + p * kResSlots + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (slot < kResSlots) seen = lds_word(zxc + p * kResSlots + slot);
                     if (seen < tgt) {
                         if ((unsigned)__builtin_amdgcn_readfirstlane((int)ld_word(cnt_zx(grp, p))) < tgt) {
                             flush();
@@ -376,13 +390,13 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         }
                         const unsigned again = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_word(cnt_zx(grp, p)));
-                        if (slot < kResSlots && lane == 0 && again >= tgt)
-                            __hip_atomic_store(zxc + p * kResSlots + slot, tgt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (slot < kResSlots && again >= tgt) lds_word_set(zxc + p * kResSlots + slot, tgt);
                     }
                 }
             }
             tr.mark(5);
             tr.stamp(2, chosen);
+            tr.stamp(10, fine);   // Zx ready
             const float* zx = a.zx[p];
             // the lane's coordinates, recomputed where they are needed instead of carried across the GEMMs (two VALU
             // instructions against a spilled register): (a lane beyond the tile's rows repeats row 0, state slot included --
@@ -426,6 +440,13 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
 #pragma unroll
                     for (int q = 0; q < TPG; ++q) cf[q] = ld4wt(r_cs, (soff + q * 256u) * 4u);
                 }
+                if constexpr (TRACE) {
+                    if (fine) {
+                        tr.stamp(11, true);   // loads issued
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        tr.stamp(12, true);   // loads landed
+                    }
+                }
 #pragma unroll
                 for (int kb = 0; kb < KBH; ++kb) {
                     float xv[8];
@@ -435,12 +456,24 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                     split2w(xv, bh, bl, wit);
                     kblock_h2<NT4>(acc, lds_w, Kl, kb, g, rl, bh, bl);
                 }
+                if constexpr (TRACE) {
+                    if (fine) {
+                        asm volatile("s_nop 0" : : "v"(acc[0]), "v"(acc[NT4 - 1]));
+                        tr.stamp(13, true);   // K GEMM done
+                    }
+                }
                 if (pend_local >= 0) {   // every load of this tile has landed, the previous tile's stores are microseconds old:
                     drain_stores();      // the wait is (all but) free here
                     publish();
                 }
                 f32x4 nc[TPG];
                 lstm_gates<D, true, SWAP, CENTERED, true>(acc, cf, lds_ln, g, hn, nc, kH2GateEps, &vmin);
+                if constexpr (TRACE) {
+                    if (fine) {
+                        asm volatile("s_nop 0" : : "v"(hn[0]), "v"(nc[TPG - 1]));
+                        tr.stamp(14, true);   // gates done
+                    }
+                }
                 coords(rl, g, valid, rc, soff);
                 if (last) {
                     if (valid) {
@@ -461,6 +494,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                 }
             }
             tr.mark(6);
+            tr.stamp(15, fine);   // state stores issued
             take_next();
             if (!last) {
                 int rl, g;
@@ -489,6 +523,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                 pend_t = t;
                 pend_grp = grp;
             }
+            tr.stamp(16, fine);   // message MLP done, message stores issued
             tr.mark(7);
             tr.stamp(3, chosen);
         }

@@ -1398,7 +1398,7 @@ class GraphNN(object):
         a.range_flag, a.status = guard.data_ptr(), guard.data_ptr() + 8
         trace = None
         if os.environ.get("TSPGNN_LOOP_TRACE"):   # development: per-wavefront phase times (tools/loop_trace.py)
-            trace = self.loop_trace = torch.zeros((grid, resident_plan.WAVES if resident else loop_plan.WAVES, 16),
+            trace = self.loop_trace = torch.zeros((grid, resident_plan.WAVES if resident else loop_plan.WAVES, 32 if resident else 16),
                                                   dtype=torch.int64, device=f32["device"])
         a.trace = _lib.ptr(trace)
         keep.extend([out_e, out_v, vagg, counters, plan_t, v_K, zb, deg, e_K, a, trace])
