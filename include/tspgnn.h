@@ -314,13 +314,13 @@ int tspgnn_mp_loop_h2(const tspgnn_mp_loop_args* args, int d, void* stream);
  * `plan`: int32 -- grid headers of TSPGNN_RESIDENT_HDR_INTS, then items of TSPGNN_RESIDENT_ITEM_INTS (layout documented in
  * tspgnn/resident_plan.py and csrc/mp_resident_h2.hip).  `counters` as for tspgnn_mp_loop_h2, zeroed by the caller before
  * every launch.  `lds_words`: LDS words the plan's largest edge workgroup needs behind the weights (one per tile, and
- * TSPGNN_RESIDENT_SHARE_ROWS * (1 + TSPGNN_RESIDENT_SHARE_CAP) per row-sum share whose edge lists it keeps there).
+ * TSPGNN_RESIDENT_SHARE_ROWS * (1 + TSPGNN_RESIDENT_SHARE_CAP / 2) per row-sum share whose edge lists it keeps there)).
  */
 #define TSPGNN_RESIDENT_WAVES 12
 #define TSPGNN_RESIDENT_HDR_INTS 8
 #define TSPGNN_RESIDENT_ITEM_INTS 8
 #define TSPGNN_RESIDENT_SHARE_ROWS 8   /* vertex rows per row-sum share */
-#define TSPGNN_RESIDENT_SHARE_CAP 48   /* edge ids per vertex row of a share kept in LDS */
+#define TSPGNN_RESIDENT_SHARE_CAP 48   /* edge ids (16-bit offsets from the group's first edge) per vertex row of a share kept in LDS */
 typedef struct tspgnn_mp_resident_args {
     const float* e_h0; const float* e_c0;   /* [M,d] row-major initial states; e_c0 NULL = zeros */
     float* e_h; float* e_c;                 /* [M,d] final states */

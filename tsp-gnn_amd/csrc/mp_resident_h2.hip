@@ -46,7 +46,8 @@
 // then items of 8 ints
 //     edge tile:    [0] first row  [1] valid rows  [2] group  [3] local tile index >= 0  [4] vertex tiles of the group
 //     share:        [0] v0         [1] v1          [2] group  [3] -1                     [4] edge tiles of the group
-//                   [5] offset (ints) of the share's edge-list block in the workgroup's LDS words, or -1
+//                   [5] offset (ints) of the share's edge-list block in the workgroup's LDS share area, or -1
+//                   [6] first edge row of the group (the block holds 16-bit offsets from it)
 //     vertex tile:  [0] first row  [1] valid rows  [2] group  [3] -2                     [4] cells: vertex rows of the group;
 //                                                                                            messages: vertex tiles of the group
 #include "common.h"
@@ -166,6 +167,120 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
     const __amdgpu_buffer_rsrc_t r_vagg0 = make_rsrc(a.vagg[0], (long long)a.N * D * 4);
     const __amdgpu_buffer_rsrc_t r_vagg1 = make_rsrc(a.vagg[1], (long long)a.N * D * 4);
 
+    // ---- V<-E row-sum SHARES (held by the edge workgroups, among their items).  A workgroup's shares never change: their edge lists
+    // wait in LDS -- per share a block of kShareRows counts (int) + kShareRows x kShareCap edge ids as 16-bit offsets from the
+    // group's first edge row (item [6]); item [5] = the block's offset in ints from `shl`, < 0: no block (the general loop).
+    int* shl = nullptr;   // set by the role, behind what it keeps in LDS
+    constexpr int kShareBlockInts = kShareRows + kShareRows * kShareCap / 2;
+    auto fill_share_blocks = [&](int first, int count) {
+        for (int j = wave; j < count; j += kResWaves) {
+            const int* it = items + (size_t)(first + j) * kResItem;
+            const int v0 = __builtin_amdgcn_readfirstlane(it[0]), v1 = __builtin_amdgcn_readfirstlane(it[1]);
+            const int off = __builtin_amdgcn_readfirstlane(it[5]), e0 = __builtin_amdgcn_readfirstlane(it[6]);
+            if (__builtin_amdgcn_readfirstlane(it[3]) != -1 || off < 0) continue;
+            int* blk = shl + off;
+            unsigned short* el = reinterpret_cast<unsigned short*>(blk + kShareRows);
+            for (int q = 0; q < kShareRows; ++q) {
+                const int v = v0 + q;
+                const int beg = v < v1 ? a.rowptr[v] : 0;
+                const int cnt = v < v1 ? a.rowptr[v + 1] - beg : 0;
+                if (lane == 0) blk[q] = cnt;
+                if (lane < cnt && lane < kShareCap) el[q * kShareCap + lane] = (unsigned short)(a.eid[beg + lane] - e0);
+            }
+        }
+    };
+    // the share [i0, i1) of group grp at step t (parity p): waits for the group's message tiles of step t - 1
+    auto do_share = [&](int i0, int i1, int grp, int gcnt, int soff_i, int e0, int t) {
+        const int p = t & 1;
+        const __amdgpu_buffer_rsrc_t r_msg_in = p ? r_msg1 : r_msg0;
+        const __amdgpu_buffer_rsrc_t r_vagg = p ? r_vagg1 : r_vagg0;
+        wait_ge(cnt_msg(grp, p), (unsigned)(((t + 1) >> 1) * gcnt), dead, a.status);
+        asm volatile("" ::: "memory");
+        tr.mark(2);
+        tr.stamp(5, t == (T >> 1));
+        const int l = opaque_lane();
+        const int sub = l >> 4, c = l & 15;
+        bool fast = soff_i >= 0;
+        const int* blk = shl + (soff_i >= 0 ? soff_i : 0);
+        if (fast) {
+#pragma unroll
+            for (int q = 0; q < kShareRows; ++q) fast = fast && __builtin_amdgcn_readfirstlane(blk[q]) <= kShareCap;
+        }
+        if (fast) {
+            // csr_rowsum_kernel's own form, two vertex rows at a time: lane group `sub` sums the edges k = sub (mod 4) in
+            // ascending order -- every load of the pair in flight at once (a slot beyond the row's edges re-reads edge 0
+            // and is dropped) -- then the fixed butterfly
+            constexpr int NL = kShareCap / 4;
+            const int rows = i1 - i0;
+            const unsigned short* els = reinterpret_cast<const unsigned short*>(blk + kShareRows);
+            for (int q0 = 0; q0 < rows; q0 += 2) {
+                f32x4 x[2][NL];
+                int cn[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int q = q0 + u < rows ? q0 + u : q0;
+                    cn[u] = __builtin_amdgcn_readfirstlane(blk[q]);
+                    const unsigned short* el = els + q * kShareCap;
+#pragma unroll
+                    for (int m = 0; m < NL; ++m) {
+                        const int kk = 4 * m + sub;
+                        const int e = e0 + (int)el[kk < cn[u] ? kk : 0];
+                        x[u][m] = ld4wt(r_msg_in, ((unsigned)e * D + c * 4) * 4u);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int m = 0; m < NL; ++m) {
+                        const f32x4 add = 4 * m + sub < cn[u] ? x[u][m] : f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (4 * m < cn[u]) s4 += add;   // (uniform: a row of fewer edges takes fewer additions, as csr_rowsum_kernel)
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s4[r] += __shfl_xor(s4[r], 16);
+                        s4[r] += __shfl_xor(s4[r], 32);
+                    }
+                    if (sub == 0 && q0 + u < rows) st4wt(r_vagg, ((unsigned)(i0 + q0 + u) * D + c * 4) * 4u, s4);
+                }
+            }
+        } else {
+            for (int vb = i0; vb < i1; vb += 4) {
+                const int v = vb + sub;
+                const bool on = v < i1;
+                const int vv = on ? v : i1 - 1;
+                const int beg = a.rowptr[vv], cnt = a.rowptr[vv + 1] - beg;
+                int mx = cnt;
+                mx = max(mx, __shfl_xor(mx, 16));
+                mx = max(mx, __shfl_xor(mx, 32));
+                f32x4 s[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int base = 0; base < mx; base += 16) {
+                    const int my_e = (base + c < cnt) ? a.eid[beg + base + c] : 0;
+#pragma unroll
+                    for (int h8 = 0; h8 < 16; h8 += 8) {
+                        f32x4 x[8];
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) {
+                            const int e = __shfl(my_e, (l & 48) + h8 + kk);
+                            x[kk] = ld4wt(r_msg_in, ((unsigned)e * D + c * 4) * 4u);
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk)
+                            if (base + h8 + kk < cnt) s[kk & 3] += x[kk];   // ((h8 + kk) & 3 == kk & 3)
+                    }
+                }
+                const f32x4 tot = (s[0] + s[1]) + (s[2] + s[3]);   // the order of csr_rowsum_kernel's lane-group butterfly
+                if (on) st4wt(r_vagg, ((unsigned)v * D + c * 4) * 4u, tot);
+            }
+        }
+        drain_stores();
+        arrive(cnt_vagg(grp, p), (unsigned)(i1 - i0));
+        tr.mark(3);
+        tr.stamp(6, t == (T >> 1));
+    };
+
     if (role == 1) {
         // ------------------------------------------------------------------------------------------- edge workgroup
         constexpr int total = D * 4 * D;   // elements per piece of Kh
@@ -188,24 +303,8 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
         const __amdgpu_buffer_rsrc_t r_cs = make_rsrc(a.e_cs, (long long)a.n_slots * 16 * D * 4);
         const int total_items = n_items * T;
 
-        // The row-sum shares of this workgroup never change: their edge lists wait in LDS behind the per-tile words -- per
-        // share (item [5] = its block's offset in ints, < 0: none) 8 counts, then 8 x kShareCap edge ids.  A share with a
-        // vertex of more than kShareCap edges (or without a block) takes the general loop.
-        int* shl = reinterpret_cast<int*>(done + n_local);
-        for (int j = wave; j < n_items; j += kResWaves) {
-            const int* it = items + (size_t)(item0 + j) * kResItem;
-            const int v0 = __builtin_amdgcn_readfirstlane(it[0]), v1 = __builtin_amdgcn_readfirstlane(it[1]);
-            const int off = __builtin_amdgcn_readfirstlane(it[5]);
-            if (__builtin_amdgcn_readfirstlane(it[3]) != -1 || off < 0) continue;
-            int* blk = shl + off;
-            for (int q = 0; q < kShareRows; ++q) {
-                const int v = v0 + q;
-                const int beg = v < v1 ? a.rowptr[v] : 0;
-                const int cnt = v < v1 ? a.rowptr[v + 1] - beg : 0;
-                if (lane == 0) blk[q] = cnt;
-                if (lane < cnt && lane < kShareCap) blk[kShareRows + q * kShareCap + lane] = a.eid[beg + lane];
-            }
-        }
+        shl = reinterpret_cast<int*>(done + n_local);   // (an edge workgroup's share blocks: behind the per-tile words)
+        fill_share_blocks(item0, n_items);
         if (wave == 0) {    // all registrations in (see PLACEMENT above), then the verdict for the whole workgroup
             wait_ge(place + 8, (unsigned)a.n_active, dead, a.status);
             const unsigned bad = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_word(place + 9));
@@ -260,95 +359,10 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
 
             if (local < 0) {
                 // ---- a share of the V<-E row-sum over the messages of step t: vertex rows [i0, i1) of group grp
-                const int soff_i = __builtin_amdgcn_readfirstlane(it[5]);
+                const int soff_i = __builtin_amdgcn_readfirstlane(it[5]), e0 = __builtin_amdgcn_readfirstlane(it[6]);
                 flush();
-                const __amdgpu_buffer_rsrc_t r_msg_in = p ? r_msg1 : r_msg0;
-                const __amdgpu_buffer_rsrc_t r_vagg = p ? r_vagg1 : r_vagg0;
-                wait_ge(cnt_msg(grp, p), (unsigned)(((t + 1) >> 1) * gcnt), dead, a.status);
-                asm volatile("" ::: "memory");
-                tr.mark(2);
-                tr.stamp(5, chosen);
                 take_next();
-                const int l = opaque_lane();
-                const int sub = l >> 4, c = l & 15;
-                bool fast = soff_i >= 0;
-                const int* blk = shl + (soff_i >= 0 ? soff_i : 0);
-                if (fast) {
-#pragma unroll
-                    for (int q = 0; q < kShareRows; ++q) fast = fast && __builtin_amdgcn_readfirstlane(blk[q]) <= kShareCap;
-                }
-                if (fast) {
-                    // csr_rowsum_kernel's own form, two vertex rows at a time: lane group `sub` sums the edges k = sub (mod 4)
-                    // in ascending order -- every load of the pair in flight at once (a slot beyond the row's edges re-reads
-                    // edge 0 and is dropped) -- then the fixed butterfly
-                    constexpr int NL = kShareCap / 4;
-                    const int rows = i1 - i0;
-                    for (int q0 = 0; q0 < rows; q0 += 2) {
-                        f32x4 x[2][NL];
-                        int cn[2];
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int q = q0 + u < rows ? q0 + u : q0;
-                            cn[u] = __builtin_amdgcn_readfirstlane(blk[q]);
-                            const int* el = blk + kShareRows + q * kShareCap;
-#pragma unroll
-                            for (int m = 0; m < NL; ++m) {
-                                const int kk = 4 * m + sub;
-                                const int e = el[kk < cn[u] ? kk : 0];
-                                x[u][m] = ld4wt(r_msg_in, ((unsigned)e * D + c * 4) * 4u);
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int m = 0; m < NL; ++m) {
-                                const f32x4 add = 4 * m + sub < cn[u] ? x[u][m] : f32x4{0.f, 0.f, 0.f, 0.f};
-                                if (4 * m < cn[u]) s4 += add;   // (uniform: a row of fewer edges takes fewer additions, as csr_rowsum_kernel)
-                            }
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                s4[r] += __shfl_xor(s4[r], 16);
-                                s4[r] += __shfl_xor(s4[r], 32);
-                            }
-                            if (sub == 0 && q0 + u < rows) st4wt(r_vagg, ((unsigned)(i0 + q0 + u) * D + c * 4) * 4u, s4);
-                        }
-                    }
-                } else {
-                    for (int vb = i0; vb < i1; vb += 4) {
-                        const int v = vb + sub;
-                        const bool on = v < i1;
-                        const int vv = on ? v : i1 - 1;
-                        const int beg = a.rowptr[vv], cnt = a.rowptr[vv + 1] - beg;
-                        int mx = cnt;
-                        mx = max(mx, __shfl_xor(mx, 16));
-                        mx = max(mx, __shfl_xor(mx, 32));
-                        f32x4 s[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) s[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        for (int base = 0; base < mx; base += 16) {
-                            const int my_e = (base + c < cnt) ? a.eid[beg + base + c] : 0;
-#pragma unroll
-                            for (int h8 = 0; h8 < 16; h8 += 8) {
-                                f32x4 x[8];
-#pragma unroll
-                                for (int kk = 0; kk < 8; ++kk) {
-                                    const int e = __shfl(my_e, (l & 48) + h8 + kk);
-                                    x[kk] = ld4wt(r_msg_in, ((unsigned)e * D + c * 4) * 4u);
-                                }
-#pragma unroll
-                                for (int kk = 0; kk < 8; ++kk)
-                                    if (base + h8 + kk < cnt) s[kk & 3] += x[kk];   // ((h8 + kk) & 3 == kk & 3)
-                            }
-                        }
-                        const f32x4 tot = (s[0] + s[1]) + (s[2] + s[3]);   // the order of csr_rowsum_kernel's lane-group butterfly
-                        if (on) st4wt(r_vagg, ((unsigned)v * D + c * 4) * 4u, tot);
-                    }
-                }
-                drain_stores();
-                arrive(cnt_vagg(grp, p), (unsigned)(i1 - i0));
-                tr.mark(3);
-                tr.stamp(6, chosen);
+                do_share(i0, i1, grp, gcnt, soff_i, e0, t);
                 continue;
             }
 
@@ -540,19 +554,9 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
     // counter per group.  Every wavefront owns its tiles (wave, wave + 12) for the whole loop and waits for nobody but its
     // own tile's inputs.
     // tile s of this wavefront = tile (wave + s * waves) of the workgroup
-    int nt = 0;
-    int row0[kResVertTiles], nvalid[kResVertTiles], grp[kResVertTiles], gcnt[kResVertTiles];
-#pragma unroll
-    for (int s = 0; s < kResVertTiles; ++s) {
-        const int idx = wave + s * kResWaves;
-        const bool have = idx < n_items;
-        const int* it = items + (size_t)(item0 + (have ? idx : 0)) * kResItem;
-        row0[s] = __builtin_amdgcn_readfirstlane(it[0]);
-        nvalid[s] = __builtin_amdgcn_readfirstlane(it[1]);
-        grp[s] = __builtin_amdgcn_readfirstlane(it[2]);
-        gcnt[s] = __builtin_amdgcn_readfirstlane(it[4]);
-        if (have) nt = s + 1;
-    }
+    // A vertex wavefront's tiles: (wave + 12 s) of its workgroup, s = 0, 1, ...; ONE tile body per role, its parameters read per
+    // round (templated copies per tile slot cost registers across the whole kernel).
+    const int n_rounds = (n_items + kResWaves - 1) / kResWaves;
     const __amdgpu_buffer_rsrc_t r_vh0 = make_rsrc(a.vh[0], (long long)a.N * D * 4);
     const __amdgpu_buffer_rsrc_t r_vh1 = make_rsrc(a.vh[1], (long long)a.N * D * 4);
     if (role == 2) {
@@ -572,8 +576,10 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
             const __amdgpu_buffer_rsrc_t r_h_in = p ? r_vh1 : r_vh0;
             const __amdgpu_buffer_rsrc_t r_h_out = p ? r_vh0 : r_vh1;
             const float* c_in = t == 0 ? a.v_c0 : a.v_c;
-            auto cell = [&](auto J) {
-                constexpr int j = decltype(J)::value;
+            auto cell = [&](int idx) {
+                const int* it = items + (size_t)(item0 + idx) * kResItem;
+                const int row0_j = __builtin_amdgcn_readfirstlane(it[0]), nvalid_j = __builtin_amdgcn_readfirstlane(it[1]);
+                const int grp_j = __builtin_amdgcn_readfirstlane(it[2]), gcnt_j = __builtin_amdgcn_readfirstlane(it[4]);
                 // the part of z that does not wait: bias-init and h K[d:2d]
                 int rl, g;
                 {
@@ -581,8 +587,8 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                     rl = l & 15;
                     g = l >> 4;
                 }
-                const bool valid = rl < nvalid[j];
-                const unsigned rc = (unsigned)(row0[j] + (valid ? rl : 0));
+                const bool valid = rl < nvalid_j;
+                const unsigned rc = (unsigned)(row0_j + (valid ? rl : 0));
                 f32x4 ho[TPG];
                 if (t == 0) {
 #pragma unroll
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
 #pragma unroll
                     for (int q = 0; q < TPG; ++q) ho[q] = ld4wt(r_h_in, (rc * D + g * 4 + q * 16) * 4u);
                 }
-                wait_ge(cnt_vagg(grp[j], p), (unsigned)(((t >> 1) + 1) * gcnt[j]), dead, a.status);
+                wait_ge(cnt_vagg(grp_j, p), (unsigned)(((t >> 1) + 1) * gcnt_j), dead, a.status);
                 asm volatile("" ::: "memory");
                 tr.stamp(0, chosen);
                 f32x4 xo[TPG];
@@ -638,13 +644,15 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                 tr.mark(2);
                 if (!last) {
                     drain_stores();
-                    arrive(cnt_vh(grp[j], 1 - p), 1u);
+                    arrive(cnt_vh(grp_j, 1 - p), 1u);
                 }
                 tr.stamp(2, chosen);
                 tr.mark(3);
             };
-            if (nt > 0) cell(std::integral_constant<int, 0>{});
-            if (nt > 1) cell(std::integral_constant<int, 1>{});
+            for (int s_ = 0; s_ < n_rounds; ++s_) {
+                const int j = wave + s_ * kResWaves;
+                if (j < n_items) cell(j);
+            }
         }
         tr.flush();
         h2_range_report(a.range_flag, wit, vmin);
@@ -665,16 +673,18 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
             const bool chosen = t == (T >> 1);
             const __amdgpu_buffer_rsrc_t r_h = p ? r_vh0 : r_vh1;      // h' of step t lives in vh[1 - p]
             const __amdgpu_buffer_rsrc_t r_zx_out = p ? r_zx0 : r_zx1;
-            auto message = [&](auto J) {
-                constexpr int j = decltype(J)::value;
-                wait_ge(cnt_vh(grp[j], 1 - p), (unsigned)(((t >> 1) + 1) * gcnt[j]), dead, a.status);
+            auto message = [&](int idx) {
+                const int* it = items + (size_t)(item0 + idx) * kResItem;
+                const int row0_j = __builtin_amdgcn_readfirstlane(it[0]), nvalid_j = __builtin_amdgcn_readfirstlane(it[1]);
+                const int grp_j = __builtin_amdgcn_readfirstlane(it[2]), gcnt_j = __builtin_amdgcn_readfirstlane(it[4]);
+                wait_ge(cnt_vh(grp_j, 1 - p), (unsigned)(((t >> 1) + 1) * gcnt_j), dead, a.status);
                 asm volatile("" ::: "memory");
                 tr.mark(1);
                 tr.stamp(3, chosen);
                 const int l = opaque_lane();
                 const int rl = l & 15, g = l >> 4;
-                const bool valid = rl < nvalid[j];
-                const unsigned rc = (unsigned)(row0[j] + (valid ? rl : 0));
+                const bool valid = rl < nvalid_j;
+                const unsigned rc = (unsigned)(row0_j + (valid ? rl : 0));
                 f32x4 hn[TPG];
 #pragma unroll
                 for (int q = 0; q < TPG; ++q) hn[q] = ld4wt(r_h, (rc * D + g * 4 + q * 16) * 4u);
@@ -714,12 +724,14 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
                 gate(std::integral_constant<int, 3>{});
                 tr.mark(2);
                 drain_stores();
-                arrive(cnt_zx(grp[j], 1 - p), 1u);
+                arrive(cnt_zx(grp_j, 1 - p), 1u);
                 tr.mark(3);
                 tr.stamp(5, chosen);
             };
-            if (nt > 0) message(std::integral_constant<int, 0>{});
-            if (nt > 1) message(std::integral_constant<int, 1>{});
+            for (int s_ = 0; s_ < n_rounds; ++s_) {
+                const int j = wave + s_ * kResWaves;
+                if (j < n_items) message(j);
+            }
         }
         tr.flush();
         h2_range_report(a.range_flag, wit, 0xffffffffu);

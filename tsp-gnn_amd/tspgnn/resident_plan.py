@@ -13,7 +13,9 @@ rows are cut into 16-row tiles starting at the group's first row.  On top of tha
   * the vertex tiles of a class go to that class's CELL workgroups (role 2) and, once more, to its MESSAGE workgroups
     (role 3), <= 2 tiles per wavefront;
   * the V<-E row-sum of a group is cut into SHARES of <= SHARE_ROWS vertex rows, dealt to the edge workgroups that hold the
-    group's tiles in proportion to the tiles they hold.
+    group's tiles in proportion to the tiles they hold.  (Dealt to the class's VERTEX workgroups instead -- their wavefronts
+    idle through most of a step -- the step got LONGER, 59 vs 42 us at C2: 1.7 shares of ~13 us + 1.7 tiles per vertex
+    wavefront are a serial 40 us, and rounds of shares and tiles of different groups can wait for each other in a cycle.)
 
 Layout (int32): grid headers of HDR ints, then items of ITEM ints -- documented at the top of csrc/mp_resident_h2.hip.
 """
@@ -30,7 +32,7 @@ N_XCD = 8
 VERT_TILES = 2        # per wavefront
 SHARE_ROWS = int(os.environ.get("TSPGNN_RES_SHARE_ROWS", "8"))   # vertex rows per row-sum item (development override: needs a library built to match)
 SHARE_CAP = 48        # edge ids per vertex row of a share kept in LDS (TSPGNN_RESIDENT_SHARE_CAP)
-SHARE_BLOCK = SHARE_ROWS * (1 + SHARE_CAP)   # LDS words of a share's block: counts, then edge ids
+SHARE_BLOCK = SHARE_ROWS + SHARE_ROWS * SHARE_CAP // 2   # LDS words of a share's block: counts, then 16-bit edge offsets
 LDS_WORD_LIMIT = 11000  # LDS words per edge workgroup behind 113 KB of weights: one per tile + the shares' blocks
 
 _cache = {}
@@ -191,7 +193,7 @@ def _build(e_start, v_start, grid, classes, lead):
             local = 0
             g_first = None
             for c in range(len(parts)):
-                sh = [(s0, s1, gi, -1, int(et[gi])) for (s0, s1, gi) in shares[k][c]]
+                sh = [(s0, s1, gi, -1, int(et[gi]), 0, int(groups[gi][0])) for (s0, s1, gi) in shares[k][c]]
                 tl = []
                 for (r, nvld, gi) in slices[k][c]:
                     tl.append((r, nvld, gi, local, int(vt[gi])))
@@ -210,7 +212,7 @@ def _build(e_start, v_start, grid, classes, lead):
             for it in seq:
                 row = list(it) + [0] * (ITEM - len(it))
                 if it[3] == -1:    # a share: its edge lists wait in LDS while there is room (else the kernel's general loop)
-                    if words + SHARE_BLOCK <= LDS_WORD_LIMIT:
+                    if words + SHARE_BLOCK <= LDS_WORD_LIMIT and groups[it[2]][1] - groups[it[2]][0] < 65536:
                         row[5] = words - local
                         words += SHARE_BLOCK
                     else:
