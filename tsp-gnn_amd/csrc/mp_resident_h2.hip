@@ -63,7 +63,6 @@ constexpr int kResWaves = TSPGNN_RESIDENT_WAVES;
 constexpr int kResHdr = TSPGNN_RESIDENT_HDR_INTS;
 constexpr int kResItem = TSPGNN_RESIDENT_ITEM_INTS;
 constexpr int kResSlots = 32;       // groups per edge workgroup whose Zx counters are cached in LDS (others poll memory)
-constexpr int kResVertTiles = 2;
 constexpr int kShareRows = TSPGNN_RESIDENT_SHARE_ROWS;   // vertex rows per row-sum share
 constexpr int kShareCap = TSPGNN_RESIDENT_SHARE_CAP;     // edge ids per vertex row held in LDS
 // An LDS flag word, read / written RELAXED behind a compiler barrier.  The ordering the protocol needs comes from the hardware's
@@ -171,7 +170,6 @@ __global__ __launch_bounds__(kResWaves * 64) void mp_resident_h2_kernel(const ts
     // wait in LDS -- per share a block of kShareRows counts (int) + kShareRows x kShareCap edge ids as 16-bit offsets from the
     // group's first edge row (item [6]); item [5] = the block's offset in ints from `shl`, < 0: no block (the general loop).
     int* shl = nullptr;   // set by the role, behind what it keeps in LDS
-    constexpr int kShareBlockInts = kShareRows + kShareRows * kShareCap / 2;
     auto fill_share_blocks = [&](int first, int count) {
         for (int j = wave; j < count; j += kResWaves) {
             const int* it = items + (size_t)(first + j) * kResItem;
