@@ -12,7 +12,7 @@ SRC = os.path.join(ROOT, "gpurun_out", "r06")
 DST = os.path.join(ROOT, "profiles")
 KEEP = ["*_bench.json", "*_forward_kernel_stats.txt", "*_forward_timeline.txt", "*_loop_kernel_stats.txt", "*_resident_kernel_stats.txt", "c2_train_kernel_stats.txt",
         "c5_train_kernel_stats.txt", "train_variants.txt", "fuzz_parity.txt",
-        "loop_vs_steps.txt", "resident_vs_steps.txt", "resident_trace.txt", "stager_breakdown.txt", "grad_anchor_report.txt", "rowsum_once_bound.txt"]
+        "loop_vs_steps.txt", "resident_vs_steps.txt", "resident_trace.txt", "soak.txt", "stager_breakdown.txt", "grad_anchor_report.txt", "rowsum_once_bound.txt"]
 n = 0
 for pat in KEEP:
     for path in sorted(glob.glob(os.path.join(SRC, pat))):

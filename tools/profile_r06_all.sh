@@ -86,11 +86,14 @@ find $O -name "*.db" -delete
 RES_TRACE_XCD=0 timeout 300 python $R/tools/resident_trace.py 128 40 32 > $O/resident_trace.txt 2>&1
 timeout 300 python $R/tools/stager_breakdown.py 2>&1 | grep -v amdgpu > $O/stager_breakdown.txt
 ANCHORS=c2,c2t8,c1 GEMMS=f16x2,bf16x3,f32 TOP=5 timeout 900 python $R/tools/grad_anchor_report.py 2>&1 | grep -v amdgpu > $O/grad_anchor_report.txt
+{ echo "## GRAPHS=192 (default selector: tspgnn_mp_resident_h2)"; GRAPHS=192 NFWD=3000 NTRAIN=40 timeout 600 python $R/tools/soak.py 2>&1 | grep -v amdgpu; echo "## TSPGNN_LOOP_KIND=resident GRAPHS=128"; TSPGNN_LOOP_KIND=resident NFWD=5000 NTRAIN=40 timeout 600 python $R/tools/soak.py 2>&1 | grep -v amdgpu; echo "## GRAPHS=32 (register-resident loop)"; GRAPHS=32 NFWD=5000 NTRAIN=40 timeout 600 python $R/tools/soak.py 2>&1 | grep -v amdgpu; echo "## default C2"; NFWD=3000 NTRAIN=300 timeout 900 python $R/tools/soak.py 2>&1 | grep -v amdgpu; } > $O/soak.txt 2>&1
 timeout 400 python $R/tools/rowsum_once_bound.py 2>&1 | grep -v amdgpu > $O/rowsum_once_bound.txt
 # randomised parity sweeps: default path, the opt-in recomputing backward (both forms), bf16 storage, determinism
 {
 echo "## python tests/fuzz_parity.py 150 5"; timeout 900 python $R/tests/fuzz_parity.py 150 5 2>&1 | grep -v amdgpu | tail -12
 echo "## TSPGNN_RECOMPUTE=1 python tests/fuzz_parity.py 90 7   (recomputing message-MLP backward, weight gradients in the launch)"; TSPGNN_RECOMPUTE=1 timeout 900 python $R/tests/fuzz_parity.py 90 7 2>&1 | grep -v amdgpu | tail -8
+echo "## TSPGNN_LOOP_KIND=resident python tests/fuzz_parity.py 100 17   (every batch through the memory-resident one-launch loop)"; TSPGNN_LOOP_KIND=resident timeout 900 python $R/tests/fuzz_parity.py 100 17 2>&1 | grep -v amdgpu | tail -6
+echo "## TSPGNN_LOOP_KIND=loop TSPGNN_LOOP_MAX_TILES=4 python tests/fuzz_parity.py 100 19   (every batch through the register-resident loop)"; TSPGNN_LOOP_KIND=loop TSPGNN_LOOP_MAX_TILES=4 timeout 900 python $R/tests/fuzz_parity.py 100 19 2>&1 | grep -v amdgpu | tail -6
 echo "## BF16=1 python tests/fuzz_parity.py 60 11"; BF16=1 timeout 900 python $R/tests/fuzz_parity.py 60 11 2>&1 | grep -v amdgpu | tail -8
 echo "## DET=1 python tests/fuzz_parity.py 40 13"; DET=1 timeout 900 python $R/tests/fuzz_parity.py 40 13 2>&1 | grep -v amdgpu | tail -6
 echo "## DET=1 TSPGNN_RECOMPUTE=1 python tests/fuzz_parity.py 30 15"; DET=1 TSPGNN_RECOMPUTE=1 timeout 900 python $R/tests/fuzz_parity.py 30 15 2>&1 | grep -v amdgpu | tail -6
