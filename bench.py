@@ -863,6 +863,7 @@ def physical_cores():
                 elif line.startswith("core id"):
                     pairs.add((phys, line.split(":", 1)[1].strip()))
         if pairs:
+            physical_cores.sockets = len({p for p, _ in pairs})
             return min(len(pairs), os.cpu_count() or len(pairs))
     except OSError:
         pass
@@ -896,6 +897,7 @@ def run_cpu_baseline(d, batch, T, budget_s, M):
         pass
     steps_per_s = n / tn
     return {"value": round(steps_per_s, 4), "unit": "mp-steps/s", "cores": int(threads), "kind": "port",
+            "sockets": getattr(physical_cores, "sockets", None),   # (the GPU boxes: 2 x 64-core EPYC 9575F = 128 physical cores)
             "sample": "%d of %d message-passing steps of the full batch, dense EV[%d,%d] fp32 torch-CPU restatement "
                       "of the TF graph (oracle/torch_oracle.py), %.1f s" % (n, T, M, int(np.sum(n_vertices)), tn),
             "edges_per_s": round(steps_per_s * M, 1), "cpu": cpu_model}
