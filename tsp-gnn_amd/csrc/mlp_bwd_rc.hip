@@ -1,18 +1,17 @@
-// Message-MLP backward on the fp16 matrix cores (f16x2).  Three kernels share one chain -- masks, then G_l = dpre_l W_l^T
+// Message-MLP backward on the fp16 matrix cores (f16x2).  Two kernels share one chain -- masks, then G_l = dpre_l W_l^T
 // with every row normalised by a power of two and the second fp16 piece scaled into the normal range and accumulated apart
 // (split2s / kblock_h2_side, as the cells' dh = dz Kh^T in dense_bwd_h2.hip):
 //   mlp_bwd_h2_kernel   (tspgnn_mlp_bwd_multi_h2, the DEFAULT of the f16x2 and bf16 training steps): the TAPED backward --
 //                       masks from the saved activations, dpre written for the weight-gradient reduction, several MLPs per
 //                       launch, widths 64 and 128 -- replacing 3 x 256 (d = 64) v_mfma_f32_16x16x4_f32 per tile;
-//   mlp_bwd_rc_kernel   (tspgnn_mlp_bwd_rc_h2, opt-in): the hidden activations a_1 .. a_{L-1} are RECOMPUTED from the chain's
+//   mlp_bwd_rcw_kernel  (tspgnn_mlp_bwd_rc_h2, opt-in): the hidden activations a_1 .. a_{L-1} are RECOMPUTED from the chain's
 //                       input rows exactly as the f16x2 forward formed them (dense_layer_h2's arithmetic, same packed 2^s W,
 //                       same bias block: the relu masks are the forward's own; a_L, the messages, is read), so the training
-//                       forward tapes only the messages and can run the MLP inside the cell launch; a_l and dpre_l leave
-//                       through chunk buffers of the backward pass for wgrad_x3_kernel;
-//   mlp_bwd_rcw_kernel  (tspgnn_mlp_bwd_rc_task.partial, opt-in): the same with the weight gradients formed in the launch.
-// The taped form moves 205 MB per C2 step and is bound by them; the recomputing forms are parity-green and deterministic but
-// do not pay at C2 (DESIGN_HISTORY, round 5: 50 us and 82 us in the step against 50 + 27 us), hence opt-in
-// (GraphNN.recompute_messages / recompute_weight_gradients).
+//                       forward tapes only the messages and can run the MLP inside the cell launch; the weight gradients
+//                       a_l^T dpre_l are formed in the same launch (tspgnn_mlp_bwd_rc_task.partial).
+// The taped form moves 205 MB per C2 step and is bound by them; the recomputing form is parity-green and deterministic but does
+// not pay at C2 (81 us per launch; 11.6-11.7 against 11.1-11.2 ms per training step), hence opt-in (GraphNN.recompute_messages).
+// A third form, which handed the recomputed a_l and dpre_l to wgrad_x3_kernel through chunk buffers, was removed in round 6.
 #include "common.h"
 #include "bf16_tile.h"
 #include "h2_tile.h"
