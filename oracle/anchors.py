@@ -21,7 +21,10 @@ ANCHOR_ROWS = 512
 # BASELINE config 5 at one GPU's graph size and depth (n=200, d=128, T=64, bf16 embeddings / fp32 accumulate) on 4 of the 32
 # graphs of a shard: oracle = torch_oracle.forward(..., bf16=True), the float64 restatement with the build's rounding points
 # "c5shard": ALL 32 graphs of one GPU's shard of config 5 (M = 636 800 edges, the size `bench.py --workload c5` runs) at T = 8
-BF16_ANCHORS = {"c5": (lambda: [200] * 4, 128, 64), "c5shard": (lambda: [200] * 32, 128, 8)}   # (c5shard: T = 2 until round 6)
+# "c5full" (round 6): the whole shard at config 5's own depth, T = 64 -- exactly what `bench.py --workload c5` runs (40 minutes of
+# float64 on the build host)
+BF16_ANCHORS = {"c5": (lambda: [200] * 4, 128, 64), "c5shard": (lambda: [200] * 32, 128, 8),   # (c5shard: T = 2 until round 6)
+                "c5full": (lambda: [200] * 32, 128, 64)}
 
 
 def bf16_anchor_inputs(name):
