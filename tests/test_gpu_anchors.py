@@ -48,11 +48,12 @@ def test_full_size_forward_matches_float64_anchor(cuda_device, name, gemm):
         assert v < REL_TOL, (k, v)
 
 
-@pytest.mark.parametrize("name", ["c5", "c5shard"])
+@pytest.mark.parametrize("name", ["c5", "c5shard", "c5full"])
 def test_bf16_storage_at_config5_depth(cuda_device, name):
     """BASELINE config 5's mode (bf16 embeddings, fp32 accumulate) at ITS graph size, width and depth -- n=200, d=128,
     T=64 -- on 4 graphs of a shard (M = 79 600 edges; "c5"), and on ALL 32 graphs of one GPU's shard -- M = 636 800 edges,
-    the size `bench.py --workload c5` runs -- at T = 2 ("c5shard"), against committed outputs of the oracle that rounds to
+    the size `bench.py --workload c5` runs -- at T = 8 ("c5shard") and at config 5's own T = 64 ("c5full": exactly the benchmark's
+    workload, 40 minutes of float64 on the build host), against committed outputs of the oracle that rounds to
     bf16 at the same points (oracle/torch_oracle.message_passing_bf16; minutes of float64 on the build host: anchors).
     Two kinds of bars: the bulk of the values (rms, relative to the tensor's largest entry) must agree to a small
     fraction of a bf16 ulp; single entries may land on the other side of a rounding boundary and then differ by whole
