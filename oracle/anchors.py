@@ -74,7 +74,8 @@ def anchor_rows(n_rows):
 # every variable entry moves by ONE fp32 ulp (w * (1 +- 2^-23), random signs, GRAD_PERTURBATIONS draws).  An fp32-class
 # backward cannot be asked for less than that -- it computes the exact gradient of a network whose weights are a rounding
 # away -- and tests/test_gpu_anchors.py asks every arithmetic for 2x that, with no arithmetic-specific allowance.
-GRAD_ANCHORS = {"c2": (lambda: [40] * 128, 2), "c1": (lambda: [20] * 32, 8), "c2t8": (lambda: [40] * 128, 8)}
+GRAD_ANCHORS = {"c2": (lambda: [40] * 128, 2), "c1": (lambda: [20] * 32, 8), "c2t8": (lambda: [40] * 128, 8),
+                "c4": (lambda: [int(x) for x in np.random.RandomState(0).randint(20, 81, size=512)], 2)}   # (ragged, M = 695 849)
 GRAD_SAMPLES = 64
 GRAD_PERTURBATIONS = 3
 

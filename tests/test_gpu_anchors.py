@@ -97,9 +97,10 @@ def test_bf16_storage_at_config5_depth(cuda_device, name):
 
 
 @pytest.mark.parametrize("gemm", ["f16x2", "bf16x3"])
-@pytest.mark.parametrize("name", ["c2", "c2t8", "c1"])
+@pytest.mark.parametrize("name", ["c2", "c2t8", "c1", "c4"])
 def test_full_size_gradients_match_float64_anchor(cuda_device, name, gemm):
-    """The training step's gradients at FULL size -- C2 (M = 99 840 edges) at T = 2 and at T = 8, C1 at its own T = 8 --
+    """The training step's gradients at FULL size -- C2 (M = 99 840 edges) at T = 2 and at T = 8, C1 at its own T = 8, C4 (512
+    ragged instances, M = 695 849 edges) at T = 2 --
     against committed float64 autograd gradients (tests/golden/anchor_grad_*.npz, oracle/gen_golden.py grads): per variable
     the 2-norm and 64 sampled entries.  ONE bar for every arithmetic (no arithmetic-specific slack), per
     variable, relative to max(its largest entry, 1e-3 of the largest gradient entry overall):
