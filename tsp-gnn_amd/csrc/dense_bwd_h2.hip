@@ -69,20 +69,55 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
     const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
     const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
     // static round-robin over the workgroup's tiles (not a ticket): which tiles a wavefront sums into its
-    // LayerNorm-gradient slab must not depend on timing, or the gradients differ in the last bit from run to run
-    for (int tile = t_beg + wave; tile < t_end; tile += nw) {
+    // LayerNorm-gradient slab must not depend on timing, or the gradients differ in the last bit from run to run.
+    //
+    // The tile loop is software-pipelined: with ~215 registers a SIMD holds two wavefronts, so a tile's memory round trips
+    // (endpoints -> projected messages -> h rows) are not hidden by other wavefronts (traced: 3.4 + 4.5 of a tile's 26 us
+    // were those waits).  A tile therefore arrives at the top of its iteration with its operands in flight or in registers:
+    // the endpoints of the NEXT tile are fetched at the top of this one, its h rows and its
+    // projected messages Zx[u] (into acc) and Zx[v] (into zvn) behind the k-blocks of this tile's dh GEMM, as the
+    // registers of dz are consumed.
+    constexpr int KBH = D / 32;
+    f32x4 acc[NT4], zvn[NT4], hpre[2 * KBH];
+    const bool gather = uv != nullptr;
+    int tile = t_beg + wave;
+    unsigned rc_n = 0;
+    int2 ends_n = {0, 0};
+#pragma unroll
+    for (int t = 0; t < NT4; ++t) acc[t] = zvn[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2 * KBH; ++i) hpre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tile < t_end) {
         const int row = tile * 16 + rl;
-        const bool valid = row < rows;
-        const unsigned rc = (unsigned)(valid ? row : rows - 1);
-        f32x4 acc[NT4];
-        if (uv != nullptr) {  // gather-init mode: Zx as the f16x2 projection wrote it (2^s Zx, blocked by 16 rows)
-            const int2 ends = uv[rc];
+        rc_n = (unsigned)(row < rows ? row : rows - 1);
+        if (gather) {
+            const int2 ends = uv[rc_n];
             const float* zu = Zx + h2_zx_row<D>((unsigned)ends.x, g);
             const float* zv = Zx + h2_zx_row<D>((unsigned)ends.y, g);
 #pragma unroll
             for (int t = 0; t < NT4; ++t) acc[t] = ld4(zu + t * 256);
 #pragma unroll
-            for (int t = 0; t < NT4; ++t) acc[t] += ld4(zv + t * 256);
+            for (int t = 0; t < NT4; ++t) zvn[t] = ld4(zv + t * 256);
+        }
+        const float* hrow = h + (rc_n * D + g * 4);
+#pragma unroll
+        for (int kb = 0; kb < KBH; ++kb) {
+            hpre[2 * kb] = ld4(hrow + kb * 32);
+            hpre[2 * kb + 1] = ld4(hrow + kb * 32 + 16);
+        }
+    }
+    for (; tile < t_end; tile += nw) {
+        const unsigned rc = rc_n;
+        const bool valid = tile * 16 + rl < rows;
+        const bool has_n = tile + nw < t_end;   // (wavefront-uniform)
+        if (has_n) {
+            const int row_n = (tile + nw) * 16 + rl;
+            rc_n = (unsigned)(row_n < rows ? row_n : rows - 1);
+            if (gather) ends_n = uv[rc_n];
+        }
+        if (gather) {  // gather-init mode: Zx as the f16x2 projection wrote it (2^s Zx, blocked by 16 rows)
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] += zvn[t];
         } else if (zbias != nullptr) {  // the forward's bias-init: z starts at 2^s * zscale[row] * zbias
             const float sc = zscale[rc] * kH2Scale;
 #pragma unroll
@@ -97,14 +132,20 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
         lstm_tile_load<D>(c + o, dh_out ? dh_out + o : nullptr, dc_out_in ? dc_out_in + o : nullptr, cf, dhn, dcn);
         {
             const float* xrow = x + (rc * (unsigned)dx + g * 4);
-            const float* hrow = h + (rc * D + g * 4);
-            for (int kb = 0; kb < KBT; ++kb) {
-                const float* src = kb < KBX ? xrow + kb * 32 : hrow + (kb - KBX) * 32;
-                const f32x4 lo4 = ld4(src), hi4 = ld4(src + 16);
+            for (int kb = 0; kb < KBX; ++kb) {
+                const f32x4 lo4 = ld4(xrow + kb * 32), hi4 = ld4(xrow + kb * 32 + 16);
                 float xv[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
                 f16x8 bh, bl;
                 split2(xv, bh, bl);
                 kblock_h2<NT4>(acc, lds_k, lds_k + k_total, kb, g, rl, bh, bl);
+            }
+#pragma unroll
+            for (int kb = 0; kb < KBH; ++kb) {
+                const f32x4 lo4 = hpre[2 * kb], hi4 = hpre[2 * kb + 1];
+                float xv[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                f16x8 bh, bl;
+                split2(xv, bh, bl);
+                kblock_h2<NT4>(acc, lds_k, lds_k + k_total, KBX + kb, g, rl, bh, bl);
             }
         }
         f32x4 dco[TPG];
@@ -121,6 +162,17 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
 #pragma unroll
             for (int t = 0; t < TPG; ++t) st4(dc_in + o + t * 16, dco[t]);
         }
+        {  // the next tile's h rows fly behind this tile's dh GEMM (the last tile re-reads its own)
+            const float* hrow = h + (rc_n * D + g * 4);
+#pragma unroll
+            for (int kb = 0; kb < KBH; ++kb) {
+                hpre[2 * kb] = ld4(hrow + kb * 32);
+                hpre[2 * kb + 1] = ld4(hrow + kb * 32 + 16);
+            }
+        }
+        const bool pre = gather && has_n;
+        const float* zu_n = Zx + h2_zx_row<D>((unsigned)ends_n.x, g);
+        const float* zv_n = Zx + h2_zx_row<D>((unsigned)ends_n.y, g);
         if (KT != nullptr) {
             // dh = dz' (2^s Kh)^T with the row of dz' normalised to [0.5, 1) by a power of two
             float m = 0.f;
@@ -144,6 +196,14 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
                 for (int j = 0; j < 8; ++j) xv[j] = acc[2 * kb + (j >> 2)][j & 3] * up;
                 f16x8 bh, bm;
                 split2s(xv, bh, bm);
+                if (pre) {  // the two dz tiles just consumed make room for the next tile's projected messages
+                    acc[2 * kb] = ld4(zu_n + (2 * kb) * 256);
+                    acc[2 * kb + 1] = ld4(zu_n + (2 * kb + 1) * 256);
+                    zvn[2 * kb] = ld4(zv_n + (2 * kb) * 256);
+                    zvn[2 * kb + 1] = ld4(zv_n + (2 * kb + 1) * 256);
+                } else {    // (defined on every path: nothing of the old contents stays live across the tile)
+                    acc[2 * kb] = acc[2 * kb + 1] = zvn[2 * kb] = zvn[2 * kb + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
                 kblock_h2_side<TPG>(out, side, lds_kt, lds_kt + kt_total, kb, g, rl, bh, bm);
             }
             if (valid) {
@@ -156,6 +216,14 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
                     st4(dxh + (size_t)rc * D + t * 16 + g * 4, v);
                 }
             }
+        } else if (pre) {
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] = ld4(zu_n + t * 256);
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) zvn[t] = ld4(zv_n + t * 256);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) acc[t] = zvn[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     // workgroup partial of the LayerNorm parameter gradients: fixed-order sum over the wavefront slabs

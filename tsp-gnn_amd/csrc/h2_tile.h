@@ -155,13 +155,13 @@ __device__ __forceinline__ void st4o(float* p, f32x4 v) {
 // (NT_TOTAL = column tiles of the packed matrix, [T0, T0 + NT) = the tiles this call multiplies: a kernel that forms z one
 // gate (pair) at a time passes a slice; per output tile the three MFMAs and their order are those of the whole-matrix
 // call, so the results are bit-identical.)
-template <int NT_TOTAL, int T0, int NT>
+template <int NT_TOTAL, int T0, int NT, int PFW = H2_PF>
 __device__ __forceinline__ void kblock_h2_sub(f32x4 (&acc)[NT], const _Float16* wh, const _Float16* wl, int kb, int g, int jl,
                                               const f16x8& bh, const f16x8& bl) {
     const int off = ((kb * 4 + g) * NT_TOTAL * 16 + jl) * 8 + T0 * 128;
     // The fragments of the next PF tiles are in flight while the three MFMAs of this one run (the compiler interleaves
-    // the MFMA chains of neighbouring tiles on top of that).
-    constexpr int PF = H2_PF < NT ? H2_PF : NT;
+    // the MFMA chains of neighbouring tiles on top of that).  PFW: a call site with registers to spare asks for more.
+    constexpr int PF = PFW < NT ? PFW : NT;
     f16x8 ah[PF + 1], al[PF + 1];
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
@@ -221,11 +221,11 @@ __device__ __forceinline__ void kblock_h2_multi(f32x4 (&acc)[NP][NT], const _Flo
 
 // kblock_h2 for a B operand split by split2s: acc += (W_lo + W_hi) x B_hi, side += W_hi x B_m; the caller folds
 // acc + 2^-11 * side.  Three MFMAs per product, as kblock_h2.
-template <int NT>
+template <int NT, int PFW = H2_PF>
 __device__ __forceinline__ void kblock_h2_side(f32x4 (&acc)[NT], f32x4 (&side)[NT], const _Float16* wh, const _Float16* wl,
                                                int kb, int g, int jl, const f16x8& bh, const f16x8& bm) {
     const int off = ((kb * 4 + g) * NT * 16 + jl) * 8;
-    constexpr int PF = H2_PF < NT ? H2_PF : NT;
+    constexpr int PF = PFW < NT ? PFW : NT;
     f16x8 ah[PF + 1], al[PF + 1];
 #pragma unroll
     for (int p = 0; p < PF; ++p) {

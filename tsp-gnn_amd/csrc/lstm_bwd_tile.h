@@ -38,25 +38,45 @@ __device__ __forceinline__ float ln_normalize(f32x4 (&v)[TPG], int D, float eps 
 
 // LayerNorm backward of one gate: dn = gradient w.r.t. the LN output, xhat = normalised input.
 // Overwrites dn with the gradient w.r.t. the LN input and adds this tile's contribution to the
-// wavefront's (dgamma, dbeta) slab: sums over the tile's 16 rows by DPP row rotation, one ds_add per
-// feature from the lanes rl == 0.
+// wavefront's (dgamma, dbeta) slab: the sums over the tile's 16 rows are reduce-scatters over the DPP row (sixteen
+// per-lane values at a time, row16_reduce_scatter), after which lane rl holds the total of ONE feature and every lane
+// issues one ds_add.
 template <int TPG, bool SWAP = false>
 __device__ __forceinline__ void ln_backward(f32x4 (&dn)[TPG], const f32x4 (&xhat)[TPG], float rstd,
                                             const float* gamma, float* slab_dgamma, float* slab_dbeta, int g, int rl,
                                             bool valid, int D) {
+    constexpr int NV = 4 * TPG;               // values per lane and quantity (8, 16 or 32)
+    static_assert(NV == 8 || NV % 16 == 0, "ln_backward: D must be 32 or a multiple of 64");
+    if constexpr (NV == 8) {                  // one pass: [d xhat | d] of the lane's eight values
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float d_ = valid ? dn[i >> 2][i & 3] : 0.f;
+            v[i] = d_ * xhat[i >> 2][i & 3];
+            v[8 + i] = d_;
+        }
+        const float tot = row16_reduce_scatter(v, rl);
+        const int i = rl & 7;
+        atomicAdd((rl & 8 ? slab_dbeta : slab_dgamma) + (i >> 2) * 16 + g * 4 + (i & 3), tot);   // wavefront-private slab
+    } else {
+        const int f = (rl >> 2) * 16 + g * 4 + (rl & 3);
+#pragma unroll
+        for (int c = 0; c < NV / 16; ++c) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = valid ? dn[4 * c + (i >> 2)][i & 3] * xhat[4 * c + (i >> 2)][i & 3] : 0.f;
+            atomicAdd(slab_dgamma + c * 64 + f, row16_reduce_scatter(v, rl));                     // ds_add_f32
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = valid ? dn[4 * c + (i >> 2)][i & 3] : 0.f;
+            atomicAdd(slab_dbeta + c * 64 + f, row16_reduce_scatter(v, rl));
+        }
+    }
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
     for (int t = 0; t < TPG; ++t) {
         const f32x4 ga = ld4(gamma + t * 16 + g * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float d_ = valid ? dn[t][r] : 0.f;
-            const float sg = row16_sum(d_ * xhat[t][r]);
-            const float sb = row16_sum(d_);
-            if (rl == 0) {
-                atomicAdd(slab_dgamma + t * 16 + g * 4 + r, sg);  // ds_add_f32, wavefront-private slab
-                atomicAdd(slab_dbeta + t * 16 + g * 4 + r, sb);
-            }
             const float dxh = dn[t][r] * ga[r];
             dn[t][r] = dxh;
             m1 += dxh;

@@ -344,4 +344,24 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Sums of SIXTEEN per-lane values over the 16 lanes of a DPP row at once: a reduce-scatter by XOR partners (masks 15, 7, 3, 1
+// = row_mirror, row_half_mirror, quad_perm [3,2,1,0], quad_perm [1,0,3,2]; each step a lane keeps the half of its values its
+// own bit selects and adds the partner's copy of that half).  Lane rl of the row ends with the total of v[rl]: 15 DPP
+// additions + 30 selects for sixteen sums where row16_sum spends 64 dependent rotate-and-adds.  Fixed order (deterministic).
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_reduce_scatter(const float (&v)[16], int rl) {
+    const bool b3 = (rl & 8) != 0, b2 = (rl & 4) != 0, b1 = (rl & 2) != 0, b0 = (rl & 1) != 0;
+    float w[8], u[4], q[2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) w[m] = (b3 ? v[m + 8] : v[m]) + dpp_row<0x140>(b3 ? v[m] : v[m + 8]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) u[m] = (b2 ? w[m + 4] : w[m]) + dpp_row<0x141>(b2 ? w[m] : w[m + 4]);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) q[m] = (b1 ? u[m + 2] : u[m]) + dpp_row<0x1b>(b1 ? u[m] : u[m + 2]);
+    return (b0 ? q[1] : q[0]) + dpp_row<0xb1>(b0 ? q[0] : q[1]);
+}
+
 }  // namespace tspgnn
