@@ -32,9 +32,11 @@ extern "C" {
 #define TSPGNN_EINVAL (-1)      /* bad argument (null pointer, negative size, unsupported d) */
 #define TSPGNN_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
 
-#define TSPGNN_ABI_VERSION 4   /* 2: range_flag in the task structures, pack_weights_h2 / adam_clip_step arguments;
+#define TSPGNN_ABI_VERSION 5   /* 2: range_flag in the task structures, pack_weights_h2 / adam_clip_step arguments;
                                   3: tspgnn_mp_loop_h2 (the whole T-step loop as one launch);
-                                  4: tspgnn_mp_resident_h2 (the loop as one launch, states through memory) */
+                                  4: tspgnn_mp_resident_h2 (the loop as one launch, states through memory);
+                                  5: tspgnn_lstm_bwd_task.KTg / dxg, tspgnn_mlp_bwd_task.pre_X / pre_wt / pre_k (the vertex
+                                     side's data-gradient GEMMs inside the step's two backward launches) */
 
 /* ABI version of the loaded library (== TSPGNN_ABI_VERSION of the header it was built from). */
 int tspgnn_version(void);
@@ -485,6 +487,11 @@ typedef struct tspgnn_lstm_bwd_task {
     const float* zbias; const float* zscale; /* _h2 entry point only (the others require NULL): the forward's z started at
                                              zscale[row] * zbias[4d] (tspgnn_lstm_task: a bias folded through a row-sum
                                              aggregation); the recomputation of z starts there too */
+    const void* KTg; float* dxg;          /* _h2 entry point only (the others require NULL), d == dx == 64, no KT, no uv: the
+                                             data gradient [dxg[rows,dx] | dxh[rows,d]] = dz K^T in the same launch for a cell
+                                             whose K^T cannot stay in LDS beside K: KTg = tspgnn_pack_weights_h2(K^T[4d, dx+d])
+                                             in device memory, its fragments streamed through the L2 (few rows: the vertex
+                                             cell).  Replaces one tspgnn_linear_f32 launch per time step */
 } tspgnn_lstm_bwd_task;   /* fields as the arguments of tspgnn_lnlstm_bwd_f32 / tspgnn_lnlstm_gather_bwd_f32 */
 
 typedef struct tspgnn_mlp_bwd_task {
@@ -495,6 +502,12 @@ typedef struct tspgnn_mlp_bwd_task {
                                              (EV x dY, graphnn.py:156-160 with adjoint_a) without materialising it */
     int acts_bf16;                        /* != 0: acts (and Yout) are bf16 arrays -- the tape of the bf16-storage mode; they
                                              only decide the relu masks.  The tasks of one launch share the flag */
+    const float* pre_X; const void* pre_wt; int pre_k;
+                                          /* _h2 entry point only (the others require NULL), d == 64, no uv: the chain starts
+                                             from dY = pre_X[rows, pre_k] P^T instead of reading dY (then unused, may be
+                                             NULL): pre_wt = tspgnn_pack_weights_h2(P^T[pre_k, d]) in device memory, fragments
+                                             streamed through the L2; pre_k a multiple of 32, at most 256.  The vertex side of
+                                             a folded cell input: dY = dZx Kx^T without its own tspgnn_linear_f32 launch */
 } tspgnn_mlp_bwd_task;    /* fields as the arguments of tspgnn_mlp_bwd_f32 (uv = NULL there) */
 
 int tspgnn_lnlstm_bwd_multi_f32(const tspgnn_lstm_bwd_task* tasks, int n_tasks, int d, void* stream);

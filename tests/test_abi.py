@@ -68,7 +68,7 @@ def test_abi_version_and_struct_layouts_agree(tmp_path):
 
 
 def test_version_and_error_string():
-    assert _lib.lib.tspgnn_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib.tspgnn_version() == _lib.ABI_VERSION == 5
     status = _lib.lib.tspgnn_gather2_sum_f32(None, None, None, 4, 4, 3, None)   # d=3: rejected before launch
     assert status == -1
     assert b"multiple of 4" in _lib.lib.tspgnn_last_error()

@@ -676,3 +676,90 @@ def test_mlp_backward_h2_rows_of_subnormal_and_zero_gradients(cuda_device):
     G = dY.astype(np.float64) @ Ws[1].astype(np.float64).T
     G = (G * (acts[0] > 0)) @ Ws[0].astype(np.float64).T
     assert rel_err(out[8:], G[8:]) < 4 * TOL
+
+
+@pytest.mark.parametrize("rows", [1, 333, 5120])
+def test_lnlstm_backward_h2_streamed_data_gradient(cuda_device, rows):
+    """tspgnn_lstm_bwd_task.KTg: [dxg | dxh] = dz K^T formed in the launch (second phase of the task's workgroups, K^T in
+    K's place) -- beside a second task without it in the same launch, bias-init mode as the pushed vertex cell runs it:
+    dz, dc bit-identical to the launch without KTg, the data gradient against float64 arithmetic on the dz the kernel
+    wrote, row by row (incoming gradients spread over twelve orders of magnitude)."""
+    d = dx = 64
+    rng = np.random.RandomState(rows)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    x, h, c = f32(rng.randn(rows, dx)), f32(rng.randn(rows, d)), f32(rng.randn(rows, d))
+    K = f32(rng.randn(dx + d, 4 * d) / np.sqrt(dx + d))
+    ln = f32(np.stack([np.stack([1 + 0.2 * rng.randn(d), 0.2 * rng.randn(d)]) for _ in range(5)]))
+    zb, zs = f32(0.1 * rng.randn(1, 4 * d)), f32(rng.randint(1, 40, rows))
+    row_scale = 10.0 ** rng.uniform(-9, 3, size=(rows, 1))
+    dh_o, dc_o = f32(row_scale * rng.randn(rows, d)), f32(row_scale * rng.randn(rows, d))
+    xd, hd, cd, lnd = dev(x, cuda_device), dev(h, cuda_device), dev(c, cuda_device), dev(ln, cuda_device)
+    dhd, dcd, zbd, zsd = dev(dh_o, cuda_device), dev(dc_o, cuda_device), dev(zb, cuda_device), dev(zs, cuda_device)
+    Kp, KTp = packed_h2(K, cuda_device), packed_h2(np.ascontiguousarray(K.T), cuda_device)
+    outs = {}
+    for fused in (False, True):
+        dz, dc_in = empty((rows, 4 * d), cuda_device), empty((rows, d), cuda_device)
+        dxo, dho = empty((rows, dx), cuda_device, 7.0), empty((rows, d), cuda_device, 7.0)
+        ln_grad = empty((10 * d,), cuda_device, 0.0)
+        wsl = ws("tspgnn_lnlstm_bwd_workspace_floats", d, device=cuda_device)
+        task = _lib.LstmBwdTask(_lib.ptr(xd), dx, _lib.ptr(hd), _lib.ptr(cd), _lib.ptr(Kp), _lib.ptr(lnd), _lib.ptr(dhd),
+                                _lib.ptr(dcd), _lib.ptr(dz), _lib.ptr(dc_in), _lib.ptr(ln_grad), _lib.ptr(wsl), rows, None, None,
+                                None, _lib.ptr(dho) if fused else None, 0, _lib.ptr(zbd), _lib.ptr(zsd),
+                                _lib.ptr(KTp) if fused else None, _lib.ptr(dxo) if fused else None)
+        # a second, plain task beside it (the launch sizes LDS and splits workgroups over both)
+        r2 = min(77, rows)
+        dz2, dc2, lg2 = empty((r2, 4 * d), cuda_device), empty((r2, d), cuda_device), empty((10 * d,), cuda_device, 0.0)
+        ws2 = ws("tspgnn_lnlstm_bwd_workspace_floats", d, device=cuda_device)
+        other = _lib.LstmBwdTask(_lib.ptr(xd), dx, _lib.ptr(hd), _lib.ptr(cd), _lib.ptr(Kp), _lib.ptr(lnd), None, _lib.ptr(dcd),
+                                 _lib.ptr(dz2), _lib.ptr(dc2), _lib.ptr(lg2), _lib.ptr(ws2), r2, None, None, None, None, 0)
+        _lib.call_multi("tspgnn_lnlstm_bwd_multi_h2", [other, task], d)
+        torch.cuda.synchronize()
+        outs[fused] = [t.cpu().numpy() for t in (dz, dc_in, ln_grad, dxo, dho, dz2)]
+    for a, b in zip(outs[True][:3] + outs[True][5:], outs[False][:3] + outs[False][5:]):
+        assert np.array_equal(a, b)
+    want = outs[True][0].astype(np.float64) @ K.astype(np.float64).T
+    got = np.concatenate([outs[True][3], outs[True][4]], axis=1).astype(np.float64)
+    scale = np.maximum(np.abs(want).max(axis=1, keepdims=True), 1e-300)
+    assert (np.abs(got - want) / scale).max() < 2 * TOL
+
+
+@pytest.mark.parametrize("rows,k", [(1, 256), (333, 256), (5120, 256), (100, 64)])
+def test_mlp_backward_h2_projected_head(cuda_device, rows, k):
+    """tspgnn_mlp_bwd_task.pre_X: the chain starts from dY = pre_X P^T formed inside the launch (P^T resident in LDS behind
+    the layers' weights) -- beside a plain task in the same launch; dX and the pre-activation gradients against float64
+    arithmetic from pre_X, row by row, with row scales spread over nine decades."""
+    d, L, mask = 64, 4, 0b0111
+    rng = np.random.RandomState(rows + k)
+    Ws = [(rng.randn(d, d) / np.sqrt(d)).astype(np.float32) for _ in range(L)]
+    P = (rng.randn(d, k) / np.sqrt(d)).astype(np.float32)           # y P = projected message: dY = dZx P^T
+    acts = rng.randn(L - 1, rows, d).astype(np.float32)
+    X = (rng.randn(rows, k) * 10.0 ** rng.uniform(-8, 1, (rows, 1))).astype(np.float32)
+    G = X.astype(np.float64) @ P.astype(np.float64).T
+    want = [None] * L
+    for l in range(L - 1, -1, -1):
+        if (mask >> l) & 1:
+            G = G * (acts[l] > 0)
+        want[l] = G
+        G = G @ Ws[l].astype(np.float64).T
+    wt = _h2_blocks(Ws, [None] * L, cuda_device, transposed=True)
+    pw = packed_h2(np.ascontiguousarray(P.T), cuda_device)          # pack_weights_h2(P^T [k, d])
+    dpre, dX = empty((L, rows, d), cuda_device, 7.0), empty((rows, d), cuda_device, 7.0)
+    task = _lib.MlpBwdTask(None, _lib.ptr(wt), _lib.ptr(dev(acts, cuda_device)), rows * d, None, _lib.ptr(dpre), rows * d,
+                           _lib.ptr(dX), 0, rows, L, mask, None, 0, _lib.ptr(dev(X, cuda_device)), _lib.ptr(pw), k)
+    r2 = 500
+    dY2 = rng.randn(r2, d).astype(np.float32)
+    dX2 = empty((r2, d), cuda_device, 7.0)
+    plain = _lib.MlpBwdTask(_lib.ptr(dev(dY2, cuda_device)), _lib.ptr(wt), None, 0, None, None, 0, _lib.ptr(dX2), 0, r2, 1, 0,
+                            None, 0)
+    _lib.call_multi("tspgnn_mlp_bwd_multi_h2", [plain, task], d)
+    torch.cuda.synchronize()
+    scale = np.maximum(np.abs(G).max(1, keepdims=True), 1e-300)
+    assert (np.abs(dX.cpu().numpy() - G) / scale).max() < 4 * TOL
+    for l, ref in enumerate(want):
+        scale = np.maximum(np.abs(ref).max(1, keepdims=True), 1e-300)
+        assert (np.abs(dpre[l].cpu().numpy() - ref) / scale).max() < 2 * TOL, ("dpre", l)
+    ref2 = dY2.astype(np.float64) @ Ws[0].astype(np.float64).T
+    assert rel_err(dX2.cpu().numpy(), ref2) < TOL
+    # the f32 entry point refuses the field
+    with pytest.raises(_lib.TspgnnError):
+        _lib.call_multi("tspgnn_mlp_bwd_multi_f32", [task], d)

@@ -895,7 +895,7 @@ extern "C" int tspgnn_lnlstm_bwd_multi_f32(const tspgnn_lstm_bwd_task* tasks, in
                        "lnlstm_bwd: null pointer");
         TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx && (d == 32 || d == 64)),
                        "lnlstm_bwd: gather-init mode needs dx == 0, Zx and d in {32,64}");
-        TSPGNN_REQUIRE(!t.zbias, "lnlstm_bwd: a bias-init z is an f16x2 feature (tspgnn_lnlstm_bwd_multi_h2)");
+        TSPGNN_REQUIRE(!t.zbias && !t.KTg, "lnlstm_bwd: a bias-init z / a streamed data gradient are f16x2 features (tspgnn_lnlstm_bwd_multi_h2)");
         live[n++] = t;
     }
     if (n == 0) return TSPGNN_OK;
@@ -947,6 +947,7 @@ extern "C" int tspgnn_mlp_bwd_multi_f32(const tspgnn_mlp_bwd_task* tasks, int n_
         TSPGNN_REQUIRE(!inner || t.acts, "mlp_bwd: relu layers need the saved activations");
         TSPGNN_REQUIRE(!((t.relu_mask >> (t.n_layers - 1)) & 1u) || t.Yout, "mlp_bwd: relu on the last layer needs Yout");
         TSPGNN_REQUIRE(n == 0 || (t.acts_bf16 != 0) == (live[0].acts_bf16 != 0), "mlp_bwd: the tasks of a launch share acts_bf16");
+        TSPGNN_REQUIRE(!t.pre_X, "mlp_bwd: pre_X is an f16x2 feature (tspgnn_mlp_bwd_multi_h2)");
         live[n++] = t;
     }
     if (n == 0) return TSPGNN_OK;

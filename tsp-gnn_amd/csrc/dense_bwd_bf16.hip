@@ -319,7 +319,7 @@ extern "C" int tspgnn_lnlstm_bwd_multi_bf16(const tspgnn_lstm_bwd_task* tasks, i
         TSPGNN_REQUIRE(t.h && t.c && t.K && t.ln && t.dz && t.dc_in && t.ln_grad && t.workspace && (t.dx == 0 || t.x),
                        "lnlstm_bwd_bf16: null pointer");
         TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx), "lnlstm_bwd_bf16: gather-init mode needs dx == 0 and Zx");
-        TSPGNN_REQUIRE(!t.KT && !t.dxh && !t.zbias, "lnlstm_bwd_bf16: no fused data gradient / bias-init in this mode");
+        TSPGNN_REQUIRE(!t.KT && !t.dxh && !t.zbias && !t.KTg, "lnlstm_bwd_bf16: no fused data gradient / bias-init in this mode");
         live[n++] = t;
     }
     if (n == 0) return TSPGNN_OK;

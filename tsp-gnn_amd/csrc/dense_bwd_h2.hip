@@ -46,9 +46,11 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
     float* __restrict__ dxh = tt.task[k].dxh;
     const float* __restrict__ zbias = tt.task[k].zbias;
     const float* __restrict__ zscale = tt.task[k].zscale;
+    const _Float16* __restrict__ KTg = reinterpret_cast<const _Float16*>(tt.task[k].KTg);
+    float* __restrict__ dxg = tt.task[k].dxg;
     constexpr int NT4 = D / 4, TPG = D / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    const int KBX = dx >> 5, KBT = (dx + D) >> 5;
+    const int KBX = dx >> 5;
     const int k_total = (dx + D) * 4 * D;       // elements per piece of K
     const int kt_total = 4 * D * D;             // elements per piece of Kh^T ([4D, D])
     const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4, wave = tid >> 6;
@@ -226,6 +228,64 @@ __global__ __launch_bounds__(NW * 64) void lnlstm_bwd_h2_kernel(const LstmBwdTas
             for (int t = 0; t < NT4; ++t) acc[t] = zvn[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    // Second phase of a task with KTg (tspgnn_lstm_bwd_task: d == dx == 64): [dxg | dxh] = dz K^T for a cell whose K^T
+    // ([4D, 2D] in two pieces, 128 KB) has no room beside K -- so it takes K's place once the workgroup's tiles are through,
+    // and the tiles' dz rows (just written, L2-hot) come back for the second GEMM.  Few rows (the vertex cell: 320 tiles at
+    // C2); the launch this replaces (tspgnn_linear_f32 on dz) cost ~11 us of launch boundary, staging and tail per step.
+    if (KTg != nullptr) {
+        if constexpr (D == 64) {
+            __syncthreads();    // every wavefront is done with K (and its dz rows are on their way: same-lane program order)
+            h2_copy_to_lds(lds_k, KTg, 4 * D * 2 * D * 4, tid, blockDim.x);
+            h2_stage_wait();
+            __syncthreads();
+            const _Float16* gh = lds_k;
+            const _Float16* gl = lds_k + (size_t)4 * D * 2 * D;
+            for (int t2 = t_beg + wave; t2 < t_end; t2 += nw) {
+                const int row = t2 * 16 + rl;
+                const bool valid = row < rows;
+                const unsigned rc = (unsigned)(valid ? row : rows - 1);
+                // dz was stored as 2^s dz' (this lane wrote exactly the elements it reads back)
+                f32x4 dzr[NT4];
+                float m = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT4; ++t) {
+                    dzr[t] = ld4(dz + (size_t)rc * 4 * D + t * 16 + g * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, __builtin_fabsf(dzr[t][r]));
+                }
+                m = max_over_lane_groups16_swap(m);
+                const int e = h2_row_exponent(m);
+                const float up = __builtin_ldexpf(1.0f, -e), down = __builtin_ldexpf(kH2InvScale, e);
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    f32x4 out[TPG], side[TPG];
+#pragma unroll
+                    for (int t = 0; t < TPG; ++t) out[t] = side[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < NT4 / 2; ++kb) {
+                        float xv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xv[j] = dzr[2 * kb + (j >> 2)][j & 3] * up;
+                        f16x8 bh, bm;
+                        split2s(xv, bh, bm);
+                        if (pass == 0) kblock_h2_side_sub<2 * TPG, 0, TPG>(out, side, gh, gl, kb, g, rl, bh, bm);
+                        else kblock_h2_side_sub<2 * TPG, TPG, TPG>(out, side, gh, gl, kb, g, rl, bh, bm);
+                    }
+                    if (valid) {
+                        const float fold = 1.0f / 2048.0f;
+                        float* dst = pass == 0 ? dxg + (size_t)rc * D : dxh + (size_t)rc * D;
+#pragma unroll
+                        for (int t = 0; t < TPG; ++t) {
+                            f32x4 v;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaf(side[t][r], fold, out[t][r]) * down;
+                            st4(dst + t * 16 + g * 4, v);
+                        }
+                    }
+                }
+            }
+        }
+    }
     // workgroup partial of the LayerNorm parameter gradients: fixed-order sum over the wavefront slabs
     __syncthreads();
     for (int i = tid; i < 10 * D; i += blockDim.x) {
@@ -272,7 +332,7 @@ static int launch_lnlstm_bwd_h2(const tspgnn_lstm_bwd_task* tasks, int n, hipStr
                         tasks[k].KT ? " with K^T" : "");
         if (need > lds_k) lds_k = need;
         const long long tiles = ((long long)tasks[k].rows + 15) / 16;
-        cost[k] = tiles * ((tasks[k].dx + D) / 32 + (tasks[k].KT ? 2 : 0) + 10);
+        cost[k] = tiles * ((tasks[k].dx + D) / 32 + (tasks[k].KT ? 2 : 0) + (tasks[k].KTg ? 5 : 0) + 10);
         tiles_all += tiles;
     }
     tt.n = n;
@@ -319,6 +379,8 @@ extern "C" int tspgnn_lnlstm_bwd_multi_h2(const tspgnn_lstm_bwd_task* tasks, int
         TSPGNN_REQUIRE(!t.uv || (t.dx == 0 && t.Zx), "lnlstm_bwd_h2: gather-init mode needs dx == 0 and Zx");
         TSPGNN_REQUIRE(!t.KT || (t.dxh && t.dx == 0), "lnlstm_bwd_h2: the fused data gradient needs dxh and dx == 0");
         TSPGNN_REQUIRE(!t.zbias || (t.zscale && !t.uv), "lnlstm_bwd_h2: zbias needs zscale and excludes gather-init mode");
+        TSPGNN_REQUIRE(!t.KTg || (d == 64 && t.dx == 64 && t.dxg && t.dxh && !t.KT && !t.uv),
+                       "lnlstm_bwd_h2: the streamed data gradient needs d == dx == 64, dxg, dxh and excludes KT / gather-init mode");
         live[n++] = t;
     }
     if (n == 0) return TSPGNN_OK;

@@ -221,6 +221,34 @@ __device__ __forceinline__ void kblock_h2_multi(f32x4 (&acc)[NP][NT], const _Flo
 
 // kblock_h2 for a B operand split by split2s: acc += (W_lo + W_hi) x B_hi, side += W_hi x B_m; the caller folds
 // acc + 2^-11 * side.  Three MFMAs per product, as kblock_h2.
+// (NT_TOTAL / T0 as in kblock_h2_sub: the column tiles [T0, T0 + NT) of a packed matrix NT_TOTAL tiles wide.  wh / wl may
+// point into LDS or -- a matrix too large to stay resident, multiplied on few rows -- into global memory: the fragment
+// reads are then 1 KB global loads served by the L2.)
+template <int NT_TOTAL, int T0, int NT, int PFW = H2_PF>
+__device__ __forceinline__ void kblock_h2_side_sub(f32x4 (&acc)[NT], f32x4 (&side)[NT], const _Float16* wh, const _Float16* wl,
+                                                   int kb, int g, int jl, const f16x8& bh, const f16x8& bm) {
+    const int off = ((kb * 4 + g) * NT_TOTAL * 16 + jl) * 8 + T0 * 128;
+    constexpr int PF = PFW < NT ? PFW : NT;
+    f16x8 ah[PF + 1], al[PF + 1];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        ah[p] = ldw(wh + off + p * 128);
+        al[p] = ldw(wl + off + p * 128);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t + PF < NT) {
+            ah[(t + PF) % (PF + 1)] = ldw(wh + off + (t + PF) * 128);
+            al[(t + PF) % (PF + 1)] = ldw(wl + off + (t + PF) * 128);
+        }
+        const f16x8 a_h = ah[t % (PF + 1)], a_l = al[t % (PF + 1)];
+        side[t] = MFMA_F16(a_h, bm, side[t]);
+        f32x4 c = acc[t];
+        c = MFMA_F16(a_l, bh, c);
+        c = MFMA_F16(a_h, bh, c);
+        acc[t] = c;
+    }
+}
 template <int NT, int PFW = H2_PF>
 __device__ __forceinline__ void kblock_h2_side(f32x4 (&acc)[NT], f32x4 (&side)[NT], const _Float16* wh, const _Float16* wl,
                                                int kb, int g, int jl, const f16x8& bh, const f16x8& bm) {

@@ -92,9 +92,12 @@ __global__ __launch_bounds__(1024) void mlp_bwd_h2_kernel(const MlpBwdTaskTableH
     const int rows = tt.task[k].rows, n_layers = tt.task[k].n_layers;
     const unsigned relu_mask = tt.task[k].relu_mask;
     const int2* __restrict__ uv = reinterpret_cast<const int2*>(tt.task[k].uv);
+    const float* __restrict__ pre_X = tt.task[k].pre_X;
+    const int pre_k = tt.task[k].pre_k;
     const int tiles_total = (rows + 15) / 16;
     const int tid = threadIdx.x, lane = tid & 63, rl = lane & 15, g = lane >> 4;
     h2_copy_to_lds(ldsw, tt.task[k].wt, n_layers * WT_BYTES, tid, blockDim.x);
+    if (pre_X != nullptr) h2_copy_to_lds(ldsw + MAXL * WT_BYTES + 16, tt.task[k].pre_wt, pre_k * D * 4, tid, blockDim.x);
     const int t_beg = (int)((long long)tiles_total * my_blk / my_grid);
     const int t_end = (int)((long long)tiles_total * (my_blk + 1) / my_grid);
     if (tid == 0) *ticket = t_beg;
@@ -110,7 +113,40 @@ __global__ __launch_bounds__(1024) void mlp_bwd_h2_kernel(const MlpBwdTaskTableH
         const unsigned rc = (unsigned)(valid ? row : rows - 1);
         const size_t rbase = (size_t)rc * D + g * 4;
         f32x4 gr[1][NT];
-        if (uv != nullptr) {
+        if (pre_X != nullptr) {
+            // dY = pre_X P^T first (tspgnn_mlp_bwd_task.pre_X): a gradient row of pre_k entries, normalised and split like
+            // the layers' own (its largest entry found in a first pass over the row, the row re-read block by block: 128
+            // registers do not hold it beside the accumulators); P^T resident in LDS behind the layers' weights
+            if constexpr (D == 64) {
+                const float* xr = pre_X + (size_t)rc * pre_k + g * 4;
+                float m = 0.f;
+                for (int i = 0; i * 16 < pre_k; ++i) {
+                    const f32x4 v = ld4(xr + i * 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) m = fmaxf(m, __builtin_fabsf(v[q]));
+                }
+                m = max_over_lane_groups16_swap(m);
+                const int e = h2_row_exponent(m);
+                const float up = __builtin_ldexpf(1.0f, -e), down = __builtin_ldexpf(kH2InvScale, e);
+                f32x4 out[NT], side[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) out[t] = side[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const _Float16* ph = reinterpret_cast<const _Float16*>(ldsw + MAXL * WT_BYTES + 16);
+                const _Float16* pl = ph + (size_t)pre_k * D;
+                for (int kb = 0; kb * 32 < pre_k; ++kb) {
+                    const f32x4 lo4 = ld4(xr + kb * 32), hi4 = ld4(xr + kb * 32 + 16);
+                    float xv[8] = {lo4[0] * up, lo4[1] * up, lo4[2] * up, lo4[3] * up, hi4[0] * up, hi4[1] * up, hi4[2] * up, hi4[3] * up};
+                    f16x8 bh, bm;
+                    split2s(xv, bh, bm);
+                    kblock_h2_side<NT>(out, side, ph, pl, kb, g, rl, bh, bm);
+                }
+                const float fold = 1.0f / 2048.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gr[0][t][q] = fmaf(side[t][q], fold, out[t][q]) * down;
+            }
+        } else if (uv != nullptr) {
             const int2 ends = uv[rc];
             const float* pu = dY + (size_t)ends.x * D + g * 4;
             const float* pv = dY + (size_t)ends.y * D + g * 4;
@@ -191,7 +227,7 @@ static int launch_mlp_bwd_h2(const tspgnn_mlp_bwd_task* tasks, int n, hipStream_
         if (tt.task[k].acts && tt.task[k].acts_stride == 0) tt.task[k].acts_stride = (long long)tasks[k].rows * D;
         if (tt.task[k].dpre && tt.task[k].dpre_stride == 0) tt.task[k].dpre_stride = (long long)tasks[k].rows * D;
         const long long tiles = ((long long)tasks[k].rows + 15) / 16;
-        cost[k] = tiles * tasks[k].n_layers;
+        cost[k] = tiles * (tasks[k].n_layers + (tasks[k].pre_X ? (tasks[k].pre_k + 63) / 64 : 0));
         total += cost[k];
         tiles_all += tiles;
     }
@@ -208,7 +244,10 @@ static int launch_mlp_bwd_h2(const tspgnn_mlp_bwd_task* tasks, int n, hipStream_
         used += bk;
         tt.blk_end[k] = used;
     }
-    const int lds_bytes = MAXL * 2 * D * D * 2 + 16;
+    int pre_bytes = 0;
+    for (int k = 0; k < n; ++k)
+        if (tasks[k].pre_X && tasks[k].pre_k * D * 4 > pre_bytes) pre_bytes = tasks[k].pre_k * D * 4;
+    const int lds_bytes = MAXL * 2 * D * D * 2 + 16 + pre_bytes;
     const bool abf = tasks[0].acts_bf16 != 0;
     const void* fn = abf ? reinterpret_cast<const void*>(&mlp_bwd_h2_kernel<D, MAXL, true>)
                          : reinterpret_cast<const void*>(&mlp_bwd_h2_kernel<D, MAXL, false>);
@@ -492,7 +531,9 @@ extern "C" int tspgnn_mlp_bwd_multi_h2(const tspgnn_mlp_bwd_task* tasks, int n_t
         if (d == 128 && t.n_layers > 2)
             return fail(TSPGNN_EUNSUPPORTED, "mlp_bwd_h2: d=128 holds at most 2 layers in LDS (got %d)", t.n_layers);
         if (t.rows == 0) continue;
-        TSPGNN_REQUIRE(t.dY && t.wt, "mlp_bwd_h2: null pointer");
+        TSPGNN_REQUIRE((t.dY || t.pre_X) && t.wt, "mlp_bwd_h2: null pointer");
+        TSPGNN_REQUIRE(!t.pre_X || (d == 64 && t.pre_wt && !t.uv && t.pre_k >= 32 && t.pre_k <= 256 && t.pre_k % 32 == 0),
+                       "mlp_bwd_h2: pre_X needs d == 64, pre_wt, no uv and pre_k in 32..256 (a multiple of 32), got %d", t.pre_k);
         const unsigned inner = t.relu_mask & ((1u << (t.n_layers - 1)) - 1u);
         TSPGNN_REQUIRE(!inner || t.acts, "mlp_bwd_h2: relu layers need the saved activations");
         TSPGNN_REQUIRE(!((t.relu_mask >> (t.n_layers - 1)) & 1u) || t.Yout, "mlp_bwd_h2: relu on the last layer needs Yout");

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSPGNN_LIB") or os.path.join(_HERE, "libtspgnn.so")   # (TSPGNN_LIB: A/B builds)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_int, c_uint, c_float, c_void_p, c_char_p, c_longlong = (ctypes.c_int, ctypes.c_uint, ctypes.c_float,
                                                           ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong)
@@ -171,14 +171,16 @@ class LstmBwdTask(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("dx", c_int), ("h", c_void_p), ("c", c_void_p), ("K", c_void_p), ("ln", c_void_p),
                 ("dh_out", c_void_p), ("dc_out", c_void_p), ("dz", c_void_p), ("dc_in", c_void_p), ("ln_grad", c_void_p),
                 ("workspace", c_void_p), ("rows", c_int), ("uv", c_void_p), ("Zx", c_void_p),
-                ("KT", c_void_p), ("dxh", c_void_p), ("defer_reduce", c_int), ("zbias", c_void_p), ("zscale", c_void_p)]
+                ("KT", c_void_p), ("dxh", c_void_p), ("defer_reduce", c_int), ("zbias", c_void_p), ("zscale", c_void_p),
+                ("KTg", c_void_p), ("dxg", c_void_p)]
 
 
 class MlpBwdTask(ctypes.Structure):
     """tspgnn_mlp_bwd_task (include/tspgnn.h)."""
     _fields_ = [("dY", c_void_p), ("wt", c_void_p), ("acts", c_void_p), ("acts_stride", c_longlong), ("Yout", c_void_p),
                 ("dpre", c_void_p), ("dpre_stride", c_longlong), ("dX", c_void_p), ("accumulate_dx", c_int),
-                ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint), ("uv", c_void_p), ("acts_bf16", c_int)]
+                ("rows", c_int), ("n_layers", c_int), ("relu_mask", c_uint), ("uv", c_void_p), ("acts_bf16", c_int),
+                ("pre_X", c_void_p), ("pre_wt", c_void_p), ("pre_k", c_int)]
 
 
 class MlpBwdRcTask(ctypes.Structure):

@@ -509,12 +509,32 @@ class LayerNormBasicLSTMCell(object):
                                  else out.copy_(_center_gates(self.pushed_kernel(mlp)[1], d)))
         return packed, zb_c
 
-    def pushed_backward_task(self, x, h, c, dh_out, dc_out, dz, dc_in, ws, kp, zb, deg, defer=False):
+    def pushed_backward_task(self, x, h, c, dh_out, dc_out, dz, dc_in, ws, kp, zb, deg, defer=False, data=None):
         """Backward task (tspgnn_lnlstm_bwd_multi_h2) of pushed_task: K = pushed_bias_pack's f16x2 K', z restarts at
-        deg * zb."""
+        deg * zb.  ``data`` = (f16x2 packing of K'^T, dx_out, dh_in): the data gradient [dx_out | dh_in] = dz K'^T formed in
+        the same launch (tspgnn_lstm_bwd_task.KTg) instead of by pushed_backward_data."""
+        ktg, dx_out, dh_in = data if data is not None else (None, None, None)
         return _lib.LstmBwdTask(_lib.ptr(x), self.dx, _lib.ptr(h), _lib.ptr(c), _lib.ptr(kp), _lib.ptr(self.ln()),
                                 _lib.ptr(dh_out), _lib.ptr(dc_out), _lib.ptr(dz), _lib.ptr(dc_in), _lib.ptr(self.ln_grad()),
-                                _lib.ptr(ws), h.shape[0], None, None, None, None, 1 if defer else 0, _lib.ptr(zb), _lib.ptr(deg))
+                                _lib.ptr(ws), h.shape[0], None, None, None, _lib.ptr(dh_in), 1 if defer else 0, _lib.ptr(zb),
+                                _lib.ptr(deg), _lib.ptr(ktg), _lib.ptr(dx_out))
+
+    def pushed_kernel_t_h2(self, mlp):
+        """f16x2 packing of K'^T ([4d, dx+d], K' of pushed_kernel): the weight operand of the data gradient formed inside
+        tspgnn_lnlstm_bwd_multi_h2 (tspgnn_lstm_bwd_task.KTg)."""
+        last = mlp.layer_names[-1]
+
+        def build(out):
+            KT = self.pushed_kernel(mlp)[0].t().contiguous()
+            if out is None:
+                out = torch.empty(SPLIT_BYTES["h2"] * KT.numel(), dtype=torch.uint8, device=KT.device)
+            _pack_split(self.store, "h2", KT, out, 4 * self.d, self.dx + self.d)
+            return out
+        return self.store.packed(("lstm.pushed.kT.h2", self.base, last), build)
+
+    def fuses_pushed_data_gradient(self):
+        """The pushed cell's data gradient can ride in its backward launch (f16x2, d == dx == 64)."""
+        return self.d == 64 and self.dx == 64 and os.environ.get("TSPGNN_FUSE_DATA_GRADIENTS", "1") != "0"
 
     def pushed_backward_data(self, mlp, dz, dx_out, dh_in):
         """[d(aggregate) | dh] = dz K'^T."""
@@ -670,13 +690,21 @@ class LayerNormBasicLSTMCell(object):
         _lib.call("tspgnn_linear_f32", _lib.ptr(dz), 4 * self.d, _lib.ptr(self.kernel_t_packed()), _lib.ptr(dx_out),
                   self.dx, _lib.ptr(dh_in), self.d, 0, dz.shape[0], _lib.current_stream())
 
+    def kx_t_packed_h2(self):
+        """f16x2 packing of Kx^T ([4d, dx]): dy = dZx Kx^T inside the source MLP's backward launch
+        (tspgnn_mlp_bwd_task.pre_X)."""
+        return self._packed_h2_t("lstm.kxT", 0, self.dx)
+
     def gather_backward_data(self, adj, dz, dh_in, dzx, dy):
-        """dh = dz Kh^T (unless the cell launch already formed it: dh_in None), dZx = EV^T dz, dy = dZx Kx^T."""
+        """dh = dz Kh^T (unless the cell launch already formed it: dh_in None), dZx = EV^T dz, dy = dZx Kx^T (``dy`` None:
+        left to the source MLP's backward launch)."""
         st = _lib.current_stream()
         if dh_in is not None:
             _lib.call("tspgnn_linear_f32", _lib.ptr(dz), 4 * self.d, _lib.ptr(self.kh_t_packed()), None, 0, _lib.ptr(dh_in),
                       self.d, 0, dz.shape[0], st)
         adj.matmul(dz, transpose=True, out=dzx)
+        if dy is None:
+            return
         _lib.call("tspgnn_linear_f32", _lib.ptr(dzx), 4 * self.d, _lib.ptr(self.kx_t_packed()), None, 0, _lib.ptr(dy),
                   self.dx, 0, dzx.shape[0], st)
 
@@ -2045,6 +2073,19 @@ class GraphNN(object):
 
         dH = {v: (dstates.get(v, (None, None))[0]) for v in self.var}
         dC = {v: (dstates.get(v, (None, None))[1]) for v in self.var}
+        # The vertex side's two data-gradient GEMMs ride in the step's two backward launches (TSPGNN_FUSE_DATA_GRADIENTS=0: as
+        # launches of their own): a pushed cell's [d(aggregate) | dh] = dz K'^T as a second phase of its backward task,
+        # a folded cell's dy = dZx Kx^T as the head of its source MLP's chain
+        fuse_data = bwd_arith == "h2" and not native and os.environ.get("TSPGNN_FUSE_DATA_GRADIENTS", "1") != "0"
+        fused_data = {v: bool(fuse_data and pushed[v] and self._RNN_cells[v].fuses_pushed_data_gradient()) for v in self.var}
+        projected = {}
+        for v in self.var:
+            u0 = self.loop[v][0]
+            projected[v] = bool(
+                fuse_data and folded[v] is not None and len(self.loop[v]) == 1 and "msg" in u0 and "fun" not in u0
+                and not rc.get((v, 0)) and not pushed[v] and self.mlp_backward_h2 and T > 0
+                and self._msg_MLPs[u0["msg"]].backward_task_takes_projection(tape.acts_at((v, 0), 0)[0],
+                                                                              4 * self._RNN_cells[v].d))
         for t in range(T - 1, -1, -1):
             k = t % CH      # slot of step t in the chunk buffers (chunks start at multiples of CH)
             ndH = {v: torch.empty((n[v], d), **f32) for v, d in self.var.items()}
@@ -2069,8 +2110,11 @@ class GraphNN(object):
                                                      ws[v], dh_in=ndH[v], defer=True, arith=bwd_arith)
                 elif pushed[v]:
                     kp, zb = cell.pushed_bias_pack(push[v]["mlp"], arith="h2")
+                    # (d == dx == 64: [d(aggregate) | dh] = dz K'^T rides in this launch as a second phase of the task's
+                    # workgroups -- one launch less per step)
+                    data = (cell.pushed_kernel_t_h2(push[v]["mlp"]), dX[v], ndH[v]) if fused_data[v] else None
                     task = cell.pushed_backward_task(tape.x(v, t), h_t, c_t, dH[v], dC[v], DZ[v][k], ndC[v], ws[v], kp, zb,
-                                                     push[v]["deg"], defer=True)
+                                                     push[v]["deg"], defer=True, data=data)
                 else:
                     x_t = tape.x(v, t)
                     keep += [h_t, x_t]
@@ -2089,9 +2133,11 @@ class GraphNN(object):
                     cell.backward_data_bf16(DZ[v][k], dX[v], ndH[v])
                 elif folded[v] is not None:   # dX[v] becomes the gradient w.r.t. the message y (source rows)
                     cell.gather_backward_data(mats[folded[v]["mat"]], DZ[v][k], None if cell.d == 64 else ndH[v],
-                                              DZX[v][k], dX[v])   # (d == 64: dh was formed by the cell launch)
+                                              DZX[v][k], None if projected[v] else dX[v])
+                    # (d == 64: dh was formed by the cell launch; projected: dy = dZx Kx^T is left to the message MLP's launch)
                 elif pushed[v]:             # dX[v] becomes the gradient w.r.t. the aggregated last hidden activation
-                    cell.pushed_backward_data(push[v]["mlp"], DZ[v][k], dX[v], ndH[v])
+                    if not fused_data[v]:
+                        cell.pushed_backward_data(push[v]["mlp"], DZ[v][k], dX[v], ndH[v])
                 else:
                     cell.backward_data(DZ[v][k], dX[v], ndH[v])
             # ---- 3: adjoint adjacency products, then every message MLP's data gradient in one launch
@@ -2147,6 +2193,16 @@ class GraphNN(object):
                         (acts_t, acts_stride), dpre = tape.acts_at((v, i), t), DPRE[(v, i)]
                         keep.append(acts_t)
                         h2 = bool((bwd_arith == "h2" or mlp_h2_native) and self.mlp_backward_h2 and mlp.backward_h2_ok(acts_t))
+                        if projected[v]:   # the chain starts from dZx Kx^T, formed inside the launch
+                            cell = self._RNN_cells[v]
+                            if src not in targets:
+                                task = mlp.backward_task(None, acts_t, acts_stride, None, dpre[:, k], dpre.stride(0), ndH[src],
+                                                         True, h2=True, pre=(DZX[v][k], cell.kx_t_packed_h2()))
+                                mlp_tasks.append(((self.var[src], True), task, None))
+                                targets.append(src)
+                                continue
+                            _lib.call("tspgnn_linear_f32", _lib.ptr(DZX[v][k]), 4 * cell.d, _lib.ptr(cell.kx_t_packed()), None, 0,
+                                      _lib.ptr(dy), cell.dx, 0, DZX[v][k].shape[0], _lib.current_stream())
                         if pushed[v]:   # the chain ends at the last hidden activation (a relu layer: masked by its output)
                             task = mlp.backward_prefix_task(dpre.shape[0], dy, acts_t, acts_stride, acts_t[dpre.shape[0] - 1],
                                                             dpre[:, k], dpre.stride(0), ndH[src], True, gather_uv=gather_uv, h2=h2)

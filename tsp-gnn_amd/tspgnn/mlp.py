@@ -317,18 +317,31 @@ class Mlp(object):
         kind, d, n_sq, head = self._plan
         return kind == "square" and d in (64, 128)
 
-    def backward_task(self, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, gather_uv=None, h2=False):
+    def backward_task(self, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, gather_uv=None, h2=False,
+                      pre=None):
         """An _lib.MlpBwdTask for a single-kernel chain (None if several kernels are needed).
         ``gather_uv`` (int32 [rows,2]): dY holds SOURCE rows and the chain starts from dY[u] + dY[v] per row.
-        ``h2``: the task is for tspgnn_mlp_bwd_multi_h2 (weights in the f16x2 packing of W^T)."""
+        ``h2``: the task is for tspgnn_mlp_bwd_multi_h2 (weights in the f16x2 packing of W^T).
+        ``pre`` = (X [rows, k], f16x2 packing of P^T [k, d]), h2 only: the chain starts from X P^T and dY is not read
+        (tspgnn_mlp_bwd_task.pre_X)."""
         kind, d, n_sq, head = self._plan
         if len(self._chunks()) != 1:
             return None
         wt = self.wt_packed_h2(0, n_sq - 1, d) if h2 else self.wt_packed(0, n_sq - 1, d)
+        if pre is not None:
+            return _lib.MlpBwdTask(None, _lib.ptr(wt), _lib.ptr(acts), acts_stride, _lib.ptr(y_out), _lib.ptr(dpre),
+                                   dpre_stride, _lib.ptr(dX), 1 if accumulate else 0, pre[0].shape[0], n_sq,
+                                   self.relu_mask(0, n_sq), None, _bf16_flag(acts), _lib.ptr(pre[0]), _lib.ptr(pre[1]),
+                                   pre[0].shape[1])
         return _lib.MlpBwdTask(_lib.ptr(dY), _lib.ptr(wt), _lib.ptr(acts), acts_stride,
                                _lib.ptr(y_out), _lib.ptr(dpre), dpre_stride, _lib.ptr(dX), 1 if accumulate else 0,
                                dY.shape[0] if gather_uv is None else gather_uv.shape[0], n_sq, self.relu_mask(0, n_sq),
                                _lib.ptr(gather_uv), _bf16_flag(acts))
+
+    def backward_task_takes_projection(self, acts, k):
+        """backward_task(..., pre=...) is available (tspgnn_mlp_bwd_multi_h2 at width 64, one kernel, fp32 tape)."""
+        return self.sizes[-1] == 64 and len(self._chunks()) == 1 and self.backward_h2_ok(acts) and k % 32 == 0 \
+            and 32 <= k <= 256 and acts.dtype == torch.float32
 
     def backward_prefix_task(self, n_layers, dY, acts, acts_stride, y_out, dpre, dpre_stride, dX, accumulate, gather_uv=None,
                              h2=False):
