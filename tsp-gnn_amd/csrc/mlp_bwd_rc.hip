@@ -237,11 +237,29 @@ static int launch_mlp_bwd_h2(const tspgnn_mlp_bwd_task* tasks, int n, hipStream_
     const long long max_grid = (tiles_all + threads / 64 - 1) / (threads / 64);
     if (grid > max_grid) grid = (int)max_grid;
     if (grid < n) grid = n;
-    int used = 0;
-    for (int k = 0; k < n; ++k) {   // workgroups in proportion to tiles x layers, at least one each
+    // workgroups in proportion to tiles x layers, at least one each -- and never more than one wavefront per tile can use (a
+    // small task with a long chain, e.g. the vertex side with its projection head: the surplus goes to the largest task)
+    int bks[kMaxTasksBwdH2], used = 0, big = 0;
+    for (int k = 0; k < n; ++k) {
         int bk = (int)((cost[k] * grid + total / 2) / (total > 0 ? total : 1));
+        const long long tiles = ((long long)tasks[k].rows + 15) / 16;
+        const int useful = (int)((tiles + threads / 64 - 1) / (threads / 64));
+        if (bk > useful) bk = useful;
         if (bk < 1) bk = 1;
+        bks[k] = bk;
         used += bk;
+        if (cost[k] > cost[big]) big = k;
+    }
+    if (used < grid) {
+        const long long tiles = ((long long)tasks[big].rows + 15) / 16;
+        const int useful = (int)((tiles + threads / 64 - 1) / (threads / 64));
+        int add = grid - used;
+        if (bks[big] + add > useful) add = useful > bks[big] ? useful - bks[big] : 0;
+        bks[big] += add;
+    }
+    used = 0;
+    for (int k = 0; k < n; ++k) {
+        used += bks[k];
         tt.blk_end[k] = used;
     }
     int pre_bytes = 0;
