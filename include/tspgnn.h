@@ -232,6 +232,12 @@ int tspgnn_lnlstm_mlp_fwd_multi_x3(const tspgnn_cell_mlp_task* tasks, int n_task
 #define TSPGNN_H2_WEIGHT_SCALE_LOG2 6
 float tspgnn_h2_weight_scale(void);   /* 2^TSPGNN_H2_WEIGHT_SCALE_LOG2 */
 int tspgnn_pack_weights_h2(const float* W, void* P, int krows, int ncols, unsigned* absmax_bits, void* stream);
+/* Every square layer of an MLP in one launch, from the variables' own layout wb = n_layers blocks {W[d,d], b[d]} (mlp.py:57-63's
+ * Dense layers as a flat parameter vector holds them): transposed == 0 -> out = n_layers blocks {tspgnn_pack_weights_h2(W_l)
+ * [4 d d bytes], 2^s b_l [4 d bytes]} = tspgnn_mlp_task.wb of the _h2 entry points; transposed != 0 -> out = n_layers blocks
+ * tspgnn_pack_weights_h2(W_l^T) [4 d d bytes] = tspgnn_mlp_bwd_task.wt.  absmax_bits as tspgnn_pack_weights_h2.  A training
+ * step repacks after every optimiser step: one launch per MLP and direction instead of three per layer. */
+int tspgnn_pack_mlp_h2(const float* wb, void* out, int d, int n_layers, int transposed, unsigned* absmax_bits, void* stream);
 int tspgnn_mlp_fwd_multi_h2(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream);
 /* One task followed by a Dense(1) head on the rows in hand (the vote MLP of model.py:107-115,128: three relu layers and
  * a linear d -> 1): y[r] = <out row r, head_w[d]> + head_b[0] in fp32, where `out` is what tspgnn_mlp_fwd_multi_h2

@@ -763,3 +763,27 @@ def test_mlp_backward_h2_projected_head(cuda_device, rows, k):
     # the f32 entry point refuses the field
     with pytest.raises(_lib.TspgnnError):
         _lib.call_multi("tspgnn_mlp_bwd_multi_f32", [task], d)
+
+
+@pytest.mark.parametrize("d,L", [(64, 4), (32, 3), (128, 2), (64, 1)])
+def test_pack_mlp_h2_equals_the_per_layer_packings(cuda_device, d, L):
+    """tspgnn_pack_mlp_h2: every layer of an MLP in one launch from the flat {W, b} blocks -- byte for byte what
+    tspgnn_pack_weights_h2 per layer plus the scaled bias give (forward form), and what it gives on W^T (backward form);
+    the range-guard word ends at the same maximum."""
+    rng = np.random.RandomState(d + L)
+    Ws = [(rng.randn(d, d) / np.sqrt(d)).astype(np.float32) for _ in range(L)]
+    bs = [rng.randn(d).astype(np.float32) for _ in range(L)]
+    flat = dev(np.concatenate([np.concatenate([w.reshape(-1), b]) for w, b in zip(Ws, bs)]), cuda_device)
+    for transposed in (0, 1):
+        per = 4 * d * d + (0 if transposed else 4 * d)
+        out = torch.zeros(L * per, dtype=torch.uint8, device=cuda_device)
+        guard = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+        _lib.call("tspgnn_pack_mlp_h2", _lib.ptr(flat), _lib.ptr(out), d, L, transposed, _lib.ptr(guard), None)
+        ref = _h2_blocks(Ws, bs, cuda_device, transposed=bool(transposed))
+        g2 = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+        for w in Ws:
+            tmp = torch.empty(4 * d * d, dtype=torch.uint8, device=cuda_device)
+            _lib.call("tspgnn_pack_weights_h2", _lib.ptr(dev(w, cuda_device)), _lib.ptr(tmp), d, d, _lib.ptr(g2), None)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        assert int(guard.item()) == int(g2.item()) != 0

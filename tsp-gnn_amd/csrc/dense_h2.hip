@@ -70,6 +70,45 @@ __global__ __launch_bounds__(256) void pack_weights_h2_kernel(const float* __res
     }
 }
 
+// All square layers of an MLP in ONE launch (blockIdx.y = layer), straight from the variables' flat {W [d,d], b [d]} blocks:
+// forward form {pack(2^s W), 2^s b} per layer (what tspgnn_mlp_task.wb takes) or, transposed, pack(2^s W^T) back to back
+// (tspgnn_mlp_bwd_task.wt).  A training step rebuilds every packing after the optimiser has moved the variables: per layer
+// that was a pack launch, a bias scaling and a copy -- some fifty five-microsecond launches per step.
+__global__ __launch_bounds__(256) void pack_mlp_h2_kernel(const float* __restrict__ wb, unsigned char* __restrict__ out, int d,
+                                                          int transposed, unsigned* __restrict__ absmax_bits) {
+    const int l = blockIdx.y, NT = d >> 4, total = d * d;
+    const float* W = wb + (size_t)l * (total + d);
+    const size_t per = transposed ? (size_t)4 * total : (size_t)4 * total + 4 * d;
+    _Float16* P = reinterpret_cast<_Float16*>(out + (size_t)l * per);
+    unsigned mx = 0u;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i & 7, jl = (i >> 3) & 15;
+        int rest = i >> 7;
+        const int t = rest % NT;
+        rest /= NT;
+        const int g = rest & 3, kb = rest >> 2;
+        const int k = 16 * (2 * kb + (j >> 2)) + 4 * g + (j & 3), c = t * 16 + jl;
+        const float x = kH2Scale * (transposed ? W[(size_t)c * d + k] : W[(size_t)k * d + c]);
+        const _Float16 h = (_Float16)x;
+        P[i] = h;
+        P[(size_t)total + i] = (_Float16)(x - (float)h);
+        const unsigned b = __float_as_uint(x) & 0x7fffffffu;
+        mx = b > mx ? b : mx;
+    }
+    if (!transposed && blockIdx.x == 0) {
+        float* bias = reinterpret_cast<float*>(out + (size_t)l * per + (size_t)4 * total);
+        for (int f = threadIdx.x; f < d; f += blockDim.x) bias[f] = kH2Scale * W[total + f];
+    }
+    if (absmax_bits != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)mx, off);
+            mx = o > mx ? o : mx;
+        }
+        if ((threadIdx.x & 63) == 0 && mx != 0u) atomicMax(absmax_bits, mx);
+    }
+}
+
 constexpr int kMaxTasksH2 = 4;
 
 // ---------------------------------------------------------------------------------- MLP (f16x2)
@@ -700,6 +739,19 @@ extern "C" int tspgnn_pack_weights_h2(const float* W, void* P, int krows, int nc
     if (grid > 1024) grid = 1024;
     pack_weights_h2_kernel<<<grid, 256, 0, as_stream(stream)>>>(W, reinterpret_cast<_Float16*>(P), krows, ncols, absmax_bits);
     return launched("tspgnn_pack_weights_h2");
+}
+
+extern "C" int tspgnn_pack_mlp_h2(const float* wb, void* out, int d, int n_layers, int transposed, unsigned* absmax_bits,
+                                  void* stream) {
+    TSPGNN_REQUIRE(d > 0 && d % 32 == 0, "pack_mlp_h2: d=%d must be a positive multiple of 32", d);
+    TSPGNN_REQUIRE(n_layers >= 0 && n_layers <= 64, "pack_mlp_h2: n_layers=%d", n_layers);
+    if (n_layers == 0) return TSPGNN_OK;
+    TSPGNN_REQUIRE(wb && out, "pack_mlp_h2: null pointer");
+    int gx = (d * d + 255) / 256;
+    if (gx > 64) gx = 64;
+    pack_mlp_h2_kernel<<<dim3(gx, n_layers), 256, 0, as_stream(stream)>>>(wb, reinterpret_cast<unsigned char*>(out), d,
+                                                                          transposed ? 1 : 0, absmax_bits);
+    return launched("tspgnn_pack_mlp_h2");
 }
 
 extern "C" int tspgnn_mlp_fwd_multi_h2(const tspgnn_mlp_task* tasks, int n_tasks, int d, void* stream) {

@@ -38,6 +38,7 @@ SIGNATURES = {
     "tspgnn_lnlstm_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_lnlstm_mlp_fwd_multi_x3": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_pack_weights_h2": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "tspgnn_pack_mlp_h2": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "tspgnn_mlp_fwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],
     "tspgnn_mlp_head_fwd_h2": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "tspgnn_lnlstm_fwd_multi_h2": [c_void_p, c_int, c_int, c_void_p],

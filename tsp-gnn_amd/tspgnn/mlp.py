@@ -136,6 +136,10 @@ class Mlp(object):
             if out is None:
                 out = torch.empty((last - first + 1) * per, dtype=torch.uint8, device=src.device)
             st = _lib.current_stream()
+            if arith == "h2":      # every layer, weights and scaled biases, in one launch
+                _lib.call("tspgnn_pack_mlp_h2", _lib.ptr(src), _lib.ptr(out), d, last - first + 1, 0,
+                          self.store.h2_absmax_ptr(), st)
+                return out
             for j in range(last - first + 1):
                 o, q = j * per_src, j * per
                 if arith == "h2":
@@ -198,11 +202,8 @@ class Mlp(object):
         def build(out):
             if out is None:
                 out = torch.empty((last - first + 1) * 4 * d * d, dtype=torch.uint8, device=self.store.theta.device)
-            st = _lib.current_stream()
-            for j in range(last - first + 1):
-                Wt = self.store.view(self.layer_names[first + j] + "/kernel").t().contiguous()
-                _lib.call("tspgnn_pack_weights_h2", _lib.ptr(Wt), _lib.ptr(out[j * 4 * d * d:(j + 1) * 4 * d * d]), d, d,
-                          self.store.h2_absmax_ptr(), st)     # (max |2^s W| joins the store's range guard)
+            _lib.call("tspgnn_pack_mlp_h2", _lib.ptr(self.wb(first, last)), _lib.ptr(out), d, last - first + 1, 1,
+                      self.store.h2_absmax_ptr(), _lib.current_stream())     # (max |2^s W| joins the store's range guard)
             return out
         return self.store.packed(("mlpT.h2", self.name, first, last), build)
 
