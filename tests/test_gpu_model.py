@@ -935,6 +935,36 @@ def test_recomputed_training_gradients_equal_the_taped_form(cuda_device, name, d
         assert np.abs(gr[k] - gt[k]).max() / scale < 1e-4, k
 
 
+@pytest.mark.parametrize("name,d,T", [("ragged_B6", 64, 4), ("n20_B32", 64, 5), ("n5_B2", 64, 1)])
+def test_data_gradient_gemms_inside_the_backward_launches_equal_their_own_launches(cuda_device, monkeypatch, name, d, T):
+    """The backward step with the vertex side's two data-gradient GEMMs riding in the cell and message-MLP launches
+    (tspgnn_lstm_bwd_task.KTg, tspgnn_mlp_bwd_task.pre_X: the default) against TSPGNN_FUSE_DATA_GRADIENTS=0, where each is a
+    tspgnn_linear_f32 launch on the fp32 matrix instruction: same loss, gradients equal up to the arithmetic of those two
+    GEMMs (fp16 matrix cores on scaled splits)."""
+    t = pack_tuple(name, 1)
+    params = P.init_params(d, seed=8, perturb=True)
+    grads = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("TSPGNN_FUSE_DATA_GRADIENTS", fuse)
+        model = tspgnn.build_network(d)
+        sess = tspgnn.Session(model)
+        sess.run(tspgnn.global_variables_initializer())
+        model.store.load(params)
+        EV, W, C, route_exists, n_vertices, n_edges = t
+        feed = {model["EV"]: EV, model["W"]: W, model["C"]: C, model["time_steps"]: T,
+                model["route_exists"]: route_exists, model["n_vertices"]: n_vertices, model["n_edges"]: n_edges}
+        out = sess.loss_and_grads(feed)
+        torch.cuda.synchronize()
+        grads.append((float(out["stats"][0].item()), model.store.grad_dict()))
+    (loss_f, gf), (loss_u, gu) = grads
+    assert loss_f == loss_u
+    gscale = max(np.abs(gu[k]).max() for k in gu)
+    for k in gu:
+        scale = max(np.abs(gu[k]).max(), 1e-3 * gscale)
+        assert np.abs(gf[k] - gu[k]).max() / scale < 2e-5, k
+    assert any(not np.array_equal(gf[k], gu[k]) for k in gu)      # (the switch does switch something)
+
+
 def test_weight_gradient_chunks_agree(cuda_device):
     """GraphNN.backward reduces the weight gradients per chunk of time steps (all T when they fit the budget): one,
     two and five chunks give the same gradients up to the order of the fp32 sums."""

@@ -24,10 +24,10 @@ steps = 8      # training steps in the profiled run (5 timed + 2 warm-up + 1 cap
 
 # (pattern, grid or None, bytes per launch, formula)
 SPEC = [
-    ("lnlstm_bwd_h2_kernel", None, M * R * (4 + 4 + 2) + N * 4 * R + M * 8 + N * R * (5 + 4 + 1),
-     "E cell: h, c, dh', dc' read + dz [M,4d] + dc, dh written (10 rows of d per edge row) + Zx [N,4d] + uv; V cell: x, h, c, dh', dc' + dz + dc"),
-    ("tspgnn::mlp_bwd_h2_kernel", None, M * R * (3 + 3 + 2) + N * R * (1 + 3 + 3 + 2),
-     "E_msg_V (pushed: 3 layers on M rows): 3 saved activations read, 3 dpre written, dh read + written; dy gathered from [N,d]; V_msg_E on N rows alike"),
+    ("lnlstm_bwd_h2_kernel", None, M * R * (4 + 4 + 2) + N * 4 * R + M * 8 + N * R * (5 + 4 + 1 + 4 + 2),
+     "E cell: h, c, dh', dc' read + dz [M,4d] + dc, dh written (10 rows of d per edge row) + Zx [N,4d] + uv; V cell: x, h, c, dh', dc' + dz + dc, and its second phase: dz back in, [d(agg) | dh] out"),
+    ("tspgnn::mlp_bwd_h2_kernel", None, M * R * (3 + 3 + 2) + N * R * (4 + 3 + 4 + 2),
+     "E_msg_V (pushed: 3 layers on M rows): 3 saved activations read, 3 dpre written, dh read + written; d(agg) gathered from [N,d]; V_msg_E on N rows: dZx [N,4d] in (projection head), 3 activations, 4 dpre, dh"),
     ("lnlstm_mlp_fwd_h2_kernel<64, false", None, M * R * (2 + 2 + 3) + N * 4 * R + M * 8 + N * R * (3 + 2 + 3),
      "training forward cell + next messages: h, c read, h', c' written, 3 taped activations written per edge row; Zx gather; vertex side alike"),
     ("csr_rowsum_kernel<16, false, 4>", None, M * 4 * R + N * 4 * R + (2 * M + N + 1) * 4,
@@ -59,4 +59,4 @@ for pat, grid, nbytes, what in SPEC:
                                                                    nbytes / avg / 1e6 / 8, what))
             break
 tot = sum(c * a for _, _, c, a, _, _, _ in rows) / steps / 1e3
-print("# sum of all kernels: %.2f ms per training step under the profiler (bench: 10.9-11.3 ms)" % tot)
+print("# sum of all kernels: %.2f ms per training step under the profiler (bench line of the same set: profiles/%s_c2_train_bench.json)" % (tot, rnd))
