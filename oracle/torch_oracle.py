@@ -236,10 +236,14 @@ def vote_head(params, batch, E_n):
         "FN": ((1 - labels) * ne).sum(),
         "acc": eq.mean(),
     }
-    # tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log1p(exp(-|x|))
-    x, z = logits, labels
-    out["loss"] = (torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-x.abs()))).mean()
+    out["loss"] = sigmoid_cross_entropy_with_logits(logits, labels).mean()
     return out
+
+
+def sigmoid_cross_entropy_with_logits(x, z):
+    """tf.nn.sigmoid_cross_entropy_with_logits (model.py:147): z * -log(sigmoid(x)) + (1 - z) * -log(1 - sigmoid(x)) in the
+    form TensorFlow documents and evaluates, max(x, 0) - x * z + log(1 + exp(-|x|))."""
+    return torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-x.abs()))
 
 
 def loss_and_grads(params_np, batch, time_steps, dtype=torch.float64, dense=False, bf16=False):

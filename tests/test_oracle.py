@@ -271,3 +271,29 @@ def test_adam_reproduces_tensorflow_adam_test_basic():
     assert np.allclose(p["var0"], [0.997, 1.997], atol=1e-6) and np.allclose(p["var1"], [2.997, 3.997], atol=1e-6)
     # and the first step is NOT lr * g: Adam's first move is lr * sign(g) (up to epsilon) whatever the gradient's size
     assert abs((1.0 - 0.997) / 3 - lr) < 1e-7
+
+
+def test_sigmoid_cross_entropy_follows_tensorflows_documented_form():
+    """tf.nn.sigmoid_cross_entropy_with_logits as TensorFlow's API page defines it -- z * -log(sigmoid(x)) + (1 - z) *
+    -log(1 - sigmoid(x)), evaluated as max(x, 0) - x z + log(1 + exp(-|x|)) "to ensure stability and avoid overflow" -- on
+    closed-form values (x = 0: log 2 whatever the label; x = 1, z = 1: log(1 + 1/e)) and where the naive form breaks
+    (|x| = 50, 800); the loss the HIP path is compared with (model.py:147) goes through this function."""
+    import math
+    f = TO.sigmoid_cross_entropy_with_logits
+    t = lambda *v: torch.tensor(v, dtype=torch.float64)
+    got = f(t(0.0, 0.0, 1.0, -2.0, 2.0), t(0.0, 1.0, 1.0, 1.0, 0.0)).numpy()
+    want = [math.log(2.0), math.log(2.0), math.log1p(math.exp(-1.0)), 2.0 + math.log1p(math.exp(-2.0)), 2.0 + math.log1p(math.exp(-2.0))]
+    assert np.abs(got - np.array(want)).max() < 1e-15
+    assert abs(want[2] - 0.31326168751822286) < 1e-15 and abs(want[3] - 2.1269280110429727) < 1e-15
+    x = t(-50.0, 50.0, -800.0, 800.0, 3.7, -0.4)
+    for z in (0.0, 1.0):
+        zz = torch.full_like(x, z)
+        sig = torch.sigmoid(x)
+        with np.errstate(divide="ignore"):
+            naive = zz * -torch.log(sig) + (1 - zz) * -torch.log1p(-sig)
+        got = f(x, zz)
+        assert torch.isfinite(got).all()
+        ok = torch.isfinite(naive) & (x.abs() < 30)
+        assert (got[ok] - naive[ok]).abs().max() < 1e-12
+        # the saturated ends: the loss is |x| on the wrong side of the label, ~0 on the right side
+        assert abs(float(got[2]) - (800.0 if z == 1.0 else 0.0)) < 1e-12 and abs(float(got[3]) - (0.0 if z == 1.0 else 800.0)) < 1e-12
