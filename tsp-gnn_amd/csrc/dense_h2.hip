@@ -700,19 +700,22 @@ static int launch_cell_h2(const tspgnn_cell_mlp_task* tasks, int n, hipStream_t 
             grid = used;
         }
     }
-    bool centered = true;
+    bool centered = true, loop_buffers = false;
     long long out_bytes = 0;   // h', c' of every task and its messages: what the launch stores (and the next ones re-read)
     for (int k = 0; k < n; ++k) {
         centered = centered && tasks[k].cell.z_centered != 0;
         out_bytes += (long long)tasks[k].cell.rows * D * 4 * (tasks[k].mlp_out ? 3 : 2);
+        loop_buffers = loop_buffers || tasks[k].state_out_blocked != 0 || tasks[k].mlp_out != nullptr || tasks[k].proj_out != nullptr;
     }
     // write-through output stores while the loop's arrays (two copies of the states, two of the messages: ~2x out_bytes)
-    // stay inside the 256 MB Infinity Cache; plain stores beyond (see st4o)
+    // stay inside the 256 MB Infinity Cache; plain stores beyond (see st4o) -- and for a launch that writes nothing the next
+    // step's launch reads from these buffers (no blocked state, no messages: the training forward's cell launch stores
+    // into the tape, which the backward reads much later -- C2 training step 10.25-10.27 -> 10.12-10.16 ms)
     static const int wt_forced = [] {   // (development switch TSPGNN_H2_WT=0/1)
         const char* e = getenv("TSPGNN_H2_WT");
         return e ? atoi(e) : -1;
     }();
-    const bool wt = wt_forced >= 0 ? wt_forced != 0 : 2 * out_bytes <= (long long)200 * 1024 * 1024;
+    const bool wt = wt_forced >= 0 ? wt_forced != 0 : (loop_buffers && 2 * out_bytes <= (long long)200 * 1024 * 1024);
     void (*fn)(const CellTaskTableH2) =
         centered ? (wt ? &lnlstm_mlp_fwd_h2_kernel<D, true, true> : &lnlstm_mlp_fwd_h2_kernel<D, true, false>)
                  : (wt ? &lnlstm_mlp_fwd_h2_kernel<D, false, true> : &lnlstm_mlp_fwd_h2_kernel<D, false, false>);
